@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the *reference* (bexcite/ptudes-lab @ /root/reference)
+in THIS container and records inputs + expected outputs as small fixtures.
+
+Run only where /root/reference exists (the build container):
+
+    python tests/golden/gen_golden.py            # regenerates every fixture
+
+The reference cannot travel to the GPU box, so the fixtures written next to this
+script are what the tests consume.  Nothing here is imported by the product.
+
+How the reference is imported: `ouster.*`, `rosbags.*` and
+`kiss_icp.*` are absent from the image, so they are replaced by MagicMock modules;
+the two SO(3) helpers the EKF takes from ouster-sdk (`exp_rot_vec`, `log_rot_mat`)
+are replaced by their mathematical definition via scipy.  Python 3.10 is required
+(the reference's ndarray dataclass defaults are rejected by >= 3.11).
+
+Every case runs in a FRESH interpreter: the reference's `NavErrState` dataclass
+shares one class-level ndarray per field between all instances
+(ins/es_ekf.py:23-32), so a filter created after another filter's first update
+would start from a polluted error state.
+"""
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SRC = "/root/reference/src"
+
+
+def _mock_reference_deps():
+    from unittest.mock import MagicMock
+    import numpy as np
+    from scipy.spatial.transform import Rotation as R
+    sys.dont_write_bytecode = True
+    for m in ["ouster", "ouster.client", "ouster.client._client", "ouster.viz",
+              "ouster.viz.scans_accum", "ouster.pcap", "ouster.sdk", "ouster.sdk.util",
+              "ouster.sdk.pose_util", "rosbags", "rosbags.highlevel", "kiss_icp",
+              "kiss_icp.config", "kiss_icp.config.parser", "kiss_icp.registration",
+              "kiss_icp.kiss_icp"]:
+        mm = MagicMock(name=m)
+        mm.__path__ = []
+        sys.modules[m] = mm
+
+    class PacketSource:  # bag.py subclasses it, must be a real class
+        pass
+
+    sys.modules["ouster.client"].PacketSource = PacketSource
+    pu = sys.modules["ouster.sdk.pose_util"]
+    pu.exp_rot_vec = lambda v: R.from_rotvec(np.asarray(v, float)).as_matrix()
+    pu.log_rot_mat = lambda M: R.from_matrix(M).as_rotvec()
+    sys.modules["ouster"].client = sys.modules["ouster.client"]
+    sys.modules["ouster.sdk"].pose_util = pu
+    sys.path.insert(0, REF_SRC)
+    import matplotlib
+    matplotlib.use("Agg")
+
+
+def _nav_vec(nav):
+    """19 doubles: pos(3) quat_xyzw(4) vel(3) bg(3) ba(3) grav(3)"""
+    import numpy as np
+    return np.concatenate([nav.pos, nav.att_q, nav.vel, nav.bias_gyr, nav.bias_acc,
+                           nav.grav]).astype(np.float64)
+
+
+def _rand_pose(rng, trans_scale=1.0, rot_scale=0.3):
+    import numpy as np
+    from scipy.spatial.transform import Rotation as R
+    T = np.eye(4)
+    T[:3, :3] = R.from_rotvec(rng.normal(0, rot_scale, 3)).as_matrix()
+    T[:3, 3] = rng.normal(0, trans_scale, 3)
+    return T
+
+
+# ----------------------------------------------------------------------------- cases
+
+
+def case_ekf_steps(variant):
+    """Step-by-step ESEKF trace: seeded IMU stream with interleaved pose updates."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation as R
+    from ptudes.ins.es_ekf import ESEKF
+    from ptudes.ins.data import IMU, GRAV
+
+    rng = np.random.default_rng({"default": 11, "init": 12, "cov": 13}[variant])
+    n_imu, upd_every = 300, 10
+    kwargs = {}
+    if variant == "init":
+        kwargs = dict(init_grav=GRAV * np.array([0.02, -0.01, -0.9997]),
+                      init_bacc=np.array([0.05, -0.02, 0.03]),
+                      init_bgyr=np.array([0.002, -0.001, 0.0015]))
+    ekf = ESEKF(**kwargs)
+
+    # smooth-ish body motion: specific force + gyro, irregular dt
+    ts = 100.0 + np.cumsum(rng.uniform(0.008, 0.012, n_imu))
+    lacc = np.array([0, 0, GRAV]) + rng.normal(0, 0.8, (n_imu, 3))
+    avel = rng.normal(0, 0.3, (n_imu, 3))
+
+    navs = np.zeros((n_imu, 19))
+    upd_idx, upd_pose, upd_cov = [], [], []
+    navs_post = []
+    covs_pre, covs_post, covs_imu = [], [], []
+    for i in range(n_imu):
+        ekf.processImu(IMU(lacc[i].copy(), avel[i].copy(), float(ts[i])))
+        navs[i] = _nav_vec(ekf.nav)
+        if i % 25 == 0:
+            covs_imu.append(ekf._cov.copy())
+        if i > 0 and i % upd_every == 0:
+            # measured pose = current estimate perturbed (so residuals are realistic)
+            T = ekf.nav.pose_mat()
+            T[:3, 3] += rng.normal(0, 0.05, 3)
+            T[:3, :3] = T[:3, :3] @ R.from_rotvec(rng.normal(0, 0.02, 3)).as_matrix()
+            cov = None
+            if variant == "cov":
+                A = rng.normal(0, 0.03, (6, 6))
+                cov = A @ A.T + np.diag([4e-4] * 3 + [1e-4] * 3)
+            covs_pre.append(ekf._cov.copy())
+            ekf.processPose(T.copy(), None if cov is None else cov.copy())
+            covs_post.append(ekf._cov.copy())
+            navs_post.append(_nav_vec(ekf.nav))
+            upd_idx.append(i)
+            upd_pose.append(T)
+            upd_cov.append(np.zeros((6, 6)) if cov is None else cov)
+    np.savez_compressed(
+        os.path.join(HERE, f"ekf_steps_{variant}.npz"),
+        imu_ts=ts, imu_lacc=lacc, imu_avel=avel, nav_after_imu=navs,
+        upd_idx=np.array(upd_idx), upd_pose=np.array(upd_pose),
+        upd_cov=np.array(upd_cov), has_cov=np.array(variant == "cov"),
+        nav_after_upd=np.array(navs_post), cov_pre=np.array(covs_pre),
+        cov_post=np.array(covs_post), cov_imu_every25=np.array(covs_imu),
+        init_grav=np.asarray(kwargs.get("init_grav", GRAV * np.array([0, 0, -1.0]))),
+        init_bacc=np.asarray(kwargs.get("init_bacc", np.zeros(3))),
+        init_bgyr=np.asarray(kwargs.get("init_bgyr", np.zeros(3))),
+        cov0=ESEKF()._cov_init, final_ts=np.array(ekf.ts))
+
+
+def case_ekf_sim():
+    """`ptudes ekf-bench sim -t 2.0` with the legacy numpy RNG seeded to 0
+    (cli/ekf_bench.py:107-179).  Records the IMU stream the CLI drew, the final
+    states of both filters, update count and the printed ATE."""
+    import numpy as np
+    import ptudes.cli.ekf_bench as eb
+    from ptudes.ins.data import ekf_traj_ate
+
+    # capture the filters + imu stream through thin wrappers around the reference's own symbols
+    made = []
+    orig_esekf = eb.ESEKF
+
+    def mk(*a, **k):
+        f = orig_esekf(*a, **k)
+        made.append(f)
+        return f
+
+    stream = []
+    orig_sim = eb.sim_imu
+
+    def sim(**k):
+        for ideal, noisy in orig_sim(**k):
+            stream.append((ideal.ts, ideal.lacc.copy(), ideal.avel.copy(),
+                           noisy.lacc.copy(), noisy.avel.copy()))
+            yield ideal, noisy
+
+    eb.ESEKF = mk
+    eb.sim_imu = sim
+    from click.testing import CliRunner
+    np.random.seed(0)
+    res = CliRunner().invoke(eb.ptudes_ekf_sim, ["-t", "2.0"])
+    assert res.exit_code == 0, res.output
+    ekf_gt, ekf = made
+    ate_r, ate_t = ekf_traj_ate(ekf_gt, ekf)
+    np.savez_compressed(
+        os.path.join(HERE, "ekf_sim.npz"),
+        ts=np.array([s[0] for s in stream]),
+        ideal_lacc=np.array([s[1] for s in stream]), ideal_avel=np.array([s[2] for s in stream]),
+        noisy_lacc=np.array([s[3] for s in stream]), noisy_avel=np.array([s[4] for s in stream]),
+        nav_gt=_nav_vec(ekf_gt.nav), nav=_nav_vec(ekf.nav),
+        cov=ekf._cov, n_updates=np.array(len(ekf._nav_update_idxs)),
+        upd_ts=np.array([ekf._navs_t[i] for i in ekf._nav_update_idxs]),
+        ate_rot=np.array(ate_r), ate_trans=np.array(ate_t))
+    with open(os.path.join(HERE, "ekf_sim_stdout.txt"), "w") as f:
+        f.write(res.output)
+
+
+def case_sim_imu():
+    """First 40 draws of sim_imu with non-default args (cli/ekf_bench.py:44-79)."""
+    import numpy as np
+    import ptudes.cli.ekf_bench as eb
+    np.random.seed(7)
+    out = []
+    for k, (a, b) in enumerate(eb.sim_imu(freq=50.0, acc_noise_std=0.1, gyr_noise_std=0.05)):
+        out.append(np.concatenate([[a.ts], a.lacc, a.avel, [b.ts], b.lacc, b.avel]))
+        if k == 39:
+            break
+    np.savez_compressed(os.path.join(HERE, "sim_imu.npz"), rows=np.array(out))
+
+
+def case_pose_files():
+    """KITTI / NC-GT writers + reader (utils.py:191-252) on fixed poses."""
+    import numpy as np
+    import ptudes.utils as pu
+    rng = np.random.default_rng(21)
+    poses = [_rand_pose(rng, 20.0, 1.0) for _ in range(6)]
+    poses[0] = np.eye(4)
+    t = [1626432215.25 + 0.1 * i + 1e-4 * rng.random() for i in range(6)]
+    hdr = "data path: synthetic\nscans range: 0 - None\ntime: 20260101_000000"
+    files = {}
+    for name, h in (("hdr", hdr), ("nohdr", "")):
+        fk = os.path.join(HERE, f"poses_kitti_{name}.txt")
+        fn = os.path.join(HERE, f"poses_ncgt_{name}.csv")
+        pu.save_poses_kitti_format(fk, poses, header=h)
+        pu.save_poses_nc_gt_format(fn, t, poses, header=h)
+        files[name] = (fk, fn)
+    back = pu.read_newer_college_gt(files["hdr"][1])
+    back_raw = pu.read_newer_college_gt(files["hdr"][1], to_os_imu=False)
+    np.savez_compressed(
+        os.path.join(HERE, "pose_files.npz"), poses=np.array(poses), t=np.array(t),
+        header=np.array(hdr), read_t=np.array([b[0] for b in back]),
+        read_poses=np.array([b[1] for b in back]),
+        read_poses_raw=np.array([b[1] for b in back_raw]),
+        nc_os_imu_to_base=pu.NC_OS_IMU_TO_BASE,
+        vee_in=np.array([0.3, -1.2, 2.5]), vee_out=pu.vee(np.array([0.3, -1.2, 2.5])))
+
+
+def case_ate():
+    """calc_ate (ins/data.py:124-153) on fixed trajectory pairs."""
+    import numpy as np
+    from ptudes.ins.data import calc_ate
+    rng = np.random.default_rng(31)
+    out = {}
+    for k, n in enumerate((1, 5, 40)):
+        a = [_rand_pose(rng, 10.0, 0.8) for _ in range(n)]
+        off = _rand_pose(rng, 3.0, 0.5)
+        b = [off @ p @ _rand_pose(rng, 0.05, 0.01) for p in a]
+        r, t = calc_ate(a, b)
+        out[f"a{k}"] = np.array(a)
+        out[f"b{k}"] = np.array(b)
+        out[f"ate{k}"] = np.array([r, t])
+    np.savez_compressed(os.path.join(HERE, "calc_ate.npz"), **out)
+
+
+def case_ts_filters():
+    """filter_nc_gt_by_close_ts / filter_nc_gt_by_cmp (utils.py:255-325)."""
+    import numpy as np
+    import ptudes.utils as pu
+    rng = np.random.default_rng(41)
+    out = {}
+    for k in range(4):
+        n_gt = 60 + 10 * k
+        gt_t = 1000.0 + np.cumsum(rng.uniform(0.09, 0.11, n_gt))
+        # compare stream: different rate, jitter, starts later / ends earlier
+        start = gt_t[3 + k] + rng.uniform(-0.02, 0.02)
+        cmp_t = start + np.cumsum(rng.uniform(0.045 * (k + 1), 0.055 * (k + 1), 80))
+        cmp_t = cmp_t[cmp_t < gt_t[-2]]
+        gt = [(float(t), _rand_pose(rng)) for t in gt_t]
+        cmp_ = [(float(t), _rand_pose(rng)) for t in cmp_t]
+        m_gt, m_t = pu.filter_nc_gt_by_close_ts(gt, [c[0] for c in cmp_])
+        g2, c2 = pu.filter_nc_gt_by_cmp(gt, cmp_)
+        out[f"gt_t{k}"] = gt_t
+        out[f"gt_p{k}"] = np.array([g[1] for g in gt])
+        out[f"cmp_t{k}"] = np.array([c[0] for c in cmp_])
+        out[f"cmp_p{k}"] = np.array([c[1] for c in cmp_])
+        out[f"m_gt_t{k}"] = np.array([g[0] for g in m_gt])
+        out[f"m_t{k}"] = np.array(m_t)
+        out[f"g2_t{k}"] = np.array([g[0] for g in g2])
+        out[f"c2_t{k}"] = np.array([c[0] for c in c2])
+        out[f"c2_p{k}"] = np.array([c[1] for c in c2])
+    np.savez_compressed(os.path.join(HERE, "ts_filters.npz"), **out)
+
+
+def case_imu_nav():
+    """IMU.from_packet unit conversion (ins/data.py:18-31), NavState attitude
+    accessors (ins/data.py:70-90), reduce_active_beams row choice (utils.py:328-341)."""
+    import numpy as np
+    from types import SimpleNamespace
+    from ptudes.ins.data import IMU, NavState, GRAV
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.default_rng(51)
+    pk = SimpleNamespace(sys_ts=1626432215123456789, accel=np.array([0.01, -0.02, 1.003]),
+                         angular_vel=np.array([1.5, -2.25, 0.75]))
+    rot = R.from_rotvec([0.1, 0.2, -0.3]).as_matrix()
+    a = IMU.from_packet(pk)
+    b = IMU.from_packet(pk, _intr_rot=rot)
+    mats, quats, back, rotvecs = [], [], [], []
+    for _ in range(8):
+        M = R.from_rotvec(rng.normal(0, 1.2, 3)).as_matrix()
+        ns = NavState()
+        ns.att_h = M
+        mats.append(M)
+        quats.append(np.array(ns.att_q))
+        back.append(ns.att_h)
+        rotvecs.append(ns.att_v)
+    ns = NavState()
+    ns.pos = np.array([1.0, 2.0, 3.0])
+    ns.att_v = np.array([0.3, -0.2, 0.1])
+    beam = {f"beams_{h}_{n}": np.linspace(0, h, num=n, endpoint=False, dtype=int)
+            for h, n in ((128, 32), (128, 48), (64, 16), (128, 100))}
+    np.savez_compressed(
+        os.path.join(HERE, "imu_nav.npz"), grav=np.array(GRAV),
+        pk_sys_ts=np.array(pk.sys_ts), pk_accel=pk.accel, pk_gyro=pk.angular_vel, rot=rot,
+        imu_a=np.concatenate([[a.ts], a.lacc, a.avel, [a.dt]]),
+        imu_b=np.concatenate([[b.ts], b.lacc, b.avel, [b.dt]]),
+        mats=np.array(mats), quats=np.array(quats), mats_back=np.array(back),
+        rotvecs=np.array(rotvecs), pose_mat=ns.pose_mat(), **beam)
+
+
+CASES = {
+    "ekf_steps_default": lambda: case_ekf_steps("default"),
+    "ekf_steps_init": lambda: case_ekf_steps("init"),
+    "ekf_steps_cov": lambda: case_ekf_steps("cov"),
+    "ekf_sim": case_ekf_sim,
+    "sim_imu": case_sim_imu,
+    "pose_files": case_pose_files,
+    "ate": case_ate,
+    "ts_filters": case_ts_filters,
+    "imu_nav": case_imu_nav,
+}
+
+if __name__ == "__main__":
+    if len(sys.argv) == 2:
+        _mock_reference_deps()
+        CASES[sys.argv[1]]()
+        print("golden:", sys.argv[1], "ok")
+    else:
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        for name in CASES:
+            subprocess.run([sys.executable, os.path.abspath(__file__), name], check=True, env=env)
+        import numpy, scipy
+        with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+            json.dump({"reference": "bexcite/ptudes-lab v0.0.3 (/root/reference)",
+                       "python": sys.version.split()[0], "numpy": numpy.__version__,
+                       "scipy": scipy.__version__, "cases": sorted(CASES)}, f, indent=1)
