@@ -1,0 +1,186 @@
+/*
+ * ptudes_mi.h -- C-ABI of libptudes_mi.so: the MI355X-native lidar-odometry core.
+ *
+ * Drop-in boundary for ONE hot path of bexcite/ptudes-lab: the `ptudes ekf-bench ouster` loop
+ * (reference src/ptudes/cli/ekf_bench.py:493-563) = KISS-ICP scan-to-local-map registration
+ * (reference src/ptudes/kiss.py:54-131, arithmetic in the third-party kiss-icp 0.2.10) + the ptudes
+ * error-state EKF (reference src/ptudes/ins/es_ekf.py:191-329).
+ *
+ * The reference has NO C/FFI boundary of its own: the path sits behind two Python classes
+ * (KissICPWrapper, ESEKF) and below them kiss-icp's private pybind11 module.  The entry points here
+ * are what a ctypes/pybind11 binding for those classes binds; each one names the reference
+ * interface it replaces.  INTEGRATION.md shows the Python-side stubs.
+ *
+ * Conventions (same as the reference): poses are 4x4 row-major doubles, T_world<-body, body = IMU
+ * frame; quaternions xyzw; ICP tangent order (translation, rotation); the EKF attitude error is a
+ * right perturbation.  Every function returns 0 on success, < 0 on error (ptl_last_error() gives the
+ * text, thread-local).  A handle is not thread-safe; distinct handles are independent.  Each handle
+ * owns one HIP stream on cfg.device_id.  Caller owns all buffers passed in; the library copies.
+ * All numerics run on the GPU (hand-written HIP kernels, gfx950); there is no CPU fallback.
+ */
+#ifndef PTUDES_MI_H
+#define PTUDES_MI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTL_OK 0
+#define PTL_ERR_ARG -1
+#define PTL_ERR_HIP -2      /* HIP runtime error / no device */
+#define PTL_ERR_CAPACITY -3 /* a device-side capacity (map pool / hash table / scan size) was exceeded */
+#define PTL_ERR_STATE -4
+
+#define PTL_F32 0
+#define PTL_F64 1
+
+const char *ptl_last_error(void);
+/* 1 when a HIP device is usable (the only backend); never falls back to a CPU path */
+int ptl_backend(void);
+int ptl_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * ICP handle == reference KissICPWrapper (src/ptudes/kiss.py:18-166) + the kiss_icp.KissICP it owns
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ptl_icp ptl_icp;
+
+typedef struct {
+    /* algorithm parameters: reference kiss.py:40-43 + kiss-icp 0.2.10 config defaults */
+    double max_range;             /* kiss.py:25, ekf_bench.py:360-363 */
+    double min_range;             /* kiss.py:24,43 */
+    double voxel_size;            /* max_range / 100 */
+    int32_t max_points_per_voxel; /* 20 */
+    double initial_threshold;     /* 2.0 */
+    double min_motion_th;         /* 0.1 */
+    int32_t deskew;               /* 1 (kiss.py:41) */
+    int32_t max_iterations;       /* 500 */
+    double convergence;           /* 1e-4 */
+    /* device / capacity parameters (no reference counterpart) */
+    int32_t device_id;
+    int32_t scan_cols;            /* W: when t01 == NULL, point i gets t = (i % W) * (1/W) (kiss.py:34-35) */
+    int64_t max_points_per_scan;  /* upper bound of n per register_frame */
+    int64_t map_block_capacity;   /* voxel blocks in the local-map pool */
+    int64_t map_table_capacity;   /* hash slots (power of two) */
+    int32_t gn_workgroups;        /* workgroups of the persistent Gauss-Newton kernel */
+    int32_t rebuild_every;        /* rebuild the map hash table every this many scans (drops tombstones) */
+} ptl_icp_cfg;
+
+/* per-scan counters; identical meaning to oracle/oracle.h orc_icp_stats (SURVEY.md 8(d) byte model) */
+typedef struct {
+    double sigma;        /* kiss.py:99 */
+    double err_dt;       /* kiss.py:118 (KissICPWrapper._err_dt) */
+    double err_drot;     /* kiss.py:119-120 (KissICPWrapper._err_drot) */
+    int32_t iterations;
+    int32_t n_corr_last;
+    int64_t n_in;
+    int64_t n_valid;     /* N_v */
+    int64_t n_down;      /* N_d */
+    int64_t n_src;       /* N_s */
+    int64_t sum_cand;    /* sum_i C_i */
+    int64_t map_voxels;  /* M_v */
+    int64_t map_points;
+} ptl_icp_stats;
+
+/* fills every field with the reference defaults for (max_range, min_range) (kiss.py:21-43) */
+int ptl_icp_default_cfg(ptl_icp_cfg *cfg, double max_range, double min_range);
+/* KissICPWrapper.__init__ (kiss.py:21-52) */
+int ptl_icp_create(const ptl_icp_cfg *cfg, ptl_icp **out);
+int ptl_icp_destroy(ptl_icp *h);
+
+/* KissICPWrapper.register_frame / _kiss_register_frame (kiss.py:54-131).
+ * xyz: n x 3 (dtype PTL_F32 / PTL_F64), host memory; points with |p| outside (min_range, max_range)
+ * are dropped, so RANGE==0 returns may be passed as (0,0,0) instead of being masked (kiss.py:59-60).
+ * t01: n per-point normalised times (kiss.py:61) or NULL => column-implicit (cfg.scan_cols).
+ * guess: 4x4 initial guess (ekf_bench.py:533-548) or NULL => constant-velocity prediction (kiss.py:102-105).
+ * out_pose: poses[-1] after the call (kiss.py:74).  stats may be NULL. */
+int ptl_icp_register_frame(ptl_icp *h, const void *xyz, int dtype, int64_t n, const double *t01,
+                           double scan_ts, const double *guess, double out_pose[16], ptl_icp_stats *stats);
+/* KissICPWrapper.poses / .pose (kiss.py:142-153): copies up to max poses (16 doubles each) */
+int ptl_icp_num_poses(ptl_icp *h, int64_t *n);
+int ptl_icp_get_poses(ptl_icp *h, double *out, int64_t max_poses, int64_t *n_written);
+/* kiss_icp.KissICP.get_prediction_model, used at ekf_bench.py:545 */
+int ptl_icp_get_prediction(ptl_icp *h, double out[16]);
+/* KissICPWrapper.local_map_points (kiss.py:159-161) */
+int ptl_icp_map_size(ptl_icp *h, int64_t *voxels, int64_t *points);
+int ptl_icp_map_points(ptl_icp *h, double *xyz_out, int64_t max_points, int64_t *n_written);
+/* intermediates of the last register_frame, what _kiss_register_frame returns (kiss.py:131): frame_downsample, source */
+int ptl_icp_last_frame_down(ptl_icp *h, double *xyz_out, int64_t max_points, int64_t *n_written);
+int ptl_icp_last_source(ptl_icp *h, double *xyz_out, int64_t max_points, int64_t *n_written);
+
+/* Stage-level entry points (teacher-forced parity checks of single kernels; kiss-icp 0.2.10 units):
+ * VoxelHashMap::AddPoints + RemovePointsFarFromLocation on world-frame points */
+int ptl_icp_map_add(ptl_icp *h, const double *xyz_world, int64_t n, const double origin[3], int prune);
+/* GetCorrespondences + BuildLinearSystem for already-transformed source points: 21 JTJ upper + 6 JTr */
+int ptl_icp_linear_system(ptl_icp *h, const double *src_world, int64_t n, double max_dist, double kernel,
+                          double sums[27], int64_t *n_corr, int64_t *n_cand);
+/* RegisterFrame: full Gauss-Newton loop of `frame` (sensor frame) against the current map */
+int ptl_icp_align(ptl_icp *h, const double *frame, int64_t n, const double guess[16], double max_dist,
+                  double kernel, double out_pose[16], int32_t *iterations);
+
+/* profiling: HIP-event time of the dominant kernel (the persistent Gauss-Newton loop) since last reset */
+int ptl_icp_profile(ptl_icp *h, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
+
+/* ------------------------------------------------------------------------------------------------
+ * EKF handle == reference ESEKF (src/ptudes/ins/es_ekf.py:57-365)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ptl_ekf ptl_ekf;
+
+typedef struct {
+    double init_grav[3]; /* es_ekf.py:75 */
+    double init_bacc[3]; /* es_ekf.py:76 */
+    double init_bgyr[3]; /* es_ekf.py:77 */
+    int32_t device_id;
+} ptl_ekf_cfg;
+
+int ptl_ekf_default_cfg(ptl_ekf_cfg *cfg);
+int ptl_ekf_create(const ptl_ekf_cfg *cfg, ptl_ekf **out);        /* ESEKF.__init__  (:73-179) */
+int ptl_ekf_destroy(ptl_ekf *h);
+int ptl_ekf_process_imu(ptl_ekf *h, const double lacc[3], const double avel[3], double ts); /* processImu (:191-237) */
+/* batch form: imu is n x 7 rows (ts, lacc[3], avel[3]); one launch for the whole batch */
+int ptl_ekf_process_imu_batch(ptl_ekf *h, const double *imu, int64_t n);
+int ptl_ekf_process_pose(ptl_ekf *h, const double pose[16], const double *meas_cov36);      /* processPose (:259-329) */
+/* nav[19] = pos(3) quat_xyzw(4) vel(3) bias_gyr(3) bias_acc(3) grav(3) (ESEKF.nav, :181-184); cov 18x18 (._cov) */
+int ptl_ekf_get_state(ptl_ekf *h, double nav[19], double cov[324]);
+int ptl_ekf_pose_mat(ptl_ekf *h, double T[16]); /* NavState.pose_mat (ins/data.py:70-74) */
+int ptl_ekf_ts(ptl_ekf *h, double *ts);         /* ESEKF.ts (:186-189) */
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-sequence runner == the reference's driver loop (cli/ekf_bench.py:493-563) on a pre-uploaded
+ * sequence: all scans + IMU samples resident in HBM, no host round trip per scan.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ptl_seq ptl_seq;
+
+typedef struct {
+    ptl_icp_cfg icp;
+    ptl_ekf_cfg ekf;
+    int64_t n_scans;
+    int64_t points_per_scan;    /* H * W, every scan has exactly this many (invalid returns = (0,0,0)) */
+    int64_t n_imu;
+    int32_t use_imu_prediction; /* ekf_bench.py:533-535 */
+    int32_t with_ekf;           /* 0 => ICP only (BASELINE config 2) */
+} ptl_seq_cfg;
+
+int ptl_seq_create(const ptl_seq_cfg *cfg, ptl_seq **out);
+int ptl_seq_destroy(ptl_seq *s);
+/* host -> HBM: scan k (points_per_scan x 3 float32, row-major beam-outer) */
+int ptl_seq_upload_scan(ptl_seq *s, int64_t k, const float *xyz);
+/* imu: n_imu x 7 (ts, lacc, avel); imu_end[k] = number of IMU samples that precede scan k in the event stream */
+int ptl_seq_upload_imu(ptl_seq *s, const double *imu, const int64_t *imu_end);
+/* cold-start the filters/map and run scans [0, n) (n <= n_scans); returns after the stream has drained */
+int ptl_seq_run(ptl_seq *s, int64_t n);
+/* res_poses (n x 16), res_t (n), kiss_poses (n x 16), stats (n): any may be NULL; n_out = scans processed
+ * (scans with no IMU since the previous one are skipped when with_ekf, ekf_bench.py:512-518) */
+int ptl_seq_results(ptl_seq *s, double *res_poses, double *res_t, double *kiss_poses, ptl_icp_stats *stats,
+                    int64_t max_n, int64_t *n_out);
+/* device pointer + row count of the (T x 8) NC-GT rows [t, x,y,z, qx,qy,qz,qw] of the last run, for the
+ * RCCL trajectory gather (no host copy) */
+int ptl_seq_traj_device(ptl_seq *s, void **dev_ptr, int64_t *rows);
+int ptl_seq_icp(ptl_seq *s, ptl_icp **icp);
+int ptl_seq_profile(ptl_seq *s, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,125 @@
+"""ctypes binding of libptudes_mi.so (the C-ABI declared in include/ptudes_mi.h).
+
+The library is the only compute backend: loading fails loudly when it has not been built, and every
+handle constructor raises when no HIP device is present.  Nothing here imports torch.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libptudes_mi.so")
+
+PTL_F32, PTL_F64 = 0, 1
+c_d_p = C.POINTER(C.c_double)
+c_i64_p = C.POINTER(C.c_int64)
+
+
+class IcpCfg(C.Structure):
+    _fields_ = [("max_range", C.c_double), ("min_range", C.c_double), ("voxel_size", C.c_double),
+                ("max_points_per_voxel", C.c_int32), ("initial_threshold", C.c_double),
+                ("min_motion_th", C.c_double), ("deskew", C.c_int32), ("max_iterations", C.c_int32),
+                ("convergence", C.c_double), ("device_id", C.c_int32), ("scan_cols", C.c_int32),
+                ("max_points_per_scan", C.c_int64), ("map_block_capacity", C.c_int64),
+                ("map_table_capacity", C.c_int64), ("gn_workgroups", C.c_int32), ("rebuild_every", C.c_int32)]
+
+
+class IcpStats(C.Structure):
+    _fields_ = [("sigma", C.c_double), ("err_dt", C.c_double), ("err_drot", C.c_double),
+                ("iterations", C.c_int32), ("n_corr_last", C.c_int32), ("n_in", C.c_int64),
+                ("n_valid", C.c_int64), ("n_down", C.c_int64), ("n_src", C.c_int64),
+                ("sum_cand", C.c_int64), ("map_voxels", C.c_int64), ("map_points", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class EkfCfg(C.Structure):
+    _fields_ = [("init_grav", C.c_double * 3), ("init_bacc", C.c_double * 3), ("init_bgyr", C.c_double * 3),
+                ("device_id", C.c_int32)]
+
+
+class SeqCfg(C.Structure):
+    _fields_ = [("icp", IcpCfg), ("ekf", EkfCfg), ("n_scans", C.c_int64), ("points_per_scan", C.c_int64),
+                ("n_imu", C.c_int64), ("use_imu_prediction", C.c_int32), ("with_ekf", C.c_int32)]
+
+
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+# every exported symbol of include/ptudes_mi.h with its prototype
+PROTOTYPES = {
+    "ptl_last_error": (C.c_char_p, []),
+    "ptl_backend": (C.c_int, []),
+    "ptl_device_count": (C.c_int, []),
+    "ptl_icp_default_cfg": (C.c_int, [C.POINTER(IcpCfg), C.c_double, C.c_double]),
+    "ptl_icp_create": (C.c_int, [C.POINTER(IcpCfg), _vpp]),
+    "ptl_icp_destroy": (C.c_int, [_vp]),
+    "ptl_icp_register_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, c_d_p, C.c_double, c_d_p, c_d_p,
+                                         C.POINTER(IcpStats)]),
+    "ptl_icp_num_poses": (C.c_int, [_vp, c_i64_p]),
+    "ptl_icp_get_poses": (C.c_int, [_vp, c_d_p, C.c_int64, c_i64_p]),
+    "ptl_icp_get_prediction": (C.c_int, [_vp, c_d_p]),
+    "ptl_icp_map_size": (C.c_int, [_vp, c_i64_p, c_i64_p]),
+    "ptl_icp_map_points": (C.c_int, [_vp, c_d_p, C.c_int64, c_i64_p]),
+    "ptl_icp_last_frame_down": (C.c_int, [_vp, c_d_p, C.c_int64, c_i64_p]),
+    "ptl_icp_last_source": (C.c_int, [_vp, c_d_p, C.c_int64, c_i64_p]),
+    "ptl_icp_map_add": (C.c_int, [_vp, c_d_p, C.c_int64, c_d_p, C.c_int]),
+    "ptl_icp_linear_system": (C.c_int, [_vp, c_d_p, C.c_int64, C.c_double, C.c_double, c_d_p, c_i64_p, c_i64_p]),
+    "ptl_icp_align": (C.c_int, [_vp, c_d_p, C.c_int64, c_d_p, C.c_double, C.c_double, c_d_p,
+                                C.POINTER(C.c_int32)]),
+    "ptl_icp_profile": (C.c_int, [_vp, C.c_int, c_d_p, c_i64_p, C.c_int]),
+    "ptl_ekf_default_cfg": (C.c_int, [C.POINTER(EkfCfg)]),
+    "ptl_ekf_create": (C.c_int, [C.POINTER(EkfCfg), _vpp]),
+    "ptl_ekf_destroy": (C.c_int, [_vp]),
+    "ptl_ekf_process_imu": (C.c_int, [_vp, c_d_p, c_d_p, C.c_double]),
+    "ptl_ekf_process_imu_batch": (C.c_int, [_vp, c_d_p, C.c_int64]),
+    "ptl_ekf_process_pose": (C.c_int, [_vp, c_d_p, c_d_p]),
+    "ptl_ekf_get_state": (C.c_int, [_vp, c_d_p, c_d_p]),
+    "ptl_ekf_pose_mat": (C.c_int, [_vp, c_d_p]),
+    "ptl_ekf_ts": (C.c_int, [_vp, c_d_p]),
+    "ptl_seq_create": (C.c_int, [C.POINTER(SeqCfg), _vpp]),
+    "ptl_seq_destroy": (C.c_int, [_vp]),
+    "ptl_seq_upload_scan": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_float)]),
+    "ptl_seq_upload_imu": (C.c_int, [_vp, c_d_p, c_i64_p]),
+    "ptl_seq_run": (C.c_int, [_vp, C.c_int64]),
+    "ptl_seq_results": (C.c_int, [_vp, c_d_p, c_d_p, c_d_p, C.POINTER(IcpStats), C.c_int64, c_i64_p]),
+    "ptl_seq_traj_device": (C.c_int, [_vp, _vpp, c_i64_p]),
+    "ptl_seq_icp": (C.c_int, [_vp, _vpp]),
+    "ptl_seq_profile": (C.c_int, [_vp, C.c_int, c_d_p, c_i64_p, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) when libptudes_mi.so is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C ptudes-lab_amd/csrc).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().ptl_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)
+        raise RuntimeError(f"libptudes_mi error {rc}: {msg}")
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_d_p)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

@@ -1,0 +1,247 @@
+"""Thin object layer over the C-ABI: `Icp` (one KissICP-equivalent on one GPU), `Ekf`, `SeqRunner`
+(the reference's driver loop, cli/ekf_bench.py:493-563, on a sequence resident in HBM)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def icp_cfg(max_range=100.0, min_range=5.0, **over):
+    """Reference defaults for (max_range, min_range) (kiss.py:21-43) with overrides by field name."""
+    cfg = L.IcpCfg()
+    L.check(L.lib().ptl_icp_default_cfg(C.byref(cfg), float(max_range), float(min_range)))
+    for k, v in over.items():
+        if not hasattr(cfg, k):
+            raise ValueError(f"unknown icp cfg field {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+def ekf_cfg(init_grav=None, init_bacc=None, init_bgyr=None, device_id=0):
+    cfg = L.EkfCfg()
+    L.check(L.lib().ptl_ekf_default_cfg(C.byref(cfg)))
+    for name, val in (("init_grav", init_grav), ("init_bacc", init_bacc), ("init_bgyr", init_bgyr)):
+        if val is not None:
+            v = np.asarray(val, dtype=np.float64).reshape(3)
+            setattr(cfg, name, (C.c_double * 3)(*v))
+    cfg.device_id = device_id
+    return cfg
+
+
+class Icp:
+    def __init__(self, max_range=100.0, min_range=5.0, **over):
+        self.cfg = icp_cfg(max_range, min_range, **over)
+        self._h = C.c_void_p()
+        L.check(L.lib().ptl_icp_create(C.byref(self.cfg), C.byref(self._h)))
+        self.stats = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().ptl_icp_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def register_frame(self, xyz, t01=None, guess=None, scan_ts=0.0):
+        xyz = np.asarray(xyz)
+        if xyz.dtype == np.float32:
+            x = np.ascontiguousarray(xyz)
+            dt = L.PTL_F32
+        else:
+            x = L.as_f64(xyz)
+            dt = L.PTL_F64
+        if x.ndim != 2 or x.shape[1] != 3:
+            raise ValueError("xyz must be (N, 3)")
+        t = None if t01 is None else L.as_f64(t01)
+        if t is not None and len(t) != len(x):
+            raise ValueError("t01 must have one entry per point")
+        g = None if guess is None else L.as_f64(guess).reshape(16)
+        out = np.empty((4, 4))
+        st = L.IcpStats()
+        L.check(L.lib().ptl_icp_register_frame(self._h, x.ctypes.data_as(C.c_void_p), dt, len(x),
+                                               None if t is None else L.dptr(t), float(scan_ts),
+                                               None if g is None else L.dptr(g), L.dptr(out), C.byref(st)))
+        self.stats.append(st.as_dict())
+        return out
+
+    @property
+    def num_poses(self):
+        n = C.c_int64()
+        L.check(L.lib().ptl_icp_num_poses(self._h, C.byref(n)))
+        return n.value
+
+    def poses(self):
+        n = self.num_poses
+        out = np.empty((max(n, 1), 4, 4))
+        w = C.c_int64()
+        L.check(L.lib().ptl_icp_get_poses(self._h, L.dptr(out), n, C.byref(w)))
+        return out[:w.value]
+
+    def prediction(self):
+        out = np.empty((4, 4))
+        L.check(L.lib().ptl_icp_get_prediction(self._h, L.dptr(out)))
+        return out
+
+    def map_size(self):
+        v, p = C.c_int64(), C.c_int64()
+        L.check(L.lib().ptl_icp_map_size(self._h, C.byref(v), C.byref(p)))
+        return v.value, p.value
+
+    def map_points(self):
+        _, p = self.map_size()
+        out = np.empty((max(p, 1), 3))
+        w = C.c_int64()
+        L.check(L.lib().ptl_icp_map_points(self._h, L.dptr(out), p, C.byref(w)))
+        return out[:w.value]
+
+    def _cloud(self, fn):
+        cap = int(self.cfg.max_points_per_scan)
+        out = np.empty((cap, 3))
+        w = C.c_int64()
+        L.check(fn(self._h, L.dptr(out), cap, C.byref(w)))
+        return out[:w.value].copy()
+
+    def last_frame_down(self):
+        return self._cloud(L.lib().ptl_icp_last_frame_down)
+
+    def last_source(self):
+        return self._cloud(L.lib().ptl_icp_last_source)
+
+    # stage-level entry points (teacher-forced parity)
+    def map_add(self, xyz_world, origin=None):
+        x = L.as_f64(xyz_world)
+        o = None if origin is None else L.as_f64(origin)
+        L.check(L.lib().ptl_icp_map_add(self._h, L.dptr(x), len(x), None if o is None else L.dptr(o),
+                                        0 if o is None else 1))
+
+    def linear_system(self, src_world, max_dist, kernel):
+        s = L.as_f64(src_world)
+        sums = np.empty(27)
+        nc, cand = C.c_int64(), C.c_int64()
+        L.check(L.lib().ptl_icp_linear_system(self._h, L.dptr(s), len(s), max_dist, kernel, L.dptr(sums),
+                                              C.byref(nc), C.byref(cand)))
+        return sums, nc.value, cand.value
+
+    def align(self, frame, guess, max_dist, kernel):
+        f = L.as_f64(frame)
+        g = L.as_f64(guess).reshape(16)
+        out = np.empty((4, 4))
+        it = C.c_int32()
+        L.check(L.lib().ptl_icp_align(self._h, L.dptr(f), len(f), L.dptr(g), max_dist, kernel, L.dptr(out),
+                                      C.byref(it)))
+        return out, it.value
+
+
+class Ekf:
+    def __init__(self, init_grav=None, init_bacc=None, init_bgyr=None, device_id=0):
+        self.cfg = ekf_cfg(init_grav, init_bacc, init_bgyr, device_id)
+        self._h = C.c_void_p()
+        L.check(L.lib().ptl_ekf_create(C.byref(self.cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().ptl_ekf_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def process_imu(self, lacc, avel, ts):
+        a, w = L.as_f64(lacc), L.as_f64(avel)
+        L.check(L.lib().ptl_ekf_process_imu(self._h, L.dptr(a), L.dptr(w), float(ts)))
+
+    def process_imu_batch(self, rows):
+        r = L.as_f64(rows)
+        L.check(L.lib().ptl_ekf_process_imu_batch(self._h, L.dptr(r), len(r)))
+
+    def process_pose(self, pose, meas_cov=None):
+        p = L.as_f64(pose).reshape(16)
+        c = None if meas_cov is None else L.as_f64(meas_cov).reshape(36)
+        L.check(L.lib().ptl_ekf_process_pose(self._h, L.dptr(p), None if c is None else L.dptr(c)))
+
+    def state(self):
+        nav, cov = np.empty(19), np.empty((18, 18))
+        L.check(L.lib().ptl_ekf_get_state(self._h, L.dptr(nav), L.dptr(cov)))
+        return nav, cov
+
+    @property
+    def nav(self):
+        return self.state()[0]
+
+    @property
+    def cov(self):
+        return self.state()[1]
+
+    def pose_mat(self):
+        out = np.empty((4, 4))
+        L.check(L.lib().ptl_ekf_pose_mat(self._h, L.dptr(out)))
+        return out
+
+    @property
+    def ts(self):
+        t = C.c_double()
+        L.check(L.lib().ptl_ekf_ts(self._h, C.byref(t)))
+        return t.value
+
+
+class SeqRunner:
+    """Whole sequence in HBM, no host round trip per scan."""
+
+    def __init__(self, n_scans, points_per_scan, n_imu, *, max_range=70.0, min_range=1.0, use_imu_prediction=False,
+                 with_ekf=True, device_id=0, ekf=None, **icp_over):
+        cfg = L.SeqCfg()
+        cfg.icp = icp_cfg(max_range, min_range, device_id=device_id, **icp_over)
+        cfg.ekf = ekf if ekf is not None else ekf_cfg(device_id=device_id)
+        cfg.n_scans, cfg.points_per_scan, cfg.n_imu = n_scans, points_per_scan, n_imu
+        cfg.use_imu_prediction = int(bool(use_imu_prediction))
+        cfg.with_ekf = int(bool(with_ekf))
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        L.check(L.lib().ptl_seq_create(C.byref(cfg), C.byref(self._h)))
+        self.n_scans = n_scans
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().ptl_seq_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def upload_scan(self, k, xyz_f32):
+        x = np.ascontiguousarray(xyz_f32, dtype=np.float32)
+        if x.size != self.cfg.points_per_scan * 3:
+            raise ValueError("scan size mismatch")
+        L.check(L.lib().ptl_seq_upload_scan(self._h, k, x.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def upload_imu(self, imu_rows, imu_end):
+        r = L.as_f64(imu_rows).reshape(-1, 7) if len(imu_rows) else np.zeros((0, 7))
+        e = np.ascontiguousarray(imu_end, dtype=np.int64)
+        if len(e) != self.n_scans:
+            raise ValueError("imu_end needs one entry per scan")
+        L.check(L.lib().ptl_seq_upload_imu(self._h, L.dptr(r) if len(r) else None, e.ctypes.data_as(L.c_i64_p)))
+
+    def run(self, n=None):
+        L.check(L.lib().ptl_seq_run(self._h, self.n_scans if n is None else n))
+
+    def results(self):
+        n = self.n_scans
+        res_poses, res_t, kiss = np.empty((n, 4, 4)), np.empty(n), np.empty((n, 4, 4))
+        stats = (L.IcpStats * n)()
+        w = C.c_int64()
+        L.check(L.lib().ptl_seq_results(self._h, L.dptr(res_poses), L.dptr(res_t), L.dptr(kiss), stats, n,
+                                        C.byref(w)))
+        m = w.value
+        out = dict(kiss_poses=kiss[:m], stats=[stats[i].as_dict() for i in range(m)])
+        if self.cfg.with_ekf:
+            out.update(res_poses=res_poses[:m], res_t=res_t[:m])
+        return out
+
+    def traj_device(self):
+        p, rows = C.c_void_p(), C.c_int64()
+        L.check(L.lib().ptl_seq_traj_device(self._h, C.byref(p), C.byref(rows)))
+        return p.value, rows.value
+
+    def profile(self, enable=True, reset=False):
+        ms, n = C.c_double(), C.c_int64()
+        L.check(L.lib().ptl_seq_profile(self._h, int(enable), C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value

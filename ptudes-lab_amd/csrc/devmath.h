@@ -1,0 +1,226 @@
+// devmath.h -- small fixed-size fp64 algebra used by the HIP kernels (SE(3)/SO(3), 6x6 solve).
+// Product code: written independently of the CPU oracle (oracle/ is test infrastructure and is never
+// included from here).  The reference path is fp64 end to end, so is this.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define PTL_HD __host__ __device__ __forceinline__
+
+struct V3 {
+    double x, y, z;
+};
+PTL_HD V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+PTL_HD V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+PTL_HD V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+PTL_HD V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+PTL_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PTL_HD double norm(V3 a) { return sqrt(dot(a, a)); }
+
+// rigid transform: R row-major 3x3, t
+struct Rt {
+    double R[9];
+    double t[3];
+};
+PTL_HD Rt rt_identity() {
+    Rt a;
+    for (int i = 0; i < 9; ++i) a.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    a.t[0] = a.t[1] = a.t[2] = 0.0;
+    return a;
+}
+PTL_HD Rt rt_from16(const double* T) {
+    Rt a;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) a.R[3 * i + j] = T[4 * i + j];
+        a.t[i] = T[4 * i + 3];
+    }
+    return a;
+}
+PTL_HD void rt_to16(const Rt& a, double* T) {
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[4 * i + j] = a.R[3 * i + j];
+        T[4 * i + 3] = a.t[i];
+    }
+    T[12] = T[13] = T[14] = 0.0;
+    T[15] = 1.0;
+}
+PTL_HD V3 rt_apply(const Rt& a, V3 p) {
+    return V3{a.R[0] * p.x + a.R[1] * p.y + a.R[2] * p.z + a.t[0], a.R[3] * p.x + a.R[4] * p.y + a.R[5] * p.z + a.t[1],
+              a.R[6] * p.x + a.R[7] * p.y + a.R[8] * p.z + a.t[2]};
+}
+PTL_HD Rt rt_mul(const Rt& a, const Rt& b) {
+    Rt c;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += a.R[3 * i + k] * b.R[3 * k + j];
+            c.R[3 * i + j] = s;
+        }
+        c.t[i] = a.R[3 * i] * b.t[0] + a.R[3 * i + 1] * b.t[1] + a.R[3 * i + 2] * b.t[2] + a.t[i];
+    }
+    return c;
+}
+PTL_HD Rt rt_inv(const Rt& a) {
+    Rt c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.R[3 * i + j] = a.R[3 * j + i];
+    for (int i = 0; i < 3; ++i) c.t[i] = -(c.R[3 * i] * a.t[0] + c.R[3 * i + 1] * a.t[1] + c.R[3 * i + 2] * a.t[2]);
+    return c;
+}
+
+PTL_HD void skew(const double w[3], double K[9]) {
+    K[0] = 0.0;   K[1] = -w[2]; K[2] = w[1];
+    K[3] = w[2];  K[4] = 0.0;   K[5] = -w[0];
+    K[6] = -w[1]; K[7] = w[0];  K[8] = 0.0;
+}
+PTL_HD void mat3_mul(const double* A, const double* B, double* C) {
+    double r[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    for (int i = 0; i < 9; ++i) C[i] = r[i];
+}
+
+// ---- SO(3) through a unit quaternion (xyzw), the path scipy's Rotation takes for the reference EKF
+PTL_HD void quat_to_R(const double q[4], double R[9]) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double xx = x * x, yy = y * y, zz = z * z, ww = w * w;
+    R[0] = xx - yy - zz + ww; R[1] = 2.0 * (x * y - z * w); R[2] = 2.0 * (x * z + y * w);
+    R[3] = 2.0 * (x * y + z * w); R[4] = -xx + yy - zz + ww; R[5] = 2.0 * (y * z - x * w);
+    R[6] = 2.0 * (x * z - y * w); R[7] = 2.0 * (y * z + x * w); R[8] = -xx - yy + zz + ww;
+}
+PTL_HD void R_to_quat(const double R[9], double q[4]) {
+    const double tr = R[0] + R[4] + R[8];
+    double d[4] = {R[0], R[4], R[8], tr};
+    int c = 0;
+    for (int i = 1; i < 4; ++i)
+        if (d[i] > d[c]) c = i;
+    if (c == 3) {
+        q[0] = R[7] - R[5]; q[1] = R[2] - R[6]; q[2] = R[3] - R[1]; q[3] = 1.0 + tr;
+    } else {
+        const int i = c, j = (c + 1) % 3, k = (c + 2) % 3;
+        q[i] = 1.0 - tr + 2.0 * R[4 * i];
+        q[j] = R[3 * j + i] + R[3 * i + j];
+        q[k] = R[3 * k + i] + R[3 * i + k];
+        q[3] = R[3 * k + j] - R[3 * j + k];
+    }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+PTL_HD void rotvec_to_R(const double v[3], double R[9]) {
+    const double a = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    double s;
+    if (a <= 1e-3) {
+        const double a2 = a * a;
+        s = 0.5 - a2 / 48.0 + a2 * a2 / 3840.0;
+    } else {
+        s = sin(0.5 * a) / a;
+    }
+    const double q[4] = {s * v[0], s * v[1], s * v[2], cos(0.5 * a)};
+    quat_to_R(q, R);
+}
+PTL_HD void R_to_rotvec(const double R[9], double v[3]) {
+    double q[4];
+    R_to_quat(R, q);
+    if (q[3] < 0.0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double a = 2.0 * atan2(sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]), q[3]);
+    double s;
+    if (a <= 1e-3) {
+        const double a2 = a * a;
+        s = 2.0 + a2 / 12.0 + 7.0 * a2 * a2 / 2880.0;
+    } else {
+        s = a / sin(0.5 * a);
+    }
+    v[0] = s * q[0]; v[1] = s * q[1]; v[2] = s * q[2];
+}
+
+// rotation angle in [0, pi] of a rotation matrix (atan2 form: accurate near zero)
+PTL_HD double rot_angle(const double R[9]) {
+    const double ax = R[7] - R[5], ay = R[2] - R[6], az = R[3] - R[1];
+    return atan2(0.5 * sqrt(ax * ax + ay * ay + az * az), 0.5 * (R[0] + R[4] + R[8] - 1.0));
+}
+
+// SE(3) exp of xi = (upsilon, omega) [Sophus order]: R = I + a K + b K^2, t = (I + b K + c K^2) upsilon
+PTL_HD Rt se3_exp(const double xi[6]) {
+    const double* w = xi + 3;
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+    double a, b, c;
+    if (th < 1e-6) {
+        a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0;
+    } else {
+        const double sn = sin(th), cs = cos(th);
+        a = sn / th; b = (1.0 - cs) / th2; c = (th - sn) / (th2 * th);
+    }
+    double K[9], K2[9];
+    skew(w, K);
+    mat3_mul(K, K, K2);
+    Rt o;
+    double V[9];
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        o.R[i] = I + a * K[i] + b * K2[i];
+        V[i] = I + b * K[i] + c * K2[i];
+    }
+    for (int i = 0; i < 3; ++i) o.t[i] = V[3 * i] * xi[0] + V[3 * i + 1] * xi[1] + V[3 * i + 2] * xi[2];
+    return o;
+}
+// SE(3) log
+PTL_HD void se3_log(const Rt& T, double xi[6]) {
+    double w[3];
+    R_to_rotvec(T.R, w);
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+    double k;
+    if (th < 1e-6) {
+        k = 1.0 / 12.0 + th2 / 720.0;
+    } else {
+        const double h = 0.5 * th;
+        k = (1.0 - th * cos(h) / (2.0 * sin(h))) / th2;
+    }
+    double K[9], K2[9];
+    skew(w, K);
+    mat3_mul(K, K, K2);
+    for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < 3; ++j) {
+            const double I = (i == j) ? 1.0 : 0.0;
+            s += (I - 0.5 * K[3 * i + j] + k * K2[3 * i + j]) * T.t[j];
+        }
+        xi[i] = s;
+    }
+    xi[3] = w[0]; xi[4] = w[1]; xi[5] = w[2];
+}
+
+// Solve JTJ dx = -JTr from the 27 packed sums (21 upper-triangle JTJ row-major, then 6 JTr) by an
+// unpivoted LDL^T; a zero pivot yields a zero component (all-zero system of a scan with no pairs).
+PTL_HD void solve6_ldlt(const double* s, double dx[6]) {
+    double A[36], L[36], D[6], y[6];
+    int o = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) {
+            A[6 * i + j] = s[o];
+            A[6 * j + i] = s[o];
+            ++o;
+        }
+    for (int i = 0; i < 36; ++i) L[i] = 0.0;
+    for (int j = 0; j < 6; ++j) {
+        double d = A[6 * j + j];
+        for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k] * D[k];
+        D[j] = d;
+        L[6 * j + j] = 1.0;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[6 * i + j];
+            for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k] * D[k];
+            L[6 * i + j] = (d != 0.0) ? v / d : 0.0;
+        }
+    }
+    for (int i = 0; i < 6; ++i) {
+        double v = -s[21 + i];
+        for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k];
+        y[i] = v;
+    }
+    for (int i = 0; i < 6; ++i) y[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i];
+        for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * dx[k];
+        dx[i] = v;
+    }
+}

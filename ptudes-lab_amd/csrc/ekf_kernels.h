@@ -1,0 +1,268 @@
+// ekf_kernels.h -- the ptudes 18-state error-state EKF on device (gfx950), fp64.
+//
+// Replaces reference src/ptudes/ins/es_ekf.py: ESEKF.processImu (:191-237, with _insMech :239-257) and
+// ESEKF.processPose (:259-329).  One 384-thread workgroup (6 wavefronts) owns the filter: thread (i,j)
+// of the first 324 owns covariance entry P[i][j]; the 18x18 products go through LDS.  A launch consumes
+// a whole batch of IMU samples and, optionally, one pose update, so the per-scan EKF work of the
+// reference's driver loop (cli/ekf_bench.py:493-563) is a single launch on the handle's stream.
+//
+// State order (es_ekf.py:65-71): POS 0, VEL 3, PHI 6, BG 9, BA 12, G 15.  Attitude is kept as an xyzw
+// quaternion and every use converts through it, as the reference's NavState does (ins/data.py:76-82).
+#pragma once
+#include "devmath.h"
+
+#define EKF_N 18
+#define EKF_POS 0
+#define EKF_VEL 3
+#define EKF_PHI 6
+#define EKF_BG 9
+#define EKF_BA 12
+#define EKF_G 15
+
+struct EkfState {
+    double pos[3], q[4], vel[3], bg[3], ba[3], grav[3];
+    double P[EKF_N * EKF_N];
+    double Fx[EKF_N * EKF_N];  // persistent: identity + rewritten blocks (es_ekf.py:142, :216-223)
+    double W[EKF_N * EKF_N];   // persistent: zero + rewritten diagonal blocks (es_ekf.py:145, :226-233)
+    double cur_lacc[3], cur_avel[3], cur_ts, cur_dt;
+    int initialized, n_updates;
+    double pose[16];  // NavState.pose_mat() after the last step (ins/data.py:70-74)
+};
+
+__device__ __forceinline__ void ekf_write_pose(EkfState* e) {
+    double R[9];
+    quat_to_R(e->q, R);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) e->pose[4 * i + j] = R[3 * i + j];
+        e->pose[4 * i + 3] = e->pos[i];
+    }
+    e->pose[12] = e->pose[13] = e->pose[14] = 0.0;
+    e->pose[15] = 1.0;
+}
+
+// ESEKF.__init__ (es_ekf.py:73-179)
+__global__ void k_ekf_init(EkfState* e, const double* grav, const double* bacc, const double* bgyr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < 3; ++i) { e->pos[i] = 0.0; e->vel[i] = 0.0; e->grav[i] = grav[i]; e->ba[i] = bacc[i]; e->bg[i] = bgyr[i]; }
+    e->q[0] = e->q[1] = e->q[2] = 0.0; e->q[3] = 1.0;
+    for (int i = 0; i < EKF_N * EKF_N; ++i) { e->P[i] = 0.0; e->Fx[i] = 0.0; e->W[i] = 0.0; }
+    for (int i = 0; i < EKF_N; ++i) e->Fx[i * EKF_N + i] = 1.0;
+    // initial attitude std = rotation vector of intrinsic-XYZ euler (10, 10, 10) deg (es_ekf.py:104-107)
+    const double a = 10.0 * 3.14159265358979323846 / 180.0, cs = cos(a), sn = sin(a);
+    const double Rx[9] = {1, 0, 0, 0, cs, -sn, 0, sn, cs}, Ry[9] = {cs, 0, sn, 0, 1, 0, -sn, 0, cs}, Rz[9] = {cs, -sn, 0, sn, cs, 0, 0, 0, 1};
+    double R[9], rv[3];
+    mat3_mul(Rx, Ry, R);
+    mat3_mul(R, Rz, R);
+    R_to_rotvec(R, rv);
+    for (int i = 0; i < 3; ++i) {
+        e->P[(EKF_POS + i) * EKF_N + EKF_POS + i] = 100.0;
+        e->P[(EKF_VEL + i) * EKF_N + EKF_VEL + i] = 25.0;
+        e->P[(EKF_PHI + i) * EKF_N + EKF_PHI + i] = rv[i] * rv[i];
+        e->P[(EKF_BG + i) * EKF_N + EKF_BG + i] = 2.25;
+        e->P[(EKF_BA + i) * EKF_N + EKF_BA + i] = 0.25;
+        e->P[(EKF_G + i) * EKF_N + EKF_G + i] = 6.25;
+    }
+    e->cur_ts = 0.0; e->cur_dt = 0.0; e->initialized = 0; e->n_updates = 0;
+    for (int i = 0; i < 3; ++i) { e->cur_lacc[i] = 0.0; e->cur_avel[i] = 0.0; }
+    ekf_write_pose(e);
+}
+
+__device__ __forceinline__ void set_blk3(double* M, int r, int c, const double* B) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[(r + i) * EKF_N + c + j] = B[3 * i + j];
+}
+__device__ __forceinline__ void set_diag3(double* M, int r, int c, double v) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[(r + i) * EKF_N + c + j] = (i == j) ? v : 0.0;
+}
+
+// imu: rows of 7 doubles (ts, lacc[3], avel[3]); samples [i0, i1) are consumed in order.
+// pose (nullable): 4x4 measurement applied after the IMU samples; meas_cov (nullable): 6x6.
+// out_* (nullable): res_poses / res_t / NC-GT row slot written after the update (ekf_bench.py:560-563).
+__global__ __launch_bounds__(384) void k_ekf_step(EkfState* e, const double* imu, int i0, int i1, const double* pose,
+                                                  const double* meas_cov, double* out_pose, double* out_t,
+                                                  double* out_row8) {
+    __shared__ double sP[EKF_N * EKF_N], sF[EKF_N * EKF_N], sT[EKF_N * EKF_N];
+    __shared__ double sK[EKF_N * 6], sSi[36], sr[6], sdx[EKF_N];
+    const int tid = threadIdx.x;
+    const int ti = tid / EKF_N, tj = tid % EKF_N;
+    const bool cell = tid < EKF_N * EKF_N;
+    if (cell) sP[tid] = e->P[tid];
+    __syncthreads();
+    for (int s = i0; s < i1; ++s) {
+        // ---- processImu: scalar part on thread 0 (mechanisation + Fx/W blocks)
+        __shared__ int active;
+        if (tid == 0) {
+            const double* row = imu + 7 * (size_t)s;
+            const double ts = row[0];
+            e->cur_dt = ts - e->cur_ts;  // es_ekf.py:196
+            e->cur_ts = ts;
+            for (int k = 0; k < 3; ++k) { e->cur_lacc[k] = row[1 + k]; e->cur_avel[k] = row[4 + k]; }
+            if (!e->initialized) {  // :201-203 the first sample only latches
+                e->initialized = 1;
+                active = 0;
+            } else {
+                active = 1;
+                const double dt = e->cur_dt;
+                double Rp[9], a[3], w[3], dth[3], Rd[9], Rn[9];
+                quat_to_R(e->q, Rp);  // nav_prev.att_h
+                for (int k = 0; k < 3; ++k) { a[k] = e->cur_lacc[k] - e->ba[k]; w[k] = e->cur_avel[k] - e->bg[k]; dth[k] = w[k] * dt; }
+                rotvec_to_R(dth, Rd);
+                // _insMech (:239-257)
+                for (int k = 0; k < 3; ++k) {
+                    const double ag = (Rp[3 * k] * a[0] + Rp[3 * k + 1] * a[1] + Rp[3 * k + 2] * a[2]) + e->grav[k];
+                    e->pos[k] = e->pos[k] + e->vel[k] * dt + 0.5 * ag * dt * dt;
+                    e->vel[k] = e->vel[k] + ag * dt;
+                }
+                mat3_mul(Rp, Rd, Rn);
+                R_to_quat(Rn, e->q);
+                // Fx blocks (:216-223)
+                double K[9], B[9];
+                set_diag3(e->Fx, EKF_POS, EKF_VEL, dt);
+                skew(a, K);
+                mat3_mul(Rp, K, B);
+                for (int k = 0; k < 9; ++k) B[k] = -dt * B[k];
+                set_blk3(e->Fx, EKF_VEL, EKF_PHI, B);
+                for (int k = 0; k < 9; ++k) B[k] = -dt * Rp[k];
+                set_blk3(e->Fx, EKF_VEL, EKF_BA, B);
+                for (int r = 0; r < 3; ++r)
+                    for (int cc = 0; cc < 3; ++cc) B[3 * r + cc] = Rd[3 * cc + r];
+                set_blk3(e->Fx, EKF_PHI, EKF_PHI, B);
+                set_diag3(e->Fx, EKF_PHI, EKF_BG, -dt);
+                // W blocks (:226-233); the reference's names do not match their use, this copies the use
+                set_diag3(e->W, EKF_VEL, EKF_VEL, dt * dt * (0.049 * 0.049));
+                set_diag3(e->W, EKF_PHI, EKF_PHI, dt * dt * (0.38 * 0.38));
+                set_diag3(e->W, EKF_BA, EKF_BA, dt * (0.0043 * 0.0043));
+                set_diag3(e->W, EKF_BG, EKF_BG, dt * (0.000466 * 0.000466));
+                __threadfence_block();
+            }
+        }
+        __syncthreads();
+        if (active) {
+            // ---- P = Fx P Fx^T + W (:235), dense like the reference
+            if (cell) sF[tid] = e->Fx[tid];
+            __syncthreads();
+            if (cell) {
+                double acc = 0.0;
+                for (int k = 0; k < EKF_N; ++k) acc += sF[ti * EKF_N + k] * sP[k * EKF_N + tj];
+                sT[tid] = acc;
+            }
+            __syncthreads();
+            if (cell) {
+                double acc = 0.0;
+                for (int k = 0; k < EKF_N; ++k) acc += sT[ti * EKF_N + k] * sF[tj * EKF_N + k];
+                sP[tid] = acc + e->W[tid];
+            }
+        }
+        __syncthreads();
+    }
+    if (pose) {
+        // ---- processPose (:259-329); the error state is zero on entry (reset at :327)
+        const int sel[6] = {EKF_POS, EKF_POS + 1, EKF_POS + 2, EKF_PHI, EKF_PHI + 1, EKF_PHI + 2};
+        if (tid == 0) {
+            double Rk[9], RkT[9], Rm[9], D[9], S[36];
+            quat_to_R(e->q, Rk);
+            for (int r = 0; r < 3; ++r)
+                for (int cc = 0; cc < 3; ++cc) { RkT[3 * r + cc] = Rk[3 * cc + r]; Rm[3 * r + cc] = pose[4 * r + cc]; }
+            for (int k = 0; k < 3; ++k) sr[k] = pose[4 * k + 3] - e->pos[k];  // :294
+            mat3_mul(RkT, Rm, D);
+            R_to_rotvec(D, sr + 3);  // :297
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) {
+                    double rm;
+                    if (meas_cov) rm = meas_cov[6 * a + b];
+                    else rm = (a == b) ? ((a < 3) ? 0.02 * 0.02 : 0.01 * 0.01) : 0.0;  // :289-292
+                    S[6 * a + b] = sP[sel[a] * EKF_N + sel[b]] + rm;                    // :299
+                }
+            // inverse by Gauss-Jordan with partial pivoting (np.linalg.inv, :300)
+            double M[6][12];
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) { M[a][b] = S[6 * a + b]; M[a][6 + b] = (a == b) ? 1.0 : 0.0; }
+            for (int cI = 0; cI < 6; ++cI) {
+                int p = cI;
+                for (int r = cI + 1; r < 6; ++r)
+                    if (fabs(M[r][cI]) > fabs(M[p][cI])) p = r;
+                if (p != cI)
+                    for (int b = 0; b < 12; ++b) { const double t = M[cI][b]; M[cI][b] = M[p][b]; M[p][b] = t; }
+                const double d = M[cI][cI];
+                for (int b = 0; b < 12; ++b) M[cI][b] /= d;
+                for (int r = 0; r < 6; ++r) {
+                    if (r == cI) continue;
+                    const double f = M[r][cI];
+                    if (f == 0.0) continue;
+                    for (int b = 0; b < 12; ++b) M[r][b] -= f * M[cI][b];
+                }
+            }
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) sSi[6 * a + b] = M[a][6 + b];
+        }
+        __syncthreads();
+        if (tid < EKF_N * 6) {  // K = P Jp^T S^-1 (:300)
+            const int i = tid / 6, j = tid % 6;
+            double acc = 0.0;
+            for (int k = 0; k < 6; ++k) acc += sP[i * EKF_N + sel[k]] * sSi[6 * k + j];
+            sK[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < EKF_N) {  // dx = K r (:301)
+            double acc = 0.0;
+            for (int k = 0; k < 6; ++k) acc += sK[tid * 6 + k] * sr[k];
+            sdx[tid] = acc;
+        }
+        // P = (I - K Jp) P (:303): build (I - K Jp) in sT, then multiply
+        if (cell) {
+            double v = (ti == tj) ? 1.0 : 0.0;
+            for (int k = 0; k < 6; ++k)
+                if (sel[k] == tj) v -= sK[ti * 6 + k];
+            sT[tid] = v;
+        }
+        __syncthreads();
+        double pn = 0.0;
+        if (cell)
+            for (int k = 0; k < EKF_N; ++k) pn += sT[ti * EKF_N + k] * sP[k * EKF_N + tj];
+        __syncthreads();
+        if (cell) sP[tid] = pn;
+        __syncthreads();
+        if (tid == 0) {
+            // inject (:314-319)
+            double dth[3], R[9], Rd[9], Rn[9];
+            for (int k = 0; k < 3; ++k) {
+                e->pos[k] += sdx[EKF_POS + k];
+                e->vel[k] += sdx[EKF_VEL + k];
+                dth[k] = sdx[EKF_PHI + k];
+                e->bg[k] += sdx[EKF_BG + k];
+                e->ba[k] += sdx[EKF_BA + k];
+                e->grav[k] += sdx[EKF_G + k];
+            }
+            quat_to_R(e->q, R);
+            rotvec_to_R(dth, Rd);
+            mat3_mul(R, Rd, Rn);
+            R_to_quat(Rn, e->q);
+            // covariance projection of the PHI diagonal block only (:322-324): G = I - hat(dth / 2)
+            const double h[3] = {0.5 * dth[0], 0.5 * dth[1], 0.5 * dth[2]};
+            double Gm[9], GT[9], B[9], C[9];
+            skew(h, Gm);
+            for (int k = 0; k < 9; ++k) Gm[k] = -Gm[k];
+            Gm[0] += 1.0; Gm[4] += 1.0; Gm[8] += 1.0;
+            for (int r = 0; r < 3; ++r)
+                for (int cc = 0; cc < 3; ++cc) { GT[3 * r + cc] = Gm[3 * cc + r]; B[3 * r + cc] = sP[(EKF_PHI + r) * EKF_N + EKF_PHI + cc]; }
+            mat3_mul(Gm, B, C);
+            mat3_mul(C, GT, C);
+            for (int r = 0; r < 3; ++r)
+                for (int cc = 0; cc < 3; ++cc) sP[(EKF_PHI + r) * EKF_N + EKF_PHI + cc] = C[3 * r + cc];
+            e->n_updates += 1;
+        }
+        __syncthreads();
+    }
+    if (cell) e->P[tid] = sP[tid];
+    if (tid == 0) {
+        ekf_write_pose(e);
+        if (out_pose) for (int k = 0; k < 16; ++k) out_pose[k] = e->pose[k];
+        if (out_t) *out_t = e->cur_ts;
+        if (out_row8) {  // [t, x, y, z, qx, qy, qz, qw] for the trajectory gather
+            out_row8[0] = e->cur_ts;
+            for (int k = 0; k < 3; ++k) out_row8[1 + k] = e->pos[k];
+            for (int k = 0; k < 4; ++k) out_row8[4 + k] = e->q[k];
+        }
+    }
+}

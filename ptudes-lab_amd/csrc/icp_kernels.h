@@ -1,0 +1,711 @@
+// icp_kernels.h -- HIP kernels (gfx950) of the scan-to-local-map registration path.
+//
+// Replaces, on device, what reference src/ptudes/kiss.py:83-131 drives inside kiss-icp 0.2.10:
+//   K0 scan_prologue   deskew twist, adaptive threshold, initial guess          (kiss.py:90,99,102-105)
+//   K1 k_deskew_vds1   DeSkewScan + Preprocess + VoxelDownsample(0.5 vs) claim  (kiss.py:90,93,96)
+//   K2 k_vds2          first-point winners of pass 1 claim VoxelDownsample(1.5 vs)
+//   K3 k_compact_fd    ordered compaction -> frame_downsample
+//   K4 k_compact_src   ordered compaction -> source
+//   K5 k_gn_loop       persistent Gauss-Newton loop: 27-voxel NN + robust 6x6 system + solve (kiss.py:108-114)
+//   K6 k_post_icp      new pose, innovation log, threshold model deviation      (kiss.py:116-130)
+//   K7-9 k_map_*       VoxelHashMap::AddPoints, order-preserving, cap per voxel (kiss.py:129)
+//   K10 k_map_prune    RemovePointsFarFromLocation
+//   K11 k_map_rebuild  hash-table rebuild (drops tombstones)
+//
+// Data layout in HBM (all fp64 coordinates, as the reference):
+//   points            AoS double[3] per point (24 B), scan order (row-major beam-outer)
+//   VDS hash tables   u64 packed voxel key + u32 "smallest claiming point index" per slot
+//   local map table   16-B entries {u64 key, i32 block, i32 batch list head}, open addressing, linear probe
+//   local map blocks  one 128-B-aligned block per voxel: x[P] | y[P] | z[P] | {i32 count, i32 slot}
+//                     (P = 20 -> 512 B = four cache lines; lanes read x[j], y[j], z[j] coalesced)
+// Deterministic semantics shared with the CPU oracle: first point per voxel in scan order, voxel keeps
+// its first P points in scan order, nearest neighbour = strictly-smaller distance in (voxel i,j,k
+// ascending, insertion order) candidate order, voxel index by truncation toward zero.
+#pragma once
+#include "devmath.h"
+#include <stdint.h>
+
+#define EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define TOMB_KEY 0xFFFFFFFFFFFFFFFEull
+#define KEY_OFF (1 << 20)
+
+#define ERR_KEY_RANGE 1
+#define ERR_POOL 2
+#define ERR_TABLE 4
+#define ERR_VDS_TABLE 8
+#define ERR_GN_TIMEOUT 16
+
+struct TabEnt {
+    unsigned long long key;
+    int blk;
+    int head;
+};
+
+struct ScanStats {  // mirrors ptl_icp_stats
+    double sigma, err_dt, err_drot;
+    int iterations, n_corr_last;
+    long long n_in, n_valid, n_down, n_src, sum_cand, map_voxels, map_points;
+};
+
+struct DevState {
+    // per-scan counters
+    int n_in, n_valid, n_down, n_src;
+    // GN loop
+    unsigned bar;
+    int gn_iters, gn_ncorr, gn_pad;
+    long long gn_cand;
+    double gn_max_dist, gn_kernel;
+    double T_icp[16];
+    double dbg_sums[32];
+    // pose history (kiss_icp.KissICP.poses: only first / last two are ever read)
+    int n_poses, has_ext_guess;
+    double pose_first[16], pose_prev[16], pose_last[16];
+    double guess[16], new_pose[16];
+    double xi[6];
+    int do_deskew, pad1;
+    // Threshold.cpp AdaptiveThreshold
+    double sigma, sse;
+    long long n_samples;
+    double model_dev[16];
+    // map
+    int free_top, n_live;
+    long long map_points;
+    unsigned tab_used;
+    int err_flags;
+};
+
+struct Ctx {
+    // algorithm parameters
+    double max_range, min_range, vs, vds1, vds2, init_thr, min_motion, conv;
+    int P, deskew, max_iter, W;
+    // scan input
+    const float* in_f32;
+    const double* in_f64;
+    const double* t01;
+    int n_in, n_max;
+    // scan work buffers
+    double* pts;
+    int *slot1, *slot2;
+    unsigned long long *vkey1, *vkey2;
+    unsigned *vmin1, *vmin2;
+    unsigned vmask;
+    int *bcnt1, *bcnt2;
+    double *fd, *src0, *src_cur, *fdw;
+    int *pslot, *nxt, *prank, *plen;
+    // map
+    TabEnt* tab;
+    unsigned tmask;
+    unsigned char* blocks;
+    int bstride, pool_cap;
+    int* free_stack;
+    // GN
+    double* partials;
+    int G;
+    // state / outputs
+    DevState* st;
+    double* traj;        // [T][16] kiss poses
+    ScanStats* sstats;   // [T]
+    const double* ext_guess;  // device 4x4 or null
+    int traj_cap;
+};
+
+__device__ __forceinline__ double* blk_x(const Ctx& c, int b) { return (double*)(c.blocks + (size_t)b * c.bstride); }
+__device__ __forceinline__ int* blk_hdr(const Ctx& c, int b) {
+    return (int*)(c.blocks + (size_t)b * c.bstride + (size_t)c.P * 24);
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long h) {
+    h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;
+    return h;
+}
+// voxel index by C truncation toward zero, exactly (int)(coordinate / voxel_size)
+__device__ __forceinline__ bool vox_key(V3 p, double size, unsigned long long& key, int& kx, int& ky, int& kz) {
+    kx = (int)(p.x / size); ky = (int)(p.y / size); kz = (int)(p.z / size);
+    const int ox = kx + KEY_OFF, oy = ky + KEY_OFF, oz = kz + KEY_OFF;
+    const bool ok = ((unsigned)ox | (unsigned)oy | (unsigned)oz) < (1u << 21);
+    key = ((unsigned long long)ox << 42) | ((unsigned long long)oy << 21) | (unsigned long long)oz;
+    return ok;
+}
+__device__ __forceinline__ unsigned long long pack_key(int kx, int ky, int kz) {
+    return ((unsigned long long)(kx + KEY_OFF) << 42) | ((unsigned long long)(ky + KEY_OFF) << 21) |
+           (unsigned long long)(kz + KEY_OFF);
+}
+
+// find-or-claim a slot for `key` in a per-scan VDS table; returns slot or -1 when the table is full
+__device__ __forceinline__ int vds_claim(unsigned long long* keys, unsigned mask, unsigned long long key) {
+    unsigned s = (unsigned)mix64(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        unsigned long long cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return (int)s;
+        if (cur == EMPTY_KEY) {
+            unsigned long long old = atomicCAS(&keys[s], EMPTY_KEY, key);
+            if (old == EMPTY_KEY || old == key) return (int)s;
+        }
+        s = (s + 1) & mask;
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------------ K0
+// One thread.  kiss_icp.KissICP: deskew twist from its own last two poses, get_adaptive_threshold()
+// (Threshold.cpp ComputeThreshold, stateful), initial guess (reference kiss.py:102-105 or the caller's).
+__global__ void k_scan_prologue(Ctx c) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DevState* st = c.st;
+    st->n_in = c.n_in;
+    st->n_valid = 0; st->n_down = 0; st->n_src = 0;
+    st->bar = 0; st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0;
+    // deskew: xi = Log(P[-2]^-1 P[-1])  (Deskew.cpp)
+    st->do_deskew = (c.deskew && st->n_poses >= 2) ? 1 : 0;
+    Rt last = rt_from16(st->pose_last), prev = rt_from16(st->pose_prev);
+    Rt rel = rt_mul(rt_inv(prev), last);
+    if (st->do_deskew) {
+        double xi[6];
+        se3_log(rel, xi);
+        for (int i = 0; i < 6; ++i) st->xi[i] = xi[i];
+    }
+    // adaptive threshold
+    double sigma = c.init_thr;
+    bool moved = false;
+    if (st->n_poses >= 1) {
+        Rt d = rt_mul(rt_inv(rt_from16(st->pose_first)), last);
+        moved = sqrt(d.t[0] * d.t[0] + d.t[1] * d.t[1] + d.t[2] * d.t[2]) > 5.0 * c.min_motion;
+    }
+    if (moved) {
+        Rt dev = rt_from16(st->model_dev);
+        const double theta = rot_angle(dev.R);
+        const double err = sqrt(dev.t[0] * dev.t[0] + dev.t[1] * dev.t[1] + dev.t[2] * dev.t[2]) +
+                           2.0 * c.max_range * sin(0.5 * theta);
+        if (err > c.min_motion) { st->sse += err * err; st->n_samples += 1; }
+        sigma = (st->n_samples < 1) ? c.init_thr : sqrt(st->sse / (double)st->n_samples);
+    }
+    st->sigma = sigma;
+    st->gn_max_dist = 3.0 * sigma;
+    st->gn_kernel = sigma / 3.0;
+    // initial guess
+    Rt g;
+    if (c.ext_guess) {
+        g = rt_from16(c.ext_guess);
+    } else {
+        Rt pred = (st->n_poses >= 2) ? rel : rt_identity();
+        Rt lp = (st->n_poses >= 1) ? last : rt_identity();
+        g = rt_mul(lp, pred);
+    }
+    rt_to16(g, st->guess);
+}
+
+// ------------------------------------------------------------------------------------------------ K1
+__global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    DevState* st = c.st;
+    bool valid = false;
+    if (i < c.n_in) {
+        V3 p;
+        if (c.in_f32) p = v3((double)c.in_f32[3 * (size_t)i], (double)c.in_f32[3 * (size_t)i + 1], (double)c.in_f32[3 * (size_t)i + 2]);
+        else p = v3(c.in_f64[3 * (size_t)i], c.in_f64[3 * (size_t)i + 1], c.in_f64[3 * (size_t)i + 2]);
+        if (st->do_deskew) {
+            const double t = c.t01 ? c.t01[i] : (double)(i % c.W) * (1.0 / (double)c.W);
+            const double s = t - 0.5;
+            double x[6];
+            for (int k = 0; k < 6; ++k) x[k] = s * st->xi[k];
+            p = rt_apply(se3_exp(x), p);
+        }
+        const double r = sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
+        valid = (r < c.max_range) && (r > c.min_range);
+        int slot = -1;
+        if (valid) {
+            c.pts[3 * (size_t)i] = p.x; c.pts[3 * (size_t)i + 1] = p.y; c.pts[3 * (size_t)i + 2] = p.z;
+            unsigned long long key; int kx, ky, kz;
+            if (!vox_key(p, c.vds1, key, kx, ky, kz)) { atomicOr(&st->err_flags, ERR_KEY_RANGE); }
+            else {
+                slot = vds_claim(c.vkey1, c.vmask, key);
+                if (slot < 0) atomicOr(&st->err_flags, ERR_VDS_TABLE);
+                else atomicMin(&c.vmin1[slot], (unsigned)i);
+            }
+        }
+        c.slot1[i] = slot;
+    }
+    const int nv = __syncthreads_count(valid ? 1 : 0);
+    if (threadIdx.x == 0 && nv) atomicAdd(&st->n_valid, nv);
+}
+
+// ------------------------------------------------------------------------------------------------ K2
+__global__ __launch_bounds__(256) void k_vds2(Ctx c) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool w1 = false;
+    if (i < c.n_in) {
+        const int s1 = c.slot1[i];
+        w1 = (s1 >= 0) && (c.vmin1[s1] == (unsigned)i);
+        int slot = -1;
+        if (w1) {
+            V3 p = v3(c.pts[3 * (size_t)i], c.pts[3 * (size_t)i + 1], c.pts[3 * (size_t)i + 2]);
+            unsigned long long key; int kx, ky, kz;
+            vox_key(p, c.vds2, key, kx, ky, kz);
+            slot = vds_claim(c.vkey2, c.vmask, key);
+            if (slot < 0) atomicOr(&c.st->err_flags, ERR_VDS_TABLE);
+            else atomicMin(&c.vmin2[slot], (unsigned)i);
+        }
+        c.slot2[i] = slot;
+    }
+    const int n1 = __syncthreads_count(w1 ? 1 : 0);
+    if (threadIdx.x == 0) c.bcnt1[blockIdx.x] = n1;
+}
+
+// exclusive prefix of per-block counts + in-block rank (scan order preserved)
+__device__ __forceinline__ int block_offset(const int* bcnt, int b, int* red) {
+    int s = 0;
+    for (int k = threadIdx.x; k < b; k += 256) s += bcnt[k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const int tot = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return tot;
+}
+__device__ __forceinline__ int block_rank(bool flag, int* red, int& total) {
+    const unsigned long long m = __ballot(flag);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int within = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) red[4 + wv] = __popcll(m);
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wv; ++k) off += red[4 + k];
+    total = red[4] + red[5] + red[6] + red[7];
+    __syncthreads();
+    return off + within;
+}
+
+// ------------------------------------------------------------------------------------------------ K3
+__global__ __launch_bounds__(256) void k_compact_fd(Ctx c) {
+    __shared__ int red[8];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool w1 = false, w2 = false;
+    if (i < c.n_in) {
+        const int s1 = c.slot1[i];
+        w1 = (s1 >= 0) && (c.vmin1[s1] == (unsigned)i);
+        if (w1) {
+            const int s2 = c.slot2[i];
+            w2 = (s2 >= 0) && (c.vmin2[s2] == (unsigned)i);
+        }
+    }
+    const int off = block_offset(c.bcnt1, blockIdx.x, red);
+    int total;
+    const int rk = block_rank(w1, red, total);
+    if (w1) {
+        const size_t o = (size_t)(off + rk) * 3;
+        c.fd[o] = c.pts[3 * (size_t)i]; c.fd[o + 1] = c.pts[3 * (size_t)i + 1]; c.fd[o + 2] = c.pts[3 * (size_t)i + 2];
+        // release the pass-1 slot for the next scan (only its winner touches it)
+        const int s1 = c.slot1[i];
+        c.vkey1[s1] = EMPTY_KEY;
+        c.vmin1[s1] = 0xFFFFFFFFu;
+    }
+    const int n2 = __syncthreads_count(w2 ? 1 : 0);
+    if (threadIdx.x == 0) {
+        c.bcnt2[blockIdx.x] = n2;
+        if (blockIdx.x == gridDim.x - 1) c.st->n_down = off + total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K4
+__global__ __launch_bounds__(256) void k_compact_src(Ctx c) {
+    __shared__ int red[8];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool w2 = false;
+    if (i < c.n_in) {
+        const int s1 = c.slot1[i];
+        // pass-1 slot was already released by its winner; winners are exactly the points with slot2 >= 0
+        const int s2 = (s1 >= 0) ? c.slot2[i] : -1;
+        w2 = (s2 >= 0) && (c.vmin2[s2] == (unsigned)i);
+    }
+    const int off = block_offset(c.bcnt2, blockIdx.x, red);
+    int total;
+    const int rk = block_rank(w2, red, total);
+    if (w2) {
+        const size_t o = (size_t)(off + rk) * 3;
+        c.src0[o] = c.pts[3 * (size_t)i]; c.src0[o + 1] = c.pts[3 * (size_t)i + 1]; c.src0[o + 2] = c.pts[3 * (size_t)i + 2];
+    }
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) c.st->n_src = off + total;
+}
+// releases the pass-2 slots (separate launch: K4 still reads vmin2 of slots other points own)
+__global__ __launch_bounds__(256) void k_vds2_release(Ctx c) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < c.n_in) {
+        const int s1 = c.slot1[i];
+        const int s2 = (s1 >= 0) ? c.slot2[i] : -1;
+        if (s2 >= 0 && c.vmin2[s2] == (unsigned)i) { c.vkey2[s2] = EMPTY_KEY; c.vmin2[s2] = 0xFFFFFFFFu; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K5
+// map probe: block id of voxel `key` or -1
+__device__ __forceinline__ int map_find(const Ctx& c, unsigned long long key) {
+    unsigned s = (unsigned)mix64(key) & c.tmask;
+    for (unsigned probe = 0; probe <= c.tmask; ++probe) {
+        const TabEnt e = c.tab[s];
+        if (e.key == key) return e.blk;
+        if (e.key == EMPTY_KEY) return -1;
+        s = (s + 1) & c.tmask;
+    }
+    return -1;
+}
+
+// 32 lanes cooperate on one source point: lanes 0..26 probe the 27 neighbour voxels in (i,j,k) ascending
+// order, then all lanes scan each found block (lane j <-> j-th stored point, coalesced x/y/z reads).
+// Returns in every lane of the group: best squared distance, best target, found flag; adds candidates to ncand.
+__device__ __forceinline__ bool nn_search32(const Ctx& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
+                                            long long& ncand) {
+    const int kx = (int)(s.x / c.vs), ky = (int)(s.y / c.vs), kz = (int)(s.z / c.vs);
+    int blk = -1;
+    if (lane32 < 27) {
+        const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
+        blk = map_find(c, pack_key(kx + di, ky + dj, kz + dk));
+    }
+    const unsigned long long ball = __ballot(blk >= 0);
+    unsigned m = (unsigned)(ball >> gbase);
+    double bd = 1.7976931348623157e308;
+    unsigned border = 0xFFFFFFFFu;
+    V3 bp = v3(0, 0, 0);
+    while (m) {
+        const int v = __ffs(m) - 1;
+        m &= m - 1;
+        const int b = __shfl(blk, gbase + v);
+        const int cnt = blk_hdr(c, b)[0];
+        if (lane32 == 0) ncand += cnt;
+        const double* X = blk_x(c, b);
+        for (int j = lane32; j < cnt; j += 32) {
+            const double qx = X[j], qy = X[c.P + j], qz = X[2 * c.P + j];
+            const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < bd) { bd = d2; border = (unsigned)(v * 1024 + j); bp = v3(qx, qy, qz); }
+        }
+    }
+    // lexicographic (d2, candidate order) minimum over the 32 lanes of the group
+    for (int o = 16; o > 0; o >>= 1) {
+        const double od = __shfl_xor(bd, o);
+        const unsigned oo = __shfl_xor(border, o);
+        const double ox = __shfl_xor(bp.x, o), oy = __shfl_xor(bp.y, o), oz = __shfl_xor(bp.z, o);
+        if (od < bd || (od == bd && oo < border)) { bd = od; border = oo; bp = v3(ox, oy, oz); }
+    }
+    best = bp;
+    best_d2 = bd;
+    return border != 0xFFFFFFFFu;
+}
+
+// Persistent Gauss-Newton loop (Registration.cpp RegisterFrame).  G workgroups x 256 threads, all resident;
+// one device-scope counter barrier per iteration; every workgroup sums all partials in the same fixed
+// order and solves the 6x6 system redundantly, so all agree bit-for-bit on dx and on convergence.
+// mode 0: source = guess * src0, loop to convergence.  mode 1: src_cur given in world frame, one pass,
+// sums exported to st->dbg_sums (teacher-forced test entry).
+__global__ __launch_bounds__(256) void k_gn_loop(Ctx c, int mode) {
+    __shared__ double red[8][32];
+    __shared__ double tot[32];
+    __shared__ double Esh[12];
+    __shared__ int flag_done;
+    DevState* st = c.st;
+    const int tid = threadIdx.x, lane32 = tid & 31, grp = tid >> 5, gbase = (tid & 63) & 32;
+    const int G = gridDim.x, wg = blockIdx.x;
+    const int n = st->n_src;
+    if (st->n_live == 0 && mode == 0) {  // voxel_map.Empty() => return initial_guess
+        if (wg == 0 && tid == 0) {
+            Rt I = rt_identity();
+            rt_to16(I, st->T_icp);
+            st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0;
+        }
+        return;
+    }
+    const double max_dist = st->gn_max_dist, kern = st->gn_kernel, k2 = kern * kern;
+    const int max_iter = (mode == 1) ? 1 : c.max_iter;
+    Rt E = (mode == 0) ? rt_from16(st->guess) : rt_identity();
+    Rt Ticp = rt_identity();
+    long long cand_total = 0;
+    int iters = 0, ncorr_last = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        double acc[27];
+        for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+        long long ncand = 0;
+        int ncorr = 0;
+        for (int i = wg * 8 + grp; i < n; i += G * 8) {
+            // lazily apply the previous iteration's increment (TransformPoints(estimation, source))
+            V3 s;
+            if (it == 0 && mode == 0) s = rt_apply(E, v3(c.src0[3 * (size_t)i], c.src0[3 * (size_t)i + 1], c.src0[3 * (size_t)i + 2]));
+            else if (it == 0) s = v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]);
+            else s = rt_apply(E, v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]));
+            if (lane32 == 0 && !(it == 0 && mode == 1)) {
+                c.src_cur[3 * (size_t)i] = s.x; c.src_cur[3 * (size_t)i + 1] = s.y; c.src_cur[3 * (size_t)i + 2] = s.z;
+            }
+            V3 t;
+            double d2;
+            const bool found = nn_search32(c, s, lane32, gbase, t, d2, ncand);
+            if (lane32 == 0 && found && sqrt(d2) < max_dist) {
+                ++ncorr;
+                const double rx = s.x - t.x, ry = s.y - t.y, rz = s.z - t.z;
+                const double den = kern + (rx * rx + ry * ry + rz * rz);
+                const double w = k2 / (den * den);
+                // J = [I | -hat(s)] ; A = -hat(s) = [[0, sz, -sy], [-sz, 0, sx], [sy, -sx, 0]]
+                const double A[9] = {0.0, s.z, -s.y, -s.z, 0.0, s.x, s.y, -s.x, 0.0};
+                const double r[3] = {rx, ry, rz};
+                // JTJ upper triangle, row-major: rows 0..2 (translation) then 3..5 (rotation)
+                acc[0] += w; acc[6] += w; acc[11] += w;                       // (0,0) (1,1) (2,2)
+                acc[3] += w * A[0]; acc[4] += w * A[1]; acc[5] += w * A[2];   // (0,3..5)
+                acc[8] += w * A[3]; acc[9] += w * A[4]; acc[10] += w * A[5];  // (1,3..5)
+                acc[12] += w * A[6]; acc[13] += w * A[7]; acc[14] += w * A[8];  // (2,3..5)
+                int o = 15;
+                for (int a = 0; a < 3; ++a)
+                    for (int b = a; b < 3; ++b) {
+                        acc[o++] += w * (A[a] * A[b] + A[3 + a] * A[3 + b] + A[6 + a] * A[6 + b]);  // (3+a,3+b)
+                    }
+                acc[21] += w * r[0]; acc[22] += w * r[1]; acc[23] += w * r[2];
+                for (int a = 0; a < 3; ++a) acc[24 + a] += w * (A[a] * r[0] + A[3 + a] * r[1] + A[6 + a] * r[2]);
+            }
+        }
+        // workgroup reduction in fixed order
+        if (lane32 == 0) {
+            for (int k = 0; k < 27; ++k) red[grp][k] = acc[k];
+            red[grp][27] = (double)ncorr;
+            red[grp][28] = (double)ncand;
+        }
+        __syncthreads();
+        double* part = c.partials + ((size_t)(it & 1) * G + wg) * 32;
+        if (tid < 29) {
+            double s = 0.0;
+            for (int g = 0; g < 8; ++g) s += red[g][tid];
+            __hip_atomic_store(&part[tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // grid barrier: monotonic counter (zeroed by K0), relaxed polling
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&st->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)G * (unsigned)(it + 1);
+            unsigned spins = 0;
+            while (__hip_atomic_load(&st->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 26)) { atomicOr(&st->err_flags, ERR_GN_TIMEOUT); break; }
+            }
+        }
+        __syncthreads();
+        // every workgroup: total = sum over workgroups, fixed order (8 strided partial sums, then 8 -> 1)
+        {
+            const int col = tid & 31, part8 = tid >> 5;
+            double s = 0.0;
+            if (col < 29) {
+                const double* base = c.partials + (size_t)(it & 1) * G * 32;
+                for (int w = part8; w < G; w += 8)
+                    s += __hip_atomic_load(&base[(size_t)w * 32 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            red[part8][col] = s;
+        }
+        __syncthreads();
+        if (tid < 29) {
+            double s = 0.0;
+            for (int g = 0; g < 8; ++g) s += red[g][tid];
+            tot[tid] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double dx[6];
+            solve6_ldlt(tot, dx);
+            Rt e = se3_exp(dx);
+            for (int k = 0; k < 9; ++k) Esh[k] = e.R[k];
+            for (int k = 0; k < 3; ++k) Esh[9 + k] = e.t[k];
+            double nn = 0.0;
+            for (int k = 0; k < 6; ++k) nn += dx[k] * dx[k];
+            flag_done = (sqrt(nn) < c.conv) ? 1 : 0;
+        }
+        __syncthreads();
+        for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
+        for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
+        Ticp = rt_mul(E, Ticp);
+        cand_total += (long long)tot[28];
+        ncorr_last = (int)tot[27];
+        iters = it + 1;
+        const int done = flag_done;
+        if (mode == 1 && wg == 0 && tid < 29) st->dbg_sums[tid] = tot[tid];
+        __syncthreads();
+        if (done) break;
+    }
+    if (wg == 0 && tid == 0) {
+        rt_to16(Ticp, st->T_icp);
+        st->gn_iters = iters;
+        st->gn_ncorr = ncorr_last;
+        st->gn_cand = cand_total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K6
+__global__ void k_post_icp(Ctx c) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DevState* st = c.st;
+    Rt guess = rt_from16(st->guess);
+    Rt np = (st->n_live == 0) ? guess : rt_mul(rt_from16(st->T_icp), guess);
+    rt_to16(np, st->new_pose);
+    Rt gain = rt_mul(rt_inv(guess), np);  // kiss.py:116, :128
+    rt_to16(gain, st->model_dev);
+    const int k = st->n_poses;
+    if (k < c.traj_cap) {
+        for (int i = 0; i < 16; ++i) c.traj[(size_t)k * 16 + i] = st->new_pose[i];
+        ScanStats s;
+        s.sigma = st->sigma;
+        s.err_dt = sqrt(gain.t[0] * gain.t[0] + gain.t[1] * gain.t[1] + gain.t[2] * gain.t[2]);
+        s.err_drot = rot_angle(gain.R);
+        s.iterations = st->gn_iters; s.n_corr_last = st->gn_ncorr;
+        s.n_in = st->n_in; s.n_valid = st->n_valid; s.n_down = st->n_down; s.n_src = st->n_src;
+        s.sum_cand = st->gn_cand; s.map_voxels = 0; s.map_points = 0;  // filled by k_finish_scan
+        c.sstats[k] = s;
+    }
+}
+__global__ void k_finish_scan(Ctx c) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DevState* st = c.st;
+    const int k = st->n_poses;
+    if (k < c.traj_cap) { c.sstats[k].map_voxels = st->n_live; c.sstats[k].map_points = st->map_points; }
+    if (k == 0) for (int i = 0; i < 16; ++i) st->pose_first[i] = st->new_pose[i];
+    for (int i = 0; i < 16; ++i) { st->pose_prev[i] = st->pose_last[i]; st->pose_last[i] = st->new_pose[i]; }
+    st->n_poses = k + 1;
+}
+
+// ------------------------------------------------------------------------------------------------ K7-K9
+// AddPoints, phase a: world transform, find-or-create the voxel's table entry, join its batch list.
+// `pose` null => points are already in the world frame (stage-level API)
+__global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_in, const int* n_ptr, int n_fixed,
+                                                      int use_pose) {
+    const int n = n_ptr ? *n_ptr : n_fixed;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    DevState* st = c.st;
+    V3 p = v3(pts_in[3 * (size_t)i], pts_in[3 * (size_t)i + 1], pts_in[3 * (size_t)i + 2]);
+    if (use_pose) p = rt_apply(rt_from16(st->new_pose), p);
+    c.fdw[3 * (size_t)i] = p.x; c.fdw[3 * (size_t)i + 1] = p.y; c.fdw[3 * (size_t)i + 2] = p.z;
+    unsigned long long key; int kx, ky, kz;
+    int slot = -1;
+    if (!vox_key(p, c.vs, key, kx, ky, kz)) {
+        atomicOr(&st->err_flags, ERR_KEY_RANGE);
+    } else {
+        unsigned s = (unsigned)mix64(key) & c.tmask;
+        for (unsigned probe = 0; probe <= c.tmask; ++probe) {
+            unsigned long long cur = __hip_atomic_load(&c.tab[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == key) { slot = (int)s; break; }
+            if (cur == EMPTY_KEY) {
+                const unsigned long long old = atomicCAS(&c.tab[s].key, EMPTY_KEY, key);
+                if (old == EMPTY_KEY) {  // created: take a block from the pool
+                    slot = (int)s;
+                    const int top = atomicSub(&st->free_top, 1) - 1;
+                    int b = -1;
+                    if (top >= 0) {
+                        b = c.free_stack[top];
+                        int* h = blk_hdr(c, b);
+                        h[0] = 0;
+                        h[1] = slot;
+                        atomicAdd(&st->n_live, 1);
+                    } else {
+                        atomicOr(&st->err_flags, ERR_POOL);
+                    }
+                    c.tab[s].blk = b;
+                    const unsigned used = atomicAdd(&st->tab_used, 1u) + 1u;
+                    if (used > (c.tmask + 1u) / 4u * 3u) atomicOr(&st->err_flags, ERR_TABLE);
+                    break;
+                }
+                if (old == key) { slot = (int)s; break; }
+            }
+            s = (s + 1) & c.tmask;
+        }
+        if (slot < 0) atomicOr(&st->err_flags, ERR_TABLE);
+    }
+    c.pslot[i] = slot;
+    c.nxt[i] = (slot >= 0) ? atomicExch(&c.tab[slot].head, i) : -1;
+}
+// phase b: rank among this batch's points of the same voxel (by scan order) -> slot in the block
+__global__ __launch_bounds__(256) void k_map_insert_b(Ctx c, const int* n_ptr, int n_fixed) {
+    const int n = n_ptr ? *n_ptr : n_fixed;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int slot = c.pslot[i];
+    if (slot < 0) { c.prank[i] = -1; return; }
+    int rank = 0, len = 0;
+    for (int j = c.tab[slot].head; j >= 0; j = c.nxt[j]) { ++len; rank += (j < i) ? 1 : 0; }
+    c.prank[i] = rank;
+    c.plen[i] = len;
+    const int b = c.tab[slot].blk;
+    if (b < 0) return;
+    const int cnt = blk_hdr(c, b)[0];
+    const int pos = cnt + rank;
+    if (pos < c.P) {
+        double* X = blk_x(c, b);
+        X[pos] = c.fdw[3 * (size_t)i]; X[c.P + pos] = c.fdw[3 * (size_t)i + 1]; X[2 * c.P + pos] = c.fdw[3 * (size_t)i + 2];
+    }
+}
+// phase c: publish the new counts, reset the batch lists
+__global__ __launch_bounds__(256) void k_map_insert_c(Ctx c, const int* n_ptr, int n_fixed) {
+    const int n = n_ptr ? *n_ptr : n_fixed;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (c.prank[i] != 0) return;
+    const int slot = c.pslot[i];
+    const int b = c.tab[slot].blk;
+    c.tab[slot].head = -1;
+    if (b < 0) return;
+    int* h = blk_hdr(c, b);
+    const int cnt = h[0];
+    int nc = cnt + c.plen[i];
+    if (nc > c.P) nc = c.P;
+    h[0] = nc;
+    atomicAdd((unsigned long long*)&c.st->map_points, (unsigned long long)(nc - cnt));
+}
+
+// ------------------------------------------------------------------------------------------------ K10
+// RemovePointsFarFromLocation: a voxel goes when its FIRST point is farther than max_range from the origin
+__global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_xyz, int use_new_pose) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= c.pool_cap) return;
+    DevState* st = c.st;
+    int* h = blk_hdr(c, b);
+    const int cnt = h[0];
+    if (cnt <= 0) return;
+    double ox, oy, oz;
+    if (use_new_pose) { ox = st->new_pose[3]; oy = st->new_pose[7]; oz = st->new_pose[11]; }
+    else { ox = origin_xyz[0]; oy = origin_xyz[1]; oz = origin_xyz[2]; }
+    const double* X = blk_x(c, b);
+    const double dx = X[0] - ox, dy = X[c.P] - oy, dz = X[2 * c.P] - oz;
+    if (dx * dx + dy * dy + dz * dz > c.max_range * c.max_range) {
+        c.tab[h[1]].key = TOMB_KEY;
+        c.tab[h[1]].blk = -1;
+        h[0] = 0;
+        const int top = atomicAdd(&st->free_top, 1);
+        c.free_stack[top] = b;
+        atomicSub(&st->n_live, 1);
+        atomicAdd((unsigned long long*)&st->map_points, (unsigned long long)(-(long long)cnt));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K11
+// after the table has been reset to EMPTY: re-enter every live voxel
+__global__ __launch_bounds__(256) void k_map_rebuild(Ctx c) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= c.pool_cap) return;
+    int* h = blk_hdr(c, b);
+    if (h[0] <= 0) return;
+    const double* X = blk_x(c, b);
+    unsigned long long key; int kx, ky, kz;
+    vox_key(v3(X[0], X[c.P], X[2 * c.P]), c.vs, key, kx, ky, kz);
+    unsigned s = (unsigned)mix64(key) & c.tmask;
+    for (unsigned probe = 0; probe <= c.tmask; ++probe) {
+        const unsigned long long old = atomicCAS(&c.tab[s].key, EMPTY_KEY, key);
+        if (old == EMPTY_KEY) { c.tab[s].blk = b; h[1] = (int)s; atomicAdd(&c.st->tab_used, 1u); return; }
+        s = (s + 1) & c.tmask;
+    }
+    atomicOr(&c.st->err_flags, ERR_TABLE);
+}
+
+// export of the map points (KissICPWrapper.local_map_points)
+__global__ __launch_bounds__(256) void k_map_export(Ctx c, double* out, int* counter, int max_points) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= c.pool_cap) return;
+    const int cnt = blk_hdr(c, b)[0];
+    if (cnt <= 0) return;
+    const int o = atomicAdd(counter, cnt);
+    const double* X = blk_x(c, b);
+    for (int j = 0; j < cnt; ++j) {
+        if (o + j >= max_points) break;
+        out[3 * (size_t)(o + j)] = X[j]; out[3 * (size_t)(o + j) + 1] = X[c.P + j]; out[3 * (size_t)(o + j) + 2] = X[2 * c.P + j];
+    }
+}

@@ -1,0 +1,719 @@
+// ptudes_mi.hip -- C-ABI (include/ptudes_mi.h) + host orchestration of the HIP kernels.
+//
+// One HIP stream per handle; all arithmetic runs in the kernels of icp_kernels.h / ekf_kernels.h.
+// The host only sizes buffers, enqueues launches and copies results: there is no CPU compute path.
+#include "../../include/ptudes_mi.h"
+#include "ekf_kernels.h"
+#include "icp_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(x)                                                                                    \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) return set_err(PTL_ERR_HIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* ptl_last_error(void) { return g_err; }
+extern "C" int ptl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int ptl_backend(void) { return ptl_device_count() > 0 ? 1 : 0; }
+
+// ================================================================================================ ICP
+struct ptl_icp {
+    ptl_icp_cfg cfg;
+    hipStream_t stream;
+    bool own_stream;
+    Ctx c;               // kernel context (device pointers)
+    int64_t n_max;
+    int nblk_scan;
+    void* d_in;          // staging for host-provided scans (n_max * 3 * 8 bytes)
+    double* d_t01;
+    double* d_ext;       // staging for a host-provided guess
+    int* d_counter;
+    int64_t traj_cap;
+    int64_t scans_done;
+    // profiling of the dominant kernel
+    bool prof;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used;
+    double gn_ms;
+    int64_t gn_launches;
+};
+
+extern "C" int ptl_icp_default_cfg(ptl_icp_cfg* cfg, double max_range, double min_range) {
+    if (!cfg) return set_err(PTL_ERR_ARG, "cfg is null");
+    memset(cfg, 0, sizeof *cfg);
+    cfg->max_range = max_range;
+    cfg->min_range = min_range;
+    cfg->voxel_size = max_range / 100.0;  // kiss-icp load_config
+    cfg->max_points_per_voxel = 20;
+    cfg->initial_threshold = 2.0;
+    cfg->min_motion_th = 0.1;
+    cfg->deskew = 1;
+    cfg->max_iterations = 500;
+    cfg->convergence = 1e-4;
+    cfg->device_id = 0;
+    cfg->scan_cols = 1024;
+    cfg->max_points_per_scan = 131072;
+    cfg->map_block_capacity = 1 << 19;
+    cfg->map_table_capacity = 1 << 21;
+    cfg->gn_workgroups = 256;
+    cfg->rebuild_every = 16;
+    return PTL_OK;
+}
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
+
+static int icp_free(ptl_icp* h) {
+    if (!h) return PTL_OK;
+    hipSetDevice(h->cfg.device_id);
+    Ctx& c = h->c;
+    void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, c.fd, c.src0,
+                    c.src_cur, c.fdw, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.partials,
+                    c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    for (hipEvent_t e : h->ev) hipEventDestroy(e);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return PTL_OK;
+}
+
+__global__ void k_fill_free_stack(int* fs, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) fs[i] = n - 1 - i;  // pops hand out low block ids first
+}
+__global__ void k_state_init(DevState* st, int pool_cap) {
+    if (threadIdx.x || blockIdx.x) return;
+    memset(st, 0, sizeof(DevState));
+    Rt I = rt_identity();
+    rt_to16(I, st->pose_first); rt_to16(I, st->pose_prev); rt_to16(I, st->pose_last);
+    rt_to16(I, st->model_dev); rt_to16(I, st->guess); rt_to16(I, st->new_pose); rt_to16(I, st->T_icp);
+    st->free_top = pool_cap;
+}
+
+static int icp_reset_device(ptl_icp* h) {
+    Ctx& c = h->c;
+    const size_t vcap = (size_t)c.vmask + 1;
+    HIPCHK(hipMemsetAsync(c.vkey1, 0xFF, vcap * 8, h->stream));
+    HIPCHK(hipMemsetAsync(c.vkey2, 0xFF, vcap * 8, h->stream));
+    HIPCHK(hipMemsetAsync(c.vmin1, 0xFF, vcap * 4, h->stream));
+    HIPCHK(hipMemsetAsync(c.vmin2, 0xFF, vcap * 4, h->stream));
+    HIPCHK(hipMemsetAsync(c.tab, 0xFF, ((size_t)c.tmask + 1) * sizeof(TabEnt), h->stream));
+    HIPCHK(hipMemsetAsync(c.blocks, 0, (size_t)c.pool_cap * c.bstride, h->stream));
+    k_fill_free_stack<<<(c.pool_cap + 255) / 256, 256, 0, h->stream>>>(c.free_stack, c.pool_cap);
+    k_state_init<<<1, 64, 0, h->stream>>>(c.st, c.pool_cap);
+    HIPCHK(hipGetLastError());
+    h->scans_done = 0;
+    return PTL_OK;
+}
+
+static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, ptl_icp** out) {
+    if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
+    if (cfg->max_points_per_voxel < 1 || cfg->max_points_per_voxel > 1000) return set_err(PTL_ERR_ARG, "max_points_per_voxel out of range");
+    if (cfg->map_table_capacity & (cfg->map_table_capacity - 1)) return set_err(PTL_ERR_ARG, "map_table_capacity must be a power of two");
+    if (cfg->max_points_per_scan < 1 || cfg->gn_workgroups < 1) return set_err(PTL_ERR_ARG, "bad capacity");
+    if (ptl_device_count() <= cfg->device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->device_id);
+    HIPCHK(hipSetDevice(cfg->device_id));
+    ptl_icp* h = new ptl_icp();
+    h->cfg = *cfg;
+    h->own_stream = shared_stream == nullptr;
+    h->stream = shared_stream;
+    h->prof = false; h->ev_used = 0; h->gn_ms = 0; h->gn_launches = 0;
+    h->d_in = nullptr; h->d_t01 = nullptr; h->d_ext = nullptr; h->d_counter = nullptr;
+    memset(&h->c, 0, sizeof(Ctx));
+    if (h->own_stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return set_err(PTL_ERR_HIP, "hipStreamCreate failed");
+    }
+    Ctx& c = h->c;
+    const int64_t n = cfg->max_points_per_scan;
+    h->n_max = n;
+    c.max_range = cfg->max_range; c.min_range = cfg->min_range; c.vs = cfg->voxel_size;
+    c.vds1 = cfg->voxel_size * 0.5;  // KissICP.voxelize
+    c.vds2 = cfg->voxel_size * 1.5;
+    c.init_thr = cfg->initial_threshold; c.min_motion = cfg->min_motion_th; c.conv = cfg->convergence;
+    c.P = cfg->max_points_per_voxel; c.deskew = cfg->deskew; c.max_iter = cfg->max_iterations;
+    c.W = cfg->scan_cols > 0 ? cfg->scan_cols : 1;
+    c.n_max = (int)n;
+    size_t vcap = 1024;
+    while (vcap < (size_t)(2 * n)) vcap <<= 1;
+    c.vmask = (unsigned)(vcap - 1);
+    c.tmask = (unsigned)(cfg->map_table_capacity - 1);
+    c.bstride = (int)(((size_t)c.P * 24 + 16 + 127) / 128 * 128);
+    c.pool_cap = (int)cfg->map_block_capacity;
+    c.G = cfg->gn_workgroups;
+    h->nblk_scan = (int)((n + 255) / 256);
+    h->traj_cap = 4096;
+    c.traj_cap = (int)h->traj_cap;
+    bool ok = true;
+    ok &= dalloc(&c.pts, 3 * n) == hipSuccess;
+    ok &= dalloc(&c.slot1, n) == hipSuccess && dalloc(&c.slot2, n) == hipSuccess;
+    ok &= dalloc(&c.vkey1, vcap) == hipSuccess && dalloc(&c.vkey2, vcap) == hipSuccess;
+    ok &= dalloc(&c.vmin1, vcap) == hipSuccess && dalloc(&c.vmin2, vcap) == hipSuccess;
+    ok &= dalloc(&c.bcnt1, h->nblk_scan) == hipSuccess && dalloc(&c.bcnt2, h->nblk_scan) == hipSuccess;
+    ok &= dalloc(&c.fd, 3 * n) == hipSuccess && dalloc(&c.src0, 3 * n) == hipSuccess;
+    ok &= dalloc(&c.src_cur, 3 * n) == hipSuccess && dalloc(&c.fdw, 3 * n) == hipSuccess;
+    ok &= dalloc(&c.pslot, n) == hipSuccess && dalloc(&c.nxt, n) == hipSuccess;
+    ok &= dalloc(&c.prank, n) == hipSuccess && dalloc(&c.plen, n) == hipSuccess;
+    ok &= dalloc(&c.tab, (size_t)cfg->map_table_capacity) == hipSuccess;
+    ok &= hipMalloc((void**)&c.blocks, (size_t)c.pool_cap * c.bstride) == hipSuccess;
+    ok &= dalloc(&c.free_stack, c.pool_cap) == hipSuccess;
+    ok &= dalloc(&c.partials, (size_t)2 * c.G * 32) == hipSuccess;
+    ok &= dalloc(&c.st, 1) == hipSuccess;
+    ok &= dalloc(&c.traj, (size_t)h->traj_cap * 16) == hipSuccess;
+    ok &= dalloc(&c.sstats, (size_t)h->traj_cap) == hipSuccess;
+    ok &= hipMalloc(&h->d_in, (size_t)n * 3 * 8) == hipSuccess;
+    ok &= dalloc(&h->d_t01, n) == hipSuccess;
+    ok &= dalloc(&h->d_ext, 16) == hipSuccess;
+    ok &= dalloc(&h->d_counter, 4) == hipSuccess;
+    if (!ok) {
+        icp_free(h);
+        return set_err(PTL_ERR_HIP, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    int rc = icp_reset_device(h);
+    if (rc != PTL_OK) { icp_free(h); return rc; }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { icp_free(h); return set_err(PTL_ERR_HIP, "init sync failed"); }
+    *out = h;
+    return PTL_OK;
+}
+extern "C" int ptl_icp_create(const ptl_icp_cfg* cfg, ptl_icp** out) { return icp_create_impl(cfg, nullptr, out); }
+extern "C" int ptl_icp_destroy(ptl_icp* h) { return icp_free(h); }
+
+static int icp_grow_traj(ptl_icp* h) {
+    // doubles the trajectory / stats buffers (host-side decision: scans_done is known on the host)
+    Ctx& c = h->c;
+    const int64_t ncap = h->traj_cap * 2;
+    double* nt = nullptr;
+    ScanStats* ns = nullptr;
+    HIPCHK(dalloc(&nt, (size_t)ncap * 16));
+    HIPCHK(dalloc(&ns, (size_t)ncap));
+    HIPCHK(hipMemcpyAsync(nt, c.traj, (size_t)h->traj_cap * 16 * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(ns, c.sstats, (size_t)h->traj_cap * sizeof(ScanStats), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(c.traj); hipFree(c.sstats);
+    c.traj = nt; c.sstats = ns;
+    h->traj_cap = ncap; c.traj_cap = (int)ncap;
+    return PTL_OK;
+}
+
+static int map_rebuild(ptl_icp* h) {
+    Ctx& c = h->c;
+    HIPCHK(hipMemsetAsync(c.tab, 0xFF, ((size_t)c.tmask + 1) * sizeof(TabEnt), h->stream));
+    HIPCHK(hipMemsetAsync(&c.st->tab_used, 0, sizeof(unsigned), h->stream));
+    k_map_rebuild<<<(c.pool_cap + 255) / 256, 256, 0, h->stream>>>(c);
+    return PTL_OK;
+}
+
+// Enqueue one whole scan on the handle's stream (no host synchronisation):
+// in_f32 / in_f64 / t01 / ext_guess are DEVICE pointers (one of in_* non-null).
+static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f64, const double* t01, int64_t n,
+                            const double* ext_guess) {
+    if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "scan has %lld points, capacity %lld", (long long)n, (long long)h->n_max);
+    if (h->scans_done >= h->traj_cap) { int rc = icp_grow_traj(h); if (rc) return rc; }
+    Ctx c = h->c;
+    c.in_f32 = in_f32; c.in_f64 = in_f64; c.t01 = t01; c.n_in = (int)n; c.ext_guess = ext_guess;
+    const int nb = (int)((n + 255) / 256) > 0 ? (int)((n + 255) / 256) : 1;
+    hipStream_t s = h->stream;
+    k_scan_prologue<<<1, 64, 0, s>>>(c);
+    k_deskew_vds1<<<nb, 256, 0, s>>>(c);
+    k_vds2<<<nb, 256, 0, s>>>(c);
+    k_compact_fd<<<nb, 256, 0, s>>>(c);
+    k_compact_src<<<nb, 256, 0, s>>>(c);
+    k_vds2_release<<<nb, 256, 0, s>>>(c);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        if (h->ev_used + 2 > h->ev.size()) {
+            for (int k = 0; k < 2; ++k) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev.push_back(e); }
+        }
+        e0 = h->ev[h->ev_used++]; e1 = h->ev[h->ev_used++];
+        HIPCHK(hipEventRecord(e0, s));
+    }
+    k_gn_loop<<<c.G, 256, 0, s>>>(c, 0);
+    if (h->prof) HIPCHK(hipEventRecord(e1, s));
+    k_post_icp<<<1, 64, 0, s>>>(c);
+    // local_map.update(frame_downsample, new_pose)  (kiss.py:129)
+    k_map_insert_a<<<nb, 256, 0, s>>>(c, c.fd, &c.st->n_down, 0, 1);
+    k_map_insert_b<<<nb, 256, 0, s>>>(c, &c.st->n_down, 0);
+    k_map_insert_c<<<nb, 256, 0, s>>>(c, &c.st->n_down, 0);
+    k_map_prune<<<(c.pool_cap + 255) / 256, 256, 0, s>>>(c, nullptr, 1);
+    k_finish_scan<<<1, 64, 0, s>>>(c);
+    h->scans_done++;
+    if (h->cfg.rebuild_every > 0 && (h->scans_done % h->cfg.rebuild_every) == 0) { int rc = map_rebuild(h); if (rc) return rc; }
+    HIPCHK(hipGetLastError());
+    return PTL_OK;
+}
+
+static void icp_collect_profile(ptl_icp* h) {
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) { h->gn_ms += ms; h->gn_launches++; }
+    }
+    h->ev_used = 0;
+}
+
+static int icp_check_flags(ptl_icp* h) {
+    int flags = 0;
+    HIPCHK(hipMemcpyAsync(&flags, &h->c.st->err_flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->prof) icp_collect_profile(h);
+    if (flags)
+        return set_err(PTL_ERR_CAPACITY, "device capacity/error flags 0x%x (1 key range, 2 block pool, 4 map table, 8 vds table, 16 gn barrier timeout)", flags);
+    return PTL_OK;
+}
+
+static void stats_out(const ScanStats& s, ptl_icp_stats* o) {
+    o->sigma = s.sigma; o->err_dt = s.err_dt; o->err_drot = s.err_drot;
+    o->iterations = s.iterations; o->n_corr_last = s.n_corr_last; o->n_in = s.n_in; o->n_valid = s.n_valid;
+    o->n_down = s.n_down; o->n_src = s.n_src; o->sum_cand = s.sum_cand; o->map_voxels = s.map_voxels;
+    o->map_points = s.map_points;
+}
+
+extern "C" int ptl_icp_register_frame(ptl_icp* h, const void* xyz, int dtype, int64_t n, const double* t01,
+                                      double scan_ts, const double* guess, double out_pose[16], ptl_icp_stats* stats) {
+    (void)scan_ts;
+    if (!h || (!xyz && n > 0) || n < 0) return set_err(PTL_ERR_ARG, "bad argument");
+    if (dtype != PTL_F32 && dtype != PTL_F64) return set_err(PTL_ERR_ARG, "dtype must be PTL_F32 or PTL_F64");
+    if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "scan has %lld points, capacity %lld", (long long)n, (long long)h->n_max);
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const size_t esz = dtype == PTL_F32 ? 4 : 8;
+    if (n) HIPCHK(hipMemcpyAsync(h->d_in, xyz, (size_t)n * 3 * esz, hipMemcpyHostToDevice, h->stream));
+    if (t01 && n) HIPCHK(hipMemcpyAsync(h->d_t01, t01, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    if (guess) HIPCHK(hipMemcpyAsync(h->d_ext, guess, 16 * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = icp_enqueue_scan(h, dtype == PTL_F32 ? (const float*)h->d_in : nullptr,
+                              dtype == PTL_F64 ? (const double*)h->d_in : nullptr, t01 ? h->d_t01 : nullptr, n,
+                              guess ? h->d_ext : nullptr);
+    if (rc) return rc;
+    const int64_t k = h->scans_done - 1;
+    double pose[16];
+    ScanStats ss;
+    HIPCHK(hipMemcpyAsync(pose, h->c.traj + 16 * k, sizeof pose, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&ss, h->c.sstats + k, sizeof ss, hipMemcpyDeviceToHost, h->stream));
+    rc = icp_check_flags(h);
+    if (rc) return rc;
+    if (out_pose) memcpy(out_pose, pose, sizeof pose);
+    if (stats) stats_out(ss, stats);
+    return PTL_OK;
+}
+
+extern "C" int ptl_icp_num_poses(ptl_icp* h, int64_t* n) {
+    if (!h || !n) return set_err(PTL_ERR_ARG, "null argument");
+    *n = h->scans_done;
+    return PTL_OK;
+}
+extern "C" int ptl_icp_get_poses(ptl_icp* h, double* out, int64_t max_poses, int64_t* n_written) {
+    if (!h || !out) return set_err(PTL_ERR_ARG, "null argument");
+    const int64_t n = h->scans_done < max_poses ? h->scans_done : max_poses;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    if (n > 0) HIPCHK(hipMemcpyAsync(out, h->c.traj, (size_t)n * 16 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_written) *n_written = n;
+    return PTL_OK;
+}
+__global__ void k_prediction(const DevState* st, double* out) {
+    if (threadIdx.x || blockIdx.x) return;
+    Rt p = (st->n_poses >= 2) ? rt_mul(rt_inv(rt_from16(st->pose_prev)), rt_from16(st->pose_last)) : rt_identity();
+    rt_to16(p, out);
+}
+extern "C" int ptl_icp_get_prediction(ptl_icp* h, double out[16]) {
+    if (!h || !out) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    k_prediction<<<1, 64, 0, h->stream>>>(h->c.st, h->d_ext);
+    HIPCHK(hipMemcpyAsync(out, h->d_ext, 16 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PTL_OK;
+}
+extern "C" int ptl_icp_map_size(ptl_icp* h, int64_t* voxels, int64_t* points) {
+    if (!h) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    DevState st;
+    HIPCHK(hipMemcpyAsync(&st, h->c.st, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (voxels) *voxels = st.n_live;
+    if (points) *points = st.map_points;
+    return PTL_OK;
+}
+extern "C" int ptl_icp_map_points(ptl_icp* h, double* xyz_out, int64_t max_points, int64_t* n_written) {
+    if (!h || !xyz_out) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    double* d_out = nullptr;
+    HIPCHK(dalloc(&d_out, (size_t)(max_points > 0 ? max_points : 1) * 3));
+    HIPCHK(hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream));
+    k_map_export<<<(h->c.pool_cap + 255) / 256, 256, 0, h->stream>>>(h->c, d_out, h->d_counter, (int)max_points);
+    int cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, h->d_counter, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int64_t n = cnt < max_points ? cnt : max_points;
+    if (n > 0) HIPCHK(hipMemcpy(xyz_out, d_out, (size_t)n * 3 * 8, hipMemcpyDeviceToHost));
+    hipFree(d_out);
+    if (n_written) *n_written = n;
+    return PTL_OK;
+}
+static int copy_cloud(ptl_icp* h, const double* d_src, const int* d_n, double* out, int64_t max_points, int64_t* n_written) {
+    if (!h || !out) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    int n = 0;
+    HIPCHK(hipMemcpyAsync(&n, d_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int64_t m = n < max_points ? n : max_points;
+    if (m > 0) HIPCHK(hipMemcpy(out, d_src, (size_t)m * 3 * 8, hipMemcpyDeviceToHost));
+    if (n_written) *n_written = m;
+    return PTL_OK;
+}
+extern "C" int ptl_icp_last_frame_down(ptl_icp* h, double* out, int64_t max_points, int64_t* n_written) {
+    return copy_cloud(h, h ? h->c.fd : nullptr, h ? &h->c.st->n_down : nullptr, out, max_points, n_written);
+}
+extern "C" int ptl_icp_last_source(ptl_icp* h, double* out, int64_t max_points, int64_t* n_written) {
+    return copy_cloud(h, h ? h->c.src0 : nullptr, h ? &h->c.st->n_src : nullptr, out, max_points, n_written);
+}
+
+extern "C" int ptl_icp_map_add(ptl_icp* h, const double* xyz_world, int64_t n, const double origin[3], int prune) {
+    if (!h || (!xyz_world && n > 0)) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    Ctx& c = h->c;
+    hipStream_t s = h->stream;
+    for (int64_t off = 0; off < n; off += h->n_max) {  // batches keep scan order: earlier batch = earlier points
+        const int m = (int)((n - off) < h->n_max ? (n - off) : h->n_max);
+        HIPCHK(hipMemcpyAsync(h->d_in, xyz_world + 3 * off, (size_t)m * 24, hipMemcpyHostToDevice, s));
+        const int nb = (m + 255) / 256;
+        k_map_insert_a<<<nb, 256, 0, s>>>(c, (const double*)h->d_in, nullptr, m, 0);
+        k_map_insert_b<<<nb, 256, 0, s>>>(c, nullptr, m);
+        k_map_insert_c<<<nb, 256, 0, s>>>(c, nullptr, m);
+    }
+    if (prune && origin) {
+        HIPCHK(hipMemcpyAsync(h->d_ext, origin, 24, hipMemcpyHostToDevice, s));
+        k_map_prune<<<(c.pool_cap + 255) / 256, 256, 0, s>>>(c, h->d_ext, 0);
+    }
+    return icp_check_flags(h);
+}
+
+__global__ void k_set_gn(DevState* st, int n_src, double max_dist, double kernel, const double* guess) {
+    if (threadIdx.x || blockIdx.x) return;
+    st->n_src = n_src; st->gn_max_dist = max_dist; st->gn_kernel = kernel; st->bar = 0;
+    if (guess) for (int i = 0; i < 16; ++i) st->guess[i] = guess[i];
+}
+extern "C" int ptl_icp_linear_system(ptl_icp* h, const double* src_world, int64_t n, double max_dist, double kernel,
+                                     double sums[27], int64_t* n_corr, int64_t* n_cand) {
+    if (!h || !src_world || !sums) return set_err(PTL_ERR_ARG, "null argument");
+    if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "too many points");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    Ctx& c = h->c;
+    HIPCHK(hipMemcpyAsync(c.src_cur, src_world, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
+    k_set_gn<<<1, 64, 0, h->stream>>>(c.st, (int)n, max_dist, kernel, nullptr);
+    k_gn_loop<<<c.G, 256, 0, h->stream>>>(c, 1);
+    double out[32];
+    HIPCHK(hipMemcpyAsync(out, (char*)c.st + offsetof(DevState, dbg_sums), sizeof out, hipMemcpyDeviceToHost, h->stream));
+    int rc = icp_check_flags(h);
+    if (rc) return rc;
+    memcpy(sums, out, 27 * 8);
+    if (n_corr) *n_corr = (int64_t)out[27];
+    if (n_cand) *n_cand = (int64_t)out[28];
+    return PTL_OK;
+}
+extern "C" int ptl_icp_align(ptl_icp* h, const double* frame, int64_t n, const double guess[16], double max_dist,
+                             double kernel, double out_pose[16], int32_t* iterations) {
+    if (!h || !frame || !guess || !out_pose) return set_err(PTL_ERR_ARG, "null argument");
+    if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "too many points");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    Ctx& c = h->c;
+    HIPCHK(hipMemcpyAsync(c.src0, frame, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_ext, guess, 128, hipMemcpyHostToDevice, h->stream));
+    k_set_gn<<<1, 64, 0, h->stream>>>(c.st, (int)n, max_dist, kernel, h->d_ext);
+    k_gn_loop<<<c.G, 256, 0, h->stream>>>(c, 0);
+    k_post_icp<<<1, 64, 0, h->stream>>>(c);  // new_pose = T_icp * guess (does not append to the trajectory index)
+    DevState st;
+    HIPCHK(hipMemcpyAsync(&st, c.st, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    int rc = icp_check_flags(h);
+    if (rc) return rc;
+    memcpy(out_pose, st.new_pose, 128);
+    if (iterations) *iterations = st.gn_iters;
+    return PTL_OK;
+}
+
+extern "C" int ptl_icp_profile(ptl_icp* h, int enable, double* gn_ms_total, int64_t* gn_launches, int reset) {
+    if (!h) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    icp_collect_profile(h);
+    if (gn_ms_total) *gn_ms_total = h->gn_ms;
+    if (gn_launches) *gn_launches = h->gn_launches;
+    if (reset) { h->gn_ms = 0; h->gn_launches = 0; }
+    h->prof = enable != 0;
+    return PTL_OK;
+}
+
+// ================================================================================================ EKF
+struct ptl_ekf {
+    ptl_ekf_cfg cfg;
+    hipStream_t stream;
+    bool own_stream;
+    EkfState* st;
+    double* d_buf;  // staging: imu rows / pose / cov
+    int64_t buf_rows;
+};
+
+extern "C" int ptl_ekf_default_cfg(ptl_ekf_cfg* cfg) {
+    if (!cfg) return set_err(PTL_ERR_ARG, "cfg is null");
+    memset(cfg, 0, sizeof *cfg);
+    cfg->init_grav[2] = -9.782940329221166;  // GRAV * DOWN (es_ekf.py:75, ins/data.py:10)
+    return PTL_OK;
+}
+static int ekf_reset(ptl_ekf* h) {
+    HIPCHK(hipMemcpyAsync(h->d_buf, h->cfg.init_grav, 24, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_buf + 3, h->cfg.init_bacc, 24, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_buf + 6, h->cfg.init_bgyr, 24, hipMemcpyHostToDevice, h->stream));
+    k_ekf_init<<<1, 64, 0, h->stream>>>(h->st, h->d_buf, h->d_buf + 3, h->d_buf + 6);
+    HIPCHK(hipGetLastError());
+    return PTL_OK;
+}
+static int ekf_create_impl(const ptl_ekf_cfg* cfg, hipStream_t shared, ptl_ekf** out) {
+    if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
+    if (ptl_device_count() <= cfg->device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->device_id);
+    HIPCHK(hipSetDevice(cfg->device_id));
+    ptl_ekf* h = new ptl_ekf();
+    h->cfg = *cfg;
+    h->own_stream = shared == nullptr;
+    h->stream = shared;
+    h->st = nullptr; h->d_buf = nullptr; h->buf_rows = 1024;
+    if (h->own_stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return set_err(PTL_ERR_HIP, "stream"); }
+    if (dalloc(&h->st, 1) != hipSuccess || dalloc(&h->d_buf, (size_t)h->buf_rows * 7 + 64) != hipSuccess) {
+        if (h->st) hipFree(h->st);
+        delete h;
+        return set_err(PTL_ERR_HIP, "device allocation failed");
+    }
+    int rc = ekf_reset(h);
+    if (rc == PTL_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = set_err(PTL_ERR_HIP, "sync");
+    if (rc) { hipFree(h->st); hipFree(h->d_buf); delete h; return rc; }
+    *out = h;
+    return PTL_OK;
+}
+extern "C" int ptl_ekf_create(const ptl_ekf_cfg* cfg, ptl_ekf** out) { return ekf_create_impl(cfg, nullptr, out); }
+extern "C" int ptl_ekf_destroy(ptl_ekf* h) {
+    if (!h) return PTL_OK;
+    hipSetDevice(h->cfg.device_id);
+    hipFree(h->st); hipFree(h->d_buf);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+    return PTL_OK;
+}
+extern "C" int ptl_ekf_process_imu_batch(ptl_ekf* h, const double* imu, int64_t n) {
+    if (!h || (!imu && n > 0)) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    for (int64_t off = 0; off < n; off += h->buf_rows) {
+        const int m = (int)((n - off) < h->buf_rows ? (n - off) : h->buf_rows);
+        HIPCHK(hipMemcpyAsync(h->d_buf, imu + 7 * off, (size_t)m * 56, hipMemcpyHostToDevice, h->stream));
+        k_ekf_step<<<1, 384, 0, h->stream>>>(h->st, h->d_buf, 0, m, nullptr, nullptr, nullptr, nullptr, nullptr);
+        HIPCHK(hipStreamSynchronize(h->stream));  // staging buffer reuse
+    }
+    HIPCHK(hipGetLastError());
+    return PTL_OK;
+}
+extern "C" int ptl_ekf_process_imu(ptl_ekf* h, const double lacc[3], const double avel[3], double ts) {
+    if (!h || !lacc || !avel) return set_err(PTL_ERR_ARG, "null argument");
+    const double row[7] = {ts, lacc[0], lacc[1], lacc[2], avel[0], avel[1], avel[2]};
+    return ptl_ekf_process_imu_batch(h, row, 1);
+}
+extern "C" int ptl_ekf_process_pose(ptl_ekf* h, const double pose[16], const double* meas_cov36) {
+    if (!h || !pose) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->d_buf, pose, 128, hipMemcpyHostToDevice, h->stream));
+    if (meas_cov36) HIPCHK(hipMemcpyAsync(h->d_buf + 16, meas_cov36, 288, hipMemcpyHostToDevice, h->stream));
+    k_ekf_step<<<1, 384, 0, h->stream>>>(h->st, nullptr, 0, 0, h->d_buf, meas_cov36 ? h->d_buf + 16 : nullptr, nullptr, nullptr, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PTL_OK;
+}
+extern "C" int ptl_ekf_get_state(ptl_ekf* h, double nav[19], double cov[324]) {
+    if (!h) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    EkfState st;
+    HIPCHK(hipMemcpyAsync(&st, h->st, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (nav) {
+        memcpy(nav, st.pos, 24); memcpy(nav + 3, st.q, 32); memcpy(nav + 7, st.vel, 24);
+        memcpy(nav + 10, st.bg, 24); memcpy(nav + 13, st.ba, 24); memcpy(nav + 16, st.grav, 24);
+    }
+    if (cov) memcpy(cov, st.P, sizeof st.P);
+    return PTL_OK;
+}
+extern "C" int ptl_ekf_pose_mat(ptl_ekf* h, double T[16]) {
+    if (!h || !T) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(T, (char*)h->st + offsetof(EkfState, pose), 128, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PTL_OK;
+}
+extern "C" int ptl_ekf_ts(ptl_ekf* h, double* ts) {
+    if (!h || !ts) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(ts, (char*)h->st + offsetof(EkfState, cur_ts), 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PTL_OK;
+}
+
+// ================================================================================================ sequence runner
+struct ptl_seq {
+    ptl_seq_cfg cfg;
+    hipStream_t stream;
+    ptl_icp* icp;
+    ptl_ekf* ekf;
+    float* d_scans;      // [n_scans][pps][3] f32
+    double* d_imu;       // [n_imu][7]
+    std::vector<int64_t> imu_end;
+    double* d_res_poses; // [n_scans][16]
+    double* d_res_t;     // [n_scans]
+    double* d_rows;      // [n_scans][8]
+    std::vector<int64_t> scan_of_out;  // scan index of each processed output
+    int64_t n_out;
+};
+
+extern "C" int ptl_seq_destroy(ptl_seq* s) {
+    if (!s) return PTL_OK;
+    hipSetDevice(s->cfg.icp.device_id);
+    if (s->icp) icp_free(s->icp);
+    if (s->ekf) ptl_ekf_destroy(s->ekf);
+    if (s->d_scans) hipFree(s->d_scans);
+    if (s->d_imu) hipFree(s->d_imu);
+    if (s->d_res_poses) hipFree(s->d_res_poses);
+    if (s->d_res_t) hipFree(s->d_res_t);
+    if (s->d_rows) hipFree(s->d_rows);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return PTL_OK;
+}
+extern "C" int ptl_seq_create(const ptl_seq_cfg* cfg, ptl_seq** out) {
+    if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
+    if (cfg->n_scans < 1 || cfg->points_per_scan < 1) return set_err(PTL_ERR_ARG, "empty sequence");
+    if (ptl_device_count() <= cfg->icp.device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->icp.device_id);
+    HIPCHK(hipSetDevice(cfg->icp.device_id));
+    ptl_seq* s = new ptl_seq();
+    s->cfg = *cfg;
+    s->icp = nullptr; s->ekf = nullptr; s->d_scans = nullptr; s->d_imu = nullptr;
+    s->d_res_poses = nullptr; s->d_res_t = nullptr; s->d_rows = nullptr; s->n_out = 0; s->stream = nullptr;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return set_err(PTL_ERR_HIP, "stream"); }
+    ptl_icp_cfg ic = cfg->icp;
+    if (ic.max_points_per_scan < cfg->points_per_scan) ic.max_points_per_scan = cfg->points_per_scan;
+    s->cfg.icp = ic;
+    ptl_ekf_cfg ec = cfg->ekf;
+    ec.device_id = ic.device_id;
+    int rc = icp_create_impl(&ic, s->stream, &s->icp);
+    if (rc == PTL_OK) rc = ekf_create_impl(&ec, s->stream, &s->ekf);
+    const size_t nim = cfg->n_imu > 0 ? (size_t)cfg->n_imu : 1;
+    if (rc == PTL_OK &&
+        (hipMalloc((void**)&s->d_scans, (size_t)cfg->n_scans * cfg->points_per_scan * 12) != hipSuccess ||
+         dalloc(&s->d_imu, nim * 7) != hipSuccess || dalloc(&s->d_res_poses, (size_t)cfg->n_scans * 16) != hipSuccess ||
+         dalloc(&s->d_res_t, (size_t)cfg->n_scans) != hipSuccess || dalloc(&s->d_rows, (size_t)cfg->n_scans * 8) != hipSuccess))
+        rc = set_err(PTL_ERR_HIP, "sequence allocation failed (%.1f MB of scans)", cfg->n_scans * cfg->points_per_scan * 12 / 1e6);
+    if (rc) { ptl_seq_destroy(s); return rc; }
+    s->imu_end.assign((size_t)cfg->n_scans, 0);
+    *out = s;
+    return PTL_OK;
+}
+extern "C" int ptl_seq_upload_scan(ptl_seq* s, int64_t k, const float* xyz) {
+    if (!s || !xyz || k < 0 || k >= s->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(s->cfg.icp.device_id));
+    const size_t bytes = (size_t)s->cfg.points_per_scan * 12;
+    HIPCHK(hipMemcpy((char*)s->d_scans + (size_t)k * bytes, xyz, bytes, hipMemcpyHostToDevice));
+    return PTL_OK;
+}
+extern "C" int ptl_seq_upload_imu(ptl_seq* s, const double* imu, const int64_t* imu_end) {
+    if (!s || !imu_end || (!imu && s->cfg.n_imu > 0)) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(s->cfg.icp.device_id));
+    if (s->cfg.n_imu > 0) HIPCHK(hipMemcpy(s->d_imu, imu, (size_t)s->cfg.n_imu * 56, hipMemcpyHostToDevice));
+    for (int64_t k = 0; k < s->cfg.n_scans; ++k) {
+        if (imu_end[k] < 0 || imu_end[k] > s->cfg.n_imu || (k && imu_end[k] < imu_end[k - 1])) return set_err(PTL_ERR_ARG, "imu_end must be non-decreasing within [0, n_imu]");
+        s->imu_end[(size_t)k] = imu_end[k];
+    }
+    return PTL_OK;
+}
+// The reference's driver loop (cli/ekf_bench.py:493-563) enqueued for scans [0, n): IMU samples up to the
+// scan -> EKF predict; scan -> guess (EKF nav pose when use_imu_prediction) -> ICP -> EKF update.
+extern "C" int ptl_seq_run(ptl_seq* s, int64_t n) {
+    if (!s || n < 0 || n > s->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(s->cfg.icp.device_id));
+    int rc = icp_reset_device(s->icp);
+    if (rc) return rc;
+    rc = ekf_reset(s->ekf);
+    if (rc) return rc;
+    s->scan_of_out.clear();
+    s->n_out = 0;
+    const bool with_ekf = s->cfg.with_ekf != 0;
+    const double* guess_ptr = (with_ekf && s->cfg.use_imu_prediction) ? (const double*)((char*)s->ekf->st + offsetof(EkfState, pose)) : nullptr;
+    int64_t imu_pos = 0;
+    int64_t imus_per_scan = 1;  // ekf_bench.py:491
+    const size_t pps = (size_t)s->cfg.points_per_scan;
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t e = with_ekf ? s->imu_end[(size_t)k] : imu_pos;
+        if (e > imu_pos) {
+            k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, s->d_imu, (int)imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr);
+            imus_per_scan += e - imu_pos;
+            imu_pos = e;
+        }
+        if (with_ekf && !imus_per_scan) continue;  // ekf_bench.py:512-518
+        imus_per_scan = 0;
+        rc = icp_enqueue_scan(s->icp, s->d_scans + (size_t)k * pps * 3, nullptr, nullptr, (int64_t)pps, guess_ptr);
+        if (rc) return rc;
+        const int64_t o = s->n_out;
+        if (with_ekf) {
+            const double* kiss_pose = s->icp->c.traj + 16 * (s->icp->scans_done - 1);
+            k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, nullptr, 0, 0, kiss_pose, nullptr, s->d_res_poses + 16 * o,
+                                                s->d_res_t + o, s->d_rows + 8 * o);
+        }
+        s->scan_of_out.push_back(k);
+        s->n_out++;
+    }
+    HIPCHK(hipGetLastError());
+    return icp_check_flags(s->icp);
+}
+extern "C" int ptl_seq_results(ptl_seq* s, double* res_poses, double* res_t, double* kiss_poses, ptl_icp_stats* stats,
+                               int64_t max_n, int64_t* n_out) {
+    if (!s) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(s->cfg.icp.device_id));
+    const int64_t n = s->n_out < max_n ? s->n_out : max_n;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (n > 0) {
+        if (res_poses && s->cfg.with_ekf) HIPCHK(hipMemcpy(res_poses, s->d_res_poses, (size_t)n * 128, hipMemcpyDeviceToHost));
+        if (res_t && s->cfg.with_ekf) HIPCHK(hipMemcpy(res_t, s->d_res_t, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (kiss_poses) HIPCHK(hipMemcpy(kiss_poses, s->icp->c.traj, (size_t)n * 128, hipMemcpyDeviceToHost));
+        if (stats) {
+            std::vector<ScanStats> tmp((size_t)n);
+            HIPCHK(hipMemcpy(tmp.data(), s->icp->c.sstats, (size_t)n * sizeof(ScanStats), hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; ++i) stats_out(tmp[(size_t)i], &stats[i]);
+        }
+    }
+    if (n_out) *n_out = n;
+    return PTL_OK;
+}
+extern "C" int ptl_seq_traj_device(ptl_seq* s, void** dev_ptr, int64_t* rows) {
+    if (!s || !dev_ptr || !rows) return set_err(PTL_ERR_ARG, "null argument");
+    *dev_ptr = s->d_rows;
+    *rows = s->n_out;
+    return PTL_OK;
+}
+extern "C" int ptl_seq_icp(ptl_seq* s, ptl_icp** icp) {
+    if (!s || !icp) return set_err(PTL_ERR_ARG, "null argument");
+    *icp = s->icp;
+    return PTL_OK;
+}
+extern "C" int ptl_seq_profile(ptl_seq* s, int enable, double* gn_ms_total, int64_t* gn_launches, int reset) {
+    if (!s) return set_err(PTL_ERR_ARG, "null argument");
+    return ptl_icp_profile(s->icp, enable, gn_ms_total, gn_launches, reset);
+}

@@ -1,0 +1,231 @@
+"""GPU parity: the HIP path (through the C-ABI of include/ptudes_mi.h) against the CPU oracle on the
+same seeded inputs, and against the golden vectors generated from the reference itself.
+
+Tolerances: integer / index work bit-exact (point selections, counts); EKF state and
+covariance 1e-9; ICP teacher-forced |dt| <= 2e-4 m, angle <= 2e-5 rad; free-running trajectories
+RMSE <= 1 cm over the compared span.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ptudes_lab_amd  # noqa: F401  (import shim)
+from oracle import cpu as orc
+from ptudes_lab_amd import core, synth
+
+pytestmark = pytest.mark.gpu
+
+EKF_TOL = 1e-9
+ICP_T_TOL, ICP_R_TOL = 2e-4, 2e-5
+
+
+def _quat_close(a, b, tol):
+    return min(np.abs(a - b).max(), np.abs(a + b).max()) <= tol
+
+
+def _nav_close(a, b, tol=EKF_TOL):
+    assert np.abs(a[:3] - b[:3]).max() <= tol
+    assert _quat_close(a[3:7], b[3:7], tol)
+    assert np.abs(a[7:] - b[7:]).max() <= tol
+
+
+def _pose_diff(A, B):
+    D = np.linalg.inv(A) @ B
+    return np.linalg.norm(D[:3, 3]), orc.rot_angle(D)
+
+
+# ------------------------------------------------------------------------------------------------ EKF
+@pytest.mark.parametrize("variant", ["default", "init", "cov"])
+def test_ekf_golden_steps(golden_dir, variant):
+    g = np.load(os.path.join(golden_dir, f"ekf_steps_{variant}.npz"))
+    default = variant != "init"
+    ekf = core.Ekf(None if default else g["init_grav"], None if default else g["init_bacc"],
+                   None if default else g["init_bgyr"])
+    assert np.abs(ekf.cov - g["cov0"]).max() <= 1e-12
+    upd = {int(i): k for k, i in enumerate(g["upd_idx"])}
+    for i in range(len(g["imu_ts"])):
+        ekf.process_imu(g["imu_lacc"][i], g["imu_avel"][i], g["imu_ts"][i])
+        nav, cov = ekf.state()
+        _nav_close(nav, g["nav_after_imu"][i])
+        if i in upd:
+            k = upd[i]
+            ref = g["cov_pre"][k]
+            assert np.abs(cov - ref).max() <= EKF_TOL * max(1.0, np.abs(ref).max())
+            ekf.process_pose(g["upd_pose"][k], g["upd_cov"][k] if bool(g["has_cov"]) else None)
+            nav, cov = ekf.state()
+            ref = g["cov_post"][k]
+            assert np.abs(cov - ref).max() <= EKF_TOL * max(1.0, np.abs(ref).max())
+            _nav_close(nav, g["nav_after_upd"][k])
+    assert ekf.ts == float(g["final_ts"])
+
+
+def test_ekf_golden_sim_batched(golden_dir):
+    """ekf-bench sim (reference cli/ekf_bench.py:107-179): IMU batches between updates in one launch each."""
+    g = np.load(os.path.join(golden_dir, "ekf_sim.npz"))
+    ekf_gt, ekf = core.Ekf(), core.Ekf()
+    ts = g["ts"]
+    rows_i = np.c_[ts, g["ideal_lacc"], g["ideal_avel"]]
+    rows_n = np.c_[ts, g["noisy_lacc"], g["noisy_avel"]]
+    last_corr, start, n_upd = ts[0], 0, 0
+    for i in range(len(ts)):
+        if ts[i] - last_corr > 0.1:
+            ekf_gt.process_imu_batch(rows_i[start:i + 1])
+            ekf.process_imu_batch(rows_n[start:i + 1])
+            start = i + 1
+            ekf.process_pose(ekf_gt.pose_mat())
+            last_corr = ts[i]
+            n_upd += 1
+    ekf_gt.process_imu_batch(rows_i[start:])
+    ekf.process_imu_batch(rows_n[start:])
+    assert n_upd == int(g["n_updates"])
+    _nav_close(ekf_gt.nav, g["nav_gt"])
+    _nav_close(ekf.nav, g["nav"])
+    assert np.abs(ekf.cov - g["cov"]).max() <= EKF_TOL * np.abs(g["cov"]).max()
+
+
+# ------------------------------------------------------------------------------------------------ ICP stages
+@pytest.fixture(scope="module")
+def seq():
+    return synth.make_sequence(seed=1000, n_scans=40)
+
+
+def _sorted_rows(a):
+    return a[np.lexsort(a.T[::-1])]
+
+
+def test_map_and_linear_system_teacher_forced(seq):
+    """VoxelHashMap::AddPoints/prune + GetCorrespondences/BuildLinearSystem on identical inputs."""
+    rng = np.random.default_rng(3)
+    gt = seq.gt_poses(0.5)
+    icp = core.Icp(70.0, 1.0)
+    m = orc.Map(0.7, 70.0, 20)
+    for k in range(3):
+        x = seq.scan(k).astype(np.float64)
+        fd = orc.voxel_downsample(orc.preprocess(x, 70.0, 1.0), 0.35)
+        T = np.linalg.inv(gt[0]) @ gt[k]
+        w = (T @ np.c_[fd, np.ones(len(fd))].T).T[:, :3].copy()
+        m.add_points(w)
+        m.prune(T[:3, 3])
+        icp.map_add(w, origin=T[:3, 3])
+    assert icp.map_size() == (m.num_voxels, m.num_points)
+    assert np.array_equal(_sorted_rows(icp.map_points()), _sorted_rows(m.points()))  # bit-exact content
+    x = seq.scan(3).astype(np.float64)
+    src = orc.voxel_downsample(orc.voxel_downsample(orc.preprocess(x, 70.0, 1.0), 0.35), 1.05)
+    T = np.linalg.inv(gt[0]) @ gt[3] @ orc.se3_exp(rng.normal(0, 0.02, 6))
+    sw = (T @ np.c_[src, np.ones(len(src))].T).T[:, :3].copy()
+    for sigma in (2.0, 0.4):
+        s_ref, nc_ref, cand_ref = m.linear_system(sw, 3 * sigma, sigma / 3)
+        s_gpu, nc, cand = icp.linear_system(sw, 3 * sigma, sigma / 3)
+        assert (nc, cand) == (nc_ref, cand_ref)
+        assert np.abs(s_gpu - s_ref).max() <= 1e-9 * np.abs(s_ref).max()
+    # full Gauss-Newton loop on the same map
+    out_ref, it_ref, _, _ = m.register(src, T, 6.0, 2 / 3)
+    out_gpu, it_gpu = icp.align(src, T, 6.0, 2 / 3)
+    dt, dr = _pose_diff(out_ref, out_gpu)
+    assert dt <= ICP_T_TOL and dr <= ICP_R_TOL
+    assert abs(it_gpu - it_ref) <= 1
+
+
+def test_map_prune_and_capacity(seq):
+    """cap of 20 points per voxel in insertion order, first-point pruning, empty / ragged batches"""
+    rng = np.random.default_rng(5)
+    icp = core.Icp(30.0, 1.0, max_points_per_scan=20000)
+    m = orc.Map(0.3, 30.0, 20)
+    pos = np.zeros(3)
+    for step in range(12):
+        pos = pos + np.array([4.0, 1.0, 0.0])
+        n = [0, 1, 257, 5000, 19999][step % 5]
+        P = pos + rng.normal(0, 6, (n, 3))
+        P[: n // 3] = np.round(P[: n // 3] * 2) / 2 + rng.normal(0, 0.02, (n // 3, 3))  # crowded voxels
+        m.add_points(P)
+        m.prune(pos)
+        icp.map_add(P, origin=pos)
+        assert icp.map_size() == (m.num_voxels, m.num_points)
+    assert np.array_equal(_sorted_rows(icp.map_points()), _sorted_rows(m.points()))
+
+
+def test_register_frame_teacher_forced_guess(seq):
+    """per-scan pipeline (reference kiss.py:83-131) with the same external guess on both sides:
+    selections bit-exact, poses within the ICP tolerance, stats identical"""
+    gt = seq.gt_poses(0.5)
+    g0i = np.linalg.inv(gt[0])
+    t01 = seq.column_times()
+    icp = core.Icp(70.0, 1.0)
+    ref = orc.ICP(70.0, 1.0)
+    for k in range(8):
+        x32 = seq.scan(k)
+        guess = g0i @ gt[k]
+        Tr = ref.register_frame(x32.astype(np.float64), t01, guess)
+        Tg = icp.register_frame(x32, None, guess)  # f32 input, column-implicit times
+        sr, sg = ref.stats[-1], icp.stats[-1]
+        for key in ("n_in", "n_valid", "n_down", "n_src"):
+            assert sr[key] == sg[key], (k, key, sr[key], sg[key])
+        if k < 2:  # no deskew yet: identical fp64 arithmetic => identical clouds
+            assert np.array_equal(icp.last_frame_down(), ref.last_frame_down())
+            assert np.array_equal(icp.last_source(), ref.last_source())
+        else:
+            assert np.abs(icp.last_frame_down() - ref.last_frame_down()).max() <= 1e-9
+        dt, dr = _pose_diff(Tr, Tg)
+        assert dt <= ICP_T_TOL and dr <= ICP_R_TOL, (k, dt, dr)
+        assert abs(sr["sigma"] - sg["sigma"]) <= 1e-9
+        assert abs(sr["iterations"] - sg["iterations"]) <= 1
+        assert (sr["map_voxels"], sr["map_points"]) == (sg["map_voxels"], sg["map_points"])
+
+
+def test_register_frame_edge_cases():
+    icp = core.Icp(70.0, 1.0)
+    # empty scan, all-invalid scan: first pose is the guess (identity), nothing enters the map
+    T = icp.register_frame(np.zeros((0, 3)), np.zeros(0))
+    assert np.array_equal(T, np.eye(4))
+    T = icp.register_frame(np.zeros((500, 3), dtype=np.float32), None)
+    assert np.array_equal(T, np.eye(4)) and icp.map_size() == (0, 0)
+    with pytest.raises(RuntimeError):
+        icp.register_frame(np.zeros((200000, 3)), np.zeros(200000))  # above max_points_per_scan
+    with pytest.raises(ValueError):
+        icp.register_frame(np.zeros((10, 2)), None)
+
+
+# ------------------------------------------------------------------------------------------------ sequence
+def _upload(seq, runner, n):
+    for k in range(n):
+        runner.upload_scan(k, seq.scan(k))
+    ends = [seq.imu_range_for_scan(k)[1] for k in range(n)]
+    runner.upload_imu(seq.imu[: ends[-1]], ends)
+
+
+def test_sequence_imu_prediction_vs_oracle(seq):
+    """driver loop (reference cli/ekf_bench.py:493-563, --use-imu-prediction) free-running on device
+    against the oracle's loop on the same events"""
+    n = 30
+    ref = orc.run_sequence(seq.events(n), max_range=70.0, min_range=1.0, use_imu_prediction=True)
+    r = core.SeqRunner(n, seq.H * seq.W, seq.imu_range_for_scan(n - 1)[1], max_range=70.0, min_range=1.0,
+                       use_imu_prediction=True, with_ekf=True)
+    _upload(seq, r, n)
+    r.run()
+    out = r.results()
+    assert len(out["kiss_poses"]) == n == len(ref["kiss_poses"])
+    assert np.array_equal(out["res_t"], ref["res_t"])
+    d_kiss = [np.linalg.norm(out["kiss_poses"][k][:3, 3] - ref["kiss_poses"][k][:3, 3]) for k in range(n)]
+    d_ekf = [np.linalg.norm(out["res_poses"][k][:3, 3] - ref["res_poses"][k][:3, 3]) for k in range(n)]
+    assert np.sqrt(np.mean(np.square(d_kiss))) <= 0.01, d_kiss
+    assert np.sqrt(np.mean(np.square(d_ekf))) <= 0.01, d_ekf
+    ate_r, ate_t = orc.calc_ate(out["res_poses"], ref["res_poses"])
+    assert ate_t <= 1e-4
+
+
+def test_sequence_icp_only_matches_per_call(seq):
+    """SeqRunner (no host sync per scan) == the per-call API on the same scans (constant-velocity guess)"""
+    n = 12
+    r = core.SeqRunner(n, seq.H * seq.W, 0, max_range=70.0, min_range=1.0, with_ekf=False)
+    for k in range(n):
+        r.upload_scan(k, seq.scan(k))
+    r.upload_imu(np.zeros((0, 7)), [0] * n)
+    r.run()
+    out = r.results()
+    icp = core.Icp(70.0, 1.0)
+    per_call = [icp.register_frame(seq.scan(k), None) for k in range(n)]
+    assert np.array_equal(out["kiss_poses"], np.array(per_call))  # same kernels, same order => bit-exact
+    # deterministic across runs
+    r.run()
+    assert np.array_equal(r.results()["kiss_poses"], out["kiss_poses"])
