@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- lidar scans/sec (ICP+EKF) on synthetic 128x1024 sweeps, MI355X.
+
+A "step" is one pass of the hot path (reference cli/ekf_bench.py:493-563: IMU predicts -> scan
+registration against the local map -> EKF pose update) over one batch of synthetic input = one sweep
+of each sequence this rank owns.  Inputs (all sweeps + IMU) are resident in HBM before the timed
+region.  Warm-up steps are the first W sweeps of the same sequence (they also build the local map, so
+the timed region is steady state).  One rank per GPU; ranks own independent sequences (no data-path
+collective); the only collective is the final trajectory all-gather over RCCL.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def icp_bytes(stats):
+    """Algorithmic bytes of one Gauss-Newton launch (B_icp): per iteration the source is
+    read once (12 B/pt), 27 hash slots are probed per point (16 B each) and every candidate map point is
+    read (12 B each): sum_i [12 N_s + 27*16 N_s + 12 C_i]."""
+    return stats["iterations"] * (12 + 27 * 16) * stats["n_src"] + 12 * stats["sum_cand"]
+
+
+def scan_bytes(s, n_raw):
+    """B_scan of SURVEY.md 8(d) for one sweep"""
+    nv, nd, ns, mv = s["n_valid"], s["n_down"], s["n_src"], s["map_voxels"]
+    b_pre = 12 * n_raw + 12 * nv
+    b_ds = (12 + 16) * nv + 12 * nd + (12 + 16) * nd + 12 * ns
+    b_map = (12 + 16 + 12) * nd + (16 + 12) * mv
+    return b_pre + b_ds + icp_bytes(s) + b_map
+
+
+def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0):
+    """The CPU oracle (kind "port": our C restatement of the reference path, single thread) timed on this
+    host on the first sweeps of the same sequence, until ~budget_s seconds of CPU work are spent."""
+    from oracle import cpu as orc
+    icp = orc.ICP(max_range=seq.max_range, min_range=seq.min_range)
+    ekf = orc.EKF()
+    t01 = seq.column_times()
+    kiss, res = [], []
+    spent, done = 0.0, 0
+    for k in range(n_total):
+        x = seq.scan(k).astype(np.float64)  # rendering is not part of the timed work
+        a, b = seq.imu_range_for_scan(k)
+        t0 = time.perf_counter()
+        for i in range(a, b):
+            ekf.process_imu(seq.imu[i, 1:4], seq.imu[i, 4:7], seq.imu[i, 0])
+        guess = ekf.pose_mat() if use_imu_prediction else None
+        pose = icp.register_frame(x, t01, guess)
+        ekf.process_pose(pose)
+        spent += time.perf_counter() - t0
+        kiss.append(pose)
+        res.append(ekf.pose_mat())
+        done += 1
+        if spent >= budget_s:
+            break
+    return dict(value=done / spent, unit="scans/s", cores=1, kind="port",
+                sample=f"first {done} sweeps of sequence seed {seq.seed} (cold start), {spent:.1f} s of CPU work, "
+                       f"oracle/liboracle.so single thread, host has {os.cpu_count()} logical cores"), \
+        np.array(kiss), np.array(res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--seqs-per-gpu", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=128)
+    ap.add_argument("--cols", type=int, default=1024)
+    ap.add_argument("--max-range", type=float, default=70.0)
+    ap.add_argument("--min-range", type=float, default=1.0)
+    ap.add_argument("--const-velocity", action="store_true",
+                    help="use the constant-velocity guess instead of --use-imu-prediction (reference default)")
+    ap.add_argument("--gn-wgs", type=int, default=0, help="workgroups of the persistent GN kernel (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import ptudes_lab_amd  # noqa: F401
+    from ptudes_lab_amd import core, synth
+
+    K, W, S = args.steps, args.warmup, args.seqs_per_gpu
+    n_total = W + K
+    use_imu = not args.const_velocity
+    pps = args.rows * args.cols
+    seqs, runners = [], []
+    for j in range(S):
+        seed = 1000 + rank * S + j
+        sq = synth.make_sequence(seed=seed, n_scans=n_total, H=args.rows, W=args.cols, min_range=args.min_range,
+                                 max_range=args.max_range)
+        n_imu = sq.imu_range_for_scan(n_total - 1)[1]
+        r = core.SeqRunner(n_total, pps, n_imu, max_range=args.max_range, min_range=args.min_range,
+                           use_imu_prediction=use_imu, with_ekf=True, device_id=local_rank, scan_cols=args.cols,
+                           **({"gn_workgroups": args.gn_wgs} if args.gn_wgs else {}))
+        for k in range(n_total):
+            r.upload_scan(k, sq.scan(k))
+        r.upload_imu(sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n_total)])
+        seqs.append(sq)
+        runners.append(r)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def sync():
+        if torch is not None:
+            torch.cuda.synchronize()
+        core.device_sync(local_rank)
+
+    # warm-up: cold start + the first W sweeps (untimed)
+    for r in runners:
+        r.run(W)
+        r.profile(enable=True, reset=True)
+    barrier(); sync()
+    t0 = time.perf_counter()
+    for r in runners:
+        r.enqueue(K)
+    for r in runners:
+        r.wait()
+    sync(); barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-rank accounting
+    outs = [r.results() for r in runners]
+    gn_ms, gn_n, gn_bytes, b_scan = 0.0, 0, 0.0, 0.0
+    iters = []
+    for r, o in zip(runners, outs):
+        ms, n = r.profile(enable=False)
+        gn_ms += ms
+        gn_n += n
+        for s in o["stats"][W:]:
+            gn_bytes += icp_bytes(s)
+            b_scan += scan_bytes(s, pps)
+            iters.append(s["iterations"])
+    n_timed = sum(len(o["stats"]) - W for o in outs)
+    assert n_timed == K * S, (n_timed, K, S)
+
+    # final trajectory gather: the only collective (T x 8 NC-GT rows per sequence)
+    gathered = None
+    if dist is not None:
+        rows = torch.zeros((S, n_total, 8), dtype=torch.float64, device="cuda")
+        for j, r in enumerate(runners):
+            r.copy_traj(rows[j].data_ptr(), n_total)
+        allrows = [torch.empty_like(rows) for _ in range(world)]
+        dist.all_gather(allrows, rows)
+        gathered = torch.stack(allrows).cpu().numpy()
+
+    if rank == 0:
+        from oracle import cpu as orc
+        o, sq = outs[0], seqs[0]
+        gt = sq.gt_poses(0.5)
+        g0i = np.linalg.inv(gt[0])
+        gt_rel = np.array([g0i @ g for g in gt])
+        ate_r, ate_t = orc.calc_ate(o["res_poses"], gt_rel[: len(o["res_poses"])])
+        rmse_gt = float(np.sqrt(np.mean(np.sum((o["res_poses"][:, :3, 3] - gt_rel[: len(o["res_poses"]), :3, 3]) ** 2, 1))))
+        avg_gn_s = (gn_ms / 1e3) / max(gn_n, 1)
+        avg_gn_bytes = gn_bytes / max(n_timed, 1)
+        achieved = avg_gn_bytes / avg_gn_s if avg_gn_s > 0 else 0.0
+        line = {
+            "metric": "lidar scans/sec (ICP+EKF) on 128x1024 sweeps",
+            "value": K * S * world / dt, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.rows}x{args.cols} sweeps, random-walk SE(3) GT, "
+                                   f"ICP + IMU-EKF ({'--use-imu-prediction' if use_imu else 'constant-velocity guess'}), "
+                                   f"min/max range {args.min_range}/{args.max_range} m, voxel {args.max_range / 100:.2f} m",
+                       "sequences_per_gpu": S, "sequence_seeds": f"{1000}..{1000 + world * S - 1}",
+                       "scans_per_sequence": n_total, "parallelism": f"{world} independent sequence shard(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "k_gn_loop",
+                         "avg_launch_us": 1e6 * avg_gn_s, "algorithmic_bytes_per_launch": avg_gn_bytes,
+                         "launches": gn_n},
+            "whole_scan": {"algorithmic_bytes_per_scan": b_scan / max(n_timed, 1),
+                           "achieved_GBps": (b_scan * world / dt) / 1e9 if world == 1 else None,
+                           "gn_share_of_wall": (gn_ms / 1e3) / (dt * S) if S == 1 else None,
+                           "mean_gn_iterations": float(np.mean(iters))},
+            "accuracy": {"ate_vs_gt_ref_style_rot": ate_r, "ate_vs_gt_ref_style_trans_m2": ate_t,
+                         "rmse_vs_gt_m": rmse_gt},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, kiss_cpu, res_cpu = cpu_baseline(sq, n_total, use_imu, args.cpu_budget)
+            m = len(res_cpu)
+            line["cpu_baseline"] = cb
+            d = np.linalg.norm(o["res_poses"][:m, :3, 3] - res_cpu[:, :3, 3], axis=1)
+            line["parity_vs_oracle"] = {"scans": m, "max_dpos_m": float(d.max()), "rmse_dpos_m": float(np.sqrt(np.mean(d ** 2)))}
+            line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
+        else:
+            line["cpu_baseline"] = None
+        if gathered is not None:
+            line["gathered_trajectories"] = list(gathered.shape)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,7 @@ const char *ptl_last_error(void);
 /* 1 when a HIP device is usable (the only backend); never falls back to a CPU path */
 int ptl_backend(void);
 int ptl_device_count(void);
+int ptl_device_sync(int device_id); /* hipDeviceSynchronize on that device */
 
 /* ------------------------------------------------------------------------------------------------
  * ICP handle == reference KissICPWrapper (src/ptudes/kiss.py:18-166) + the kiss_icp.KissICP it owns
@@ -170,6 +171,12 @@ int ptl_seq_upload_scan(ptl_seq *s, int64_t k, const float *xyz);
 int ptl_seq_upload_imu(ptl_seq *s, const double *imu, const int64_t *imu_end);
 /* cold-start the filters/map and run scans [0, n) (n <= n_scans); returns after the stream has drained */
 int ptl_seq_run(ptl_seq *s, int64_t n);
+/* continue with the next n scans from where the last run / advance stopped (state kept) */
+int ptl_seq_advance(ptl_seq *s, int64_t n);
+/* the same split in two: enqueue the next n scans on the handle's stream without waiting, then wait + check
+ * device error flags (lets several sequences on one GPU overlap on their own streams) */
+int ptl_seq_enqueue(ptl_seq *s, int64_t n);
+int ptl_seq_wait(ptl_seq *s);
 /* res_poses (n x 16), res_t (n), kiss_poses (n x 16), stats (n): any may be NULL; n_out = scans processed
  * (scans with no IMU since the previous one are skipped when with_ekf, ekf_bench.py:512-518) */
 int ptl_seq_results(ptl_seq *s, double *res_poses, double *res_t, double *kiss_poses, ptl_icp_stats *stats,
@@ -177,6 +184,8 @@ int ptl_seq_results(ptl_seq *s, double *res_poses, double *res_t, double *kiss_p
 /* device pointer + row count of the (T x 8) NC-GT rows [t, x,y,z, qx,qy,qz,qw] of the last run, for the
  * RCCL trajectory gather (no host copy) */
 int ptl_seq_traj_device(ptl_seq *s, void **dev_ptr, int64_t *rows);
+/* device-to-device copy of those rows into a caller-owned DEVICE buffer (e.g. a torch tensor's data_ptr) */
+int ptl_seq_copy_traj(ptl_seq *s, void *dst_device, int64_t max_rows, int64_t *rows);
 int ptl_seq_icp(ptl_seq *s, ptl_icp **icp);
 int ptl_seq_profile(ptl_seq *s, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
 

@@ -184,6 +184,10 @@ class Ekf:
         return t.value
 
 
+def device_sync(device_id=0):
+    L.check(L.lib().ptl_device_sync(device_id))
+
+
 class SeqRunner:
     """Whole sequence in HBM, no host round trip per scan."""
 
@@ -222,6 +226,20 @@ class SeqRunner:
 
     def run(self, n=None):
         L.check(L.lib().ptl_seq_run(self._h, self.n_scans if n is None else n))
+
+    def advance(self, n):
+        L.check(L.lib().ptl_seq_advance(self._h, n))
+
+    def enqueue(self, n):
+        L.check(L.lib().ptl_seq_enqueue(self._h, n))
+
+    def wait(self):
+        L.check(L.lib().ptl_seq_wait(self._h))
+
+    def copy_traj(self, dst_device_ptr, max_rows):
+        rows = C.c_int64()
+        L.check(L.lib().ptl_seq_copy_traj(self._h, C.c_void_p(dst_device_ptr), max_rows, C.byref(rows)))
+        return rows.value
 
     def results(self):
         n = self.n_scans

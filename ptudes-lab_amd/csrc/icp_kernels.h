@@ -365,18 +365,53 @@ __device__ __forceinline__ bool nn_search32(const Ctx& c, V3 s, int lane32, int 
     double bd = 1.7976931348623157e308;
     unsigned border = 0xFFFFFFFFu;
     V3 bp = v3(0, 0, 0);
-    while (m) {
-        const int v = __ffs(m) - 1;
-        m &= m - 1;
-        const int b = __shfl(blk, gbase + v);
-        const int cnt = blk_hdr(c, b)[0];
-        if (lane32 == 0) ncand += cnt;
-        const double* X = blk_x(c, b);
-        for (int j = lane32; j < cnt; j += 32) {
-            const double qx = X[j], qy = X[c.P + j], qz = X[2 * c.P + j];
-            const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 < bd) { bd = d2; border = (unsigned)(v * 1024 + j); bp = v3(qx, qy, qz); }
+    if (c.P <= 32) {
+        // Four voxel blocks per round: all of a round's loads (count + x/y/z of slot `lane`) are issued
+        // before any is consumed, so a round costs one memory round trip instead of two per block.
+        const bool lane_has_slot = lane32 < c.P;
+        while (m) {
+            int vv[4], bb[4], cc[4];
+            double qx[4], qy[4], qz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (m) { vv[u] = __ffs(m) - 1; m &= m - 1; bb[u] = __shfl(blk, gbase + vv[u]); }
+                else { vv[u] = 0; bb[u] = -1; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cc[u] = 0; qx[u] = 0.0; qy[u] = 0.0; qz[u] = 0.0;
+                if (bb[u] >= 0) {
+                    cc[u] = blk_hdr(c, bb[u])[0];
+                    if (lane_has_slot) {
+                        const double* X = blk_x(c, bb[u]);
+                        qx[u] = X[lane32]; qy[u] = X[c.P + lane32]; qz[u] = X[2 * c.P + lane32];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (lane32 == 0) ncand += cc[u];
+                if (lane32 < cc[u]) {
+                    const double dx = qx[u] - s.x, dy = qy[u] - s.y, dz = qz[u] - s.z;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < bd) { bd = d2; border = (unsigned)(vv[u] * 1024 + lane32); bp = v3(qx[u], qy[u], qz[u]); }
+                }
+            }
+        }
+    } else {
+        while (m) {
+            const int v = __ffs(m) - 1;
+            m &= m - 1;
+            const int b = __shfl(blk, gbase + v);
+            const int cnt = blk_hdr(c, b)[0];
+            if (lane32 == 0) ncand += cnt;
+            const double* X = blk_x(c, b);
+            for (int j = lane32; j < cnt; j += 32) {
+                const double qx = X[j], qy = X[c.P + j], qz = X[2 * c.P + j];
+                const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 < bd) { bd = d2; border = (unsigned)(v * 1024 + j); bp = v3(qx, qy, qz); }
+            }
         }
     }
     // lexicographic (d2, candidate order) minimum over the 32 lanes of the group
@@ -489,9 +524,19 @@ __global__ __launch_bounds__(256) void k_gn_loop(Ctx c, int mode) {
             const int col = tid & 31, part8 = tid >> 5;
             double s = 0.0;
             if (col < 29) {
-                const double* base = c.partials + (size_t)(it & 1) * G * 32;
-                for (int w = part8; w < G; w += 8)
-                    s += __hip_atomic_load(&base[(size_t)w * 32 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double* base = c.partials + (size_t)(it & 1) * G * 32 + col;
+                int w = part8;
+                // eight independent L1-bypassing loads in flight per round, summed in a fixed order
+                for (; w + 56 < G; w += 64) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = __hip_atomic_load(&base[(size_t)(w + 8 * u) * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                for (; w < G; w += 8)
+                    s += __hip_atomic_load(&base[(size_t)w * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             red[part8][col] = s;
         }

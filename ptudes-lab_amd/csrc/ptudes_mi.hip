@@ -84,15 +84,15 @@ static hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * size
 
 static int icp_free(ptl_icp* h) {
     if (!h) return PTL_OK;
-    hipSetDevice(h->cfg.device_id);
+    (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
     void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, c.fd, c.src0,
                     c.src_cur, c.fdw, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.partials,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter};
     for (void* p : ptrs)
-        if (p) hipFree(p);
-    for (hipEvent_t e : h->ev) hipEventDestroy(e);
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PTL_OK;
 }
@@ -508,7 +508,7 @@ static int ekf_create_impl(const ptl_ekf_cfg* cfg, hipStream_t shared, ptl_ekf**
 extern "C" int ptl_ekf_create(const ptl_ekf_cfg* cfg, ptl_ekf** out) { return ekf_create_impl(cfg, nullptr, out); }
 extern "C" int ptl_ekf_destroy(ptl_ekf* h) {
     if (!h) return PTL_OK;
-    hipSetDevice(h->cfg.device_id);
+    (void)hipSetDevice(h->cfg.device_id);
     hipFree(h->st); hipFree(h->d_buf);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
@@ -583,11 +583,12 @@ struct ptl_seq {
     double* d_rows;      // [n_scans][8]
     std::vector<int64_t> scan_of_out;  // scan index of each processed output
     int64_t n_out;
+    int64_t next_scan, imu_pos, imus_per_scan;  // driver-loop position (ekf_bench.py:491-518)
 };
 
 extern "C" int ptl_seq_destroy(ptl_seq* s) {
     if (!s) return PTL_OK;
-    hipSetDevice(s->cfg.icp.device_id);
+    (void)hipSetDevice(s->cfg.icp.device_id);
     if (s->icp) icp_free(s->icp);
     if (s->ekf) ptl_ekf_destroy(s->ekf);
     if (s->d_scans) hipFree(s->d_scans);
@@ -644,44 +645,84 @@ extern "C" int ptl_seq_upload_imu(ptl_seq* s, const double* imu, const int64_t* 
     }
     return PTL_OK;
 }
-// The reference's driver loop (cli/ekf_bench.py:493-563) enqueued for scans [0, n): IMU samples up to the
-// scan -> EKF predict; scan -> guess (EKF nav pose when use_imu_prediction) -> ICP -> EKF update.
-extern "C" int ptl_seq_run(ptl_seq* s, int64_t n) {
-    if (!s || n < 0 || n > s->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
-    HIPCHK(hipSetDevice(s->cfg.icp.device_id));
+static int seq_reset(ptl_seq* s) {
     int rc = icp_reset_device(s->icp);
     if (rc) return rc;
     rc = ekf_reset(s->ekf);
     if (rc) return rc;
     s->scan_of_out.clear();
     s->n_out = 0;
+    s->next_scan = 0;
+    s->imu_pos = 0;
+    s->imus_per_scan = 1;  // ekf_bench.py:491
+    return PTL_OK;
+}
+// The reference's driver loop (cli/ekf_bench.py:493-563) enqueued for the next n scans: IMU samples up to
+// the scan -> EKF predict; scan -> guess (EKF nav pose when use_imu_prediction) -> ICP -> EKF update.
+// Nothing here waits for the device.
+extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
+    if (!s || n < 0 || s->next_scan + n > s->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(s->cfg.icp.device_id));
     const bool with_ekf = s->cfg.with_ekf != 0;
     const double* guess_ptr = (with_ekf && s->cfg.use_imu_prediction) ? (const double*)((char*)s->ekf->st + offsetof(EkfState, pose)) : nullptr;
-    int64_t imu_pos = 0;
-    int64_t imus_per_scan = 1;  // ekf_bench.py:491
     const size_t pps = (size_t)s->cfg.points_per_scan;
-    for (int64_t k = 0; k < n; ++k) {
-        const int64_t e = with_ekf ? s->imu_end[(size_t)k] : imu_pos;
-        if (e > imu_pos) {
-            k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, s->d_imu, (int)imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr);
-            imus_per_scan += e - imu_pos;
-            imu_pos = e;
+    const int64_t end = s->next_scan + n;
+    for (int64_t k = s->next_scan; k < end; ++k) {
+        const int64_t e = with_ekf ? s->imu_end[(size_t)k] : s->imu_pos;
+        if (e > s->imu_pos) {
+            k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr);
+            s->imus_per_scan += e - s->imu_pos;
+            s->imu_pos = e;
         }
-        if (with_ekf && !imus_per_scan) continue;  // ekf_bench.py:512-518
-        imus_per_scan = 0;
-        rc = icp_enqueue_scan(s->icp, s->d_scans + (size_t)k * pps * 3, nullptr, nullptr, (int64_t)pps, guess_ptr);
+        s->next_scan = k + 1;
+        if (with_ekf && !s->imus_per_scan) continue;  // ekf_bench.py:512-518
+        s->imus_per_scan = 0;
+        int rc = icp_enqueue_scan(s->icp, s->d_scans + (size_t)k * pps * 3, nullptr, nullptr, (int64_t)pps, guess_ptr);
         if (rc) return rc;
         const int64_t o = s->n_out;
-        if (with_ekf) {
-            const double* kiss_pose = s->icp->c.traj + 16 * (s->icp->scans_done - 1);
+        const double* kiss_pose = s->icp->c.traj + 16 * (s->icp->scans_done - 1);
+        if (with_ekf)
             k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, nullptr, 0, 0, kiss_pose, nullptr, s->d_res_poses + 16 * o,
                                                 s->d_res_t + o, s->d_rows + 8 * o);
-        }
         s->scan_of_out.push_back(k);
         s->n_out++;
     }
     HIPCHK(hipGetLastError());
+    return PTL_OK;
+}
+extern "C" int ptl_seq_wait(ptl_seq* s) {
+    if (!s) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(s->cfg.icp.device_id));
     return icp_check_flags(s->icp);
+}
+extern "C" int ptl_seq_run(ptl_seq* s, int64_t n) {
+    if (!s || n < 0 || n > s->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(s->cfg.icp.device_id));
+    int rc = seq_reset(s);
+    if (rc) return rc;
+    rc = ptl_seq_enqueue(s, n);
+    if (rc) return rc;
+    return ptl_seq_wait(s);
+}
+extern "C" int ptl_seq_advance(ptl_seq* s, int64_t n) {
+    int rc = ptl_seq_enqueue(s, n);
+    if (rc) return rc;
+    return ptl_seq_wait(s);
+}
+extern "C" int ptl_seq_copy_traj(ptl_seq* s, void* dst_device, int64_t max_rows, int64_t* rows) {
+    if (!s || !dst_device) return set_err(PTL_ERR_ARG, "null argument");
+    if (!s->cfg.with_ekf) return set_err(PTL_ERR_STATE, "trajectory rows need with_ekf");
+    HIPCHK(hipSetDevice(s->cfg.icp.device_id));
+    const int64_t n = s->n_out < max_rows ? s->n_out : max_rows;
+    if (n > 0) HIPCHK(hipMemcpyAsync(dst_device, s->d_rows, (size_t)n * 64, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (rows) *rows = n;
+    return PTL_OK;
+}
+extern "C" int ptl_device_sync(int device_id) {
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipDeviceSynchronize());
+    return PTL_OK;
 }
 extern "C" int ptl_seq_results(ptl_seq* s, double* res_poses, double* res_t, double* kiss_poses, ptl_icp_stats* stats,
                                int64_t max_n, int64_t* n_out) {
