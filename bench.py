@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--const-velocity", action="store_true",
                     help="use the constant-velocity guess instead of --use-imu-prediction (reference default)")
     ap.add_argument("--gn-wgs", type=int, default=0, help="workgroups of the persistent GN kernel (0 = library default)")
+    ap.add_argument("--gn-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -113,7 +114,8 @@ def main():
         n_imu = sq.imu_range_for_scan(n_total - 1)[1]
         r = core.SeqRunner(n_total, pps, n_imu, max_range=args.max_range, min_range=args.min_range,
                            use_imu_prediction=use_imu, with_ekf=True, device_id=local_rank, scan_cols=args.cols,
-                           **({"gn_workgroups": args.gn_wgs} if args.gn_wgs else {}))
+                           **({"gn_workgroups": args.gn_wgs} if args.gn_wgs else {}),
+                           **({"gn_threads": args.gn_threads} if args.gn_threads else {}))
         for k in range(n_total):
             r.upload_scan(k, sq.scan(k))
         r.upload_imu(sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n_total)])

@@ -66,6 +66,7 @@ typedef struct {
     int64_t map_table_capacity;   /* hash slots (power of two) */
     int32_t gn_workgroups;        /* workgroups of the persistent Gauss-Newton kernel */
     int32_t rebuild_every;        /* rebuild the map hash table every this many scans (drops tombstones) */
+    int32_t gn_threads;           /* threads per workgroup of that kernel (multiple of 64, 256..1024) */
 } ptl_icp_cfg;
 
 /* per-scan counters; identical meaning to oracle/oracle.h orc_icp_stats (SURVEY.md 8(d) byte model) */
@@ -122,6 +123,9 @@ int ptl_icp_align(ptl_icp *h, const double *frame, int64_t n, const double guess
 
 /* profiling: HIP-event time of the dominant kernel (the persistent Gauss-Newton loop) since last reset */
 int ptl_icp_profile(ptl_icp *h, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
+/* diagnostic: accumulated clock ticks of workgroup 0 per phase of that kernel (nn, wg-reduce+publish, barrier,
+ * grid-reduce, solve) and out[5] = iterations, since the handle was created / reset */
+int ptl_icp_gn_phases(ptl_icp *h, int64_t out[8]);
 
 /* ------------------------------------------------------------------------------------------------
  * EKF handle == reference ESEKF (src/ptudes/ins/es_ekf.py:57-365)

@@ -22,7 +22,8 @@ class IcpCfg(C.Structure):
                 ("min_motion_th", C.c_double), ("deskew", C.c_int32), ("max_iterations", C.c_int32),
                 ("convergence", C.c_double), ("device_id", C.c_int32), ("scan_cols", C.c_int32),
                 ("max_points_per_scan", C.c_int64), ("map_block_capacity", C.c_int64),
-                ("map_table_capacity", C.c_int64), ("gn_workgroups", C.c_int32), ("rebuild_every", C.c_int32)]
+                ("map_table_capacity", C.c_int64), ("gn_workgroups", C.c_int32), ("rebuild_every", C.c_int32),
+                ("gn_threads", C.c_int32)]
 
 
 class IcpStats(C.Structure):
@@ -69,6 +70,7 @@ PROTOTYPES = {
     "ptl_icp_align": (C.c_int, [_vp, c_d_p, C.c_int64, c_d_p, C.c_double, C.c_double, c_d_p,
                                 C.POINTER(C.c_int32)]),
     "ptl_icp_profile": (C.c_int, [_vp, C.c_int, c_d_p, c_i64_p, C.c_int]),
+    "ptl_icp_gn_phases": (C.c_int, [_vp, c_i64_p]),
     "ptl_ekf_default_cfg": (C.c_int, [C.POINTER(EkfCfg)]),
     "ptl_ekf_create": (C.c_int, [C.POINTER(EkfCfg), _vpp]),
     "ptl_ekf_destroy": (C.c_int, [_vp]),

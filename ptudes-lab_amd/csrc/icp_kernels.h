@@ -7,7 +7,7 @@
 //   K3 k_compact_fd    ordered compaction -> frame_downsample
 //   K4 k_compact_src   ordered compaction -> source
 //   K5 k_gn_loop       persistent Gauss-Newton loop: 27-voxel NN + robust 6x6 system + solve (kiss.py:108-114)
-//   K6 k_post_icp      new pose, innovation log, threshold model deviation      (kiss.py:116-130)
+//      (tail of K5)    new pose, innovation log, threshold model deviation      (kiss.py:116-130)
 //   K7-9 k_map_*       VoxelHashMap::AddPoints, order-preserving, cap per voxel (kiss.py:129)
 //   K10 k_map_prune    RemovePointsFarFromLocation
 //   K11 k_map_rebuild  hash-table rebuild (drops tombstones)
@@ -50,13 +50,16 @@ struct ScanStats {  // mirrors ptl_icp_stats
 struct DevState {
     // per-scan counters
     int n_in, n_valid, n_down, n_src;
-    // GN loop
-    unsigned bar;
+    // GN loop: grid barrier words, each on its own 128-byte line
+    unsigned bar_grp[8 * 32];
+    unsigned bar_gen[8 * 32];
+    unsigned bar_top;
     int gn_iters, gn_ncorr, gn_pad;
     long long gn_cand;
     double gn_max_dist, gn_kernel;
     double T_icp[16];
     double dbg_sums[32];
+    long long gn_phase_clk[8];  // accumulated s_memtime ticks of WG0: nn, wg-reduce, barrier, grid-reduce, solve
     // pose history (kiss_icp.KissICP.poses: only first / last two are ever read)
     int n_poses, has_ext_guess;
     double pose_first[16], pose_prev[16], pose_last[16];
@@ -67,7 +70,9 @@ struct DevState {
     double sigma, sse;
     long long n_samples;
     double model_dev[16];
+    int prev_n_in, pending_finish;
     // map
+    int pool_hw, pad2;
     int free_top, n_live;
     long long map_points;
     unsigned tab_used;
@@ -91,6 +96,7 @@ struct Ctx {
     unsigned vmask;
     int *bcnt1, *bcnt2;
     double *fd, *src0, *src_cur, *fdw;
+    double* coltab;  // [W][12] per-column deskew transforms (R row-major 9, t 3)
     int *pslot, *nxt, *prank, *plen;
     // map
     TabEnt* tab;
@@ -149,12 +155,32 @@ __device__ __forceinline__ int vds_claim(unsigned long long* keys, unsigned mask
 // ------------------------------------------------------------------------------------------------ K0
 // One thread.  kiss_icp.KissICP: deskew twist from its own last two poses, get_adaptive_threshold()
 // (Threshold.cpp ComputeThreshold, stateful), initial guess (reference kiss.py:102-105 or the caller's).
-__global__ void k_scan_prologue(Ctx c) {
+// bookkeeping that closes a scan (KissICP.poses.append, kiss.py:130); runs at the start of the next
+// scan's prologue or from k_finish_scan when the host wants to read state
+__device__ __forceinline__ void finish_pending(const Ctx& c, DevState* st) {
+    if (!st->pending_finish) return;
+    st->pending_finish = 0;
+    const int k = st->n_poses;
+    if (k < c.traj_cap) { c.sstats[k].map_voxels = st->n_live; c.sstats[k].map_points = st->map_points; }
+    if (k == 0) for (int i = 0; i < 16; ++i) st->pose_first[i] = st->new_pose[i];
+    for (int i = 0; i < 16; ++i) { st->pose_prev[i] = st->pose_last[i]; st->pose_last[i] = st->new_pose[i]; }
+    st->n_poses = k + 1;
+}
+__global__ void k_finish_scan(Ctx c) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    finish_pending(c, c.st);
+}
+
+__global__ __launch_bounds__(1024) void k_scan_prologue(Ctx c) {
     DevState* st = c.st;
+    if (threadIdx.x == 0) {
+    finish_pending(c, st);
+    st->prev_n_in = st->n_in;
     st->n_in = c.n_in;
     st->n_valid = 0; st->n_down = 0; st->n_src = 0;
-    st->bar = 0; st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0;
+    for (int g = 0; g < 8; ++g) { st->bar_grp[g * 32] = 0; st->bar_gen[g * 32] = 0; }
+    st->bar_top = 0;
+    st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0;
     // deskew: xi = Log(P[-2]^-1 P[-1])  (Deskew.cpp)
     st->do_deskew = (c.deskew && st->n_poses >= 2) ? 1 : 0;
     Rt last = rt_from16(st->pose_last), prev = rt_from16(st->pose_prev);
@@ -192,6 +218,23 @@ __global__ void k_scan_prologue(Ctx c) {
         g = rt_mul(lp, pred);
     }
     rt_to16(g, st->guess);
+    __threadfence_block();
+    }
+    __syncthreads();
+    // per-column deskew transforms Exp((j/W - 0.5) xi): only W distinct times exist in a sweep (kiss.py:34-35)
+    if (st->do_deskew && c.t01 == nullptr) {
+        double xi[6];
+        for (int k = 0; k < 6; ++k) xi[k] = st->xi[k];
+        for (int j = threadIdx.x; j < c.W; j += blockDim.x) {
+            const double sft = (double)j * (1.0 / (double)c.W) - 0.5;
+            double x[6];
+            for (int k = 0; k < 6; ++k) x[k] = sft * xi[k];
+            const Rt M = se3_exp(x);
+            double* o = c.coltab + 12 * (size_t)j;
+            for (int k = 0; k < 9; ++k) o[k] = M.R[k];
+            for (int k = 0; k < 3; ++k) o[9 + k] = M.t[k];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K1
@@ -199,16 +242,28 @@ __global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     DevState* st = c.st;
     bool valid = false;
+    if (i < st->prev_n_in) {  // release the previous scan's pass-2 slot this point won (K4 still read them)
+        const int s2 = c.slot2[i];
+        if (s2 >= 0 && c.vmin2[s2] == (unsigned)i) { c.vkey2[s2] = EMPTY_KEY; c.vmin2[s2] = 0xFFFFFFFFu; }
+    }
+    if (i >= c.n_in && i < st->prev_n_in) c.slot2[i] = -1;
     if (i < c.n_in) {
         V3 p;
         if (c.in_f32) p = v3((double)c.in_f32[3 * (size_t)i], (double)c.in_f32[3 * (size_t)i + 1], (double)c.in_f32[3 * (size_t)i + 2]);
         else p = v3(c.in_f64[3 * (size_t)i], c.in_f64[3 * (size_t)i + 1], c.in_f64[3 * (size_t)i + 2]);
         if (st->do_deskew) {
-            const double t = c.t01 ? c.t01[i] : (double)(i % c.W) * (1.0 / (double)c.W);
-            const double s = t - 0.5;
-            double x[6];
-            for (int k = 0; k < 6; ++k) x[k] = s * st->xi[k];
-            p = rt_apply(se3_exp(x), p);
+            if (c.t01) {
+                const double s = c.t01[i] - 0.5;
+                double x[6];
+                for (int k = 0; k < 6; ++k) x[k] = s * st->xi[k];
+                p = rt_apply(se3_exp(x), p);
+            } else {
+                const double* m = c.coltab + 12 * (size_t)(i % c.W);
+                Rt M;
+                for (int k = 0; k < 9; ++k) M.R[k] = m[k];
+                for (int k = 0; k < 3; ++k) M.t[k] = m[9 + k];
+                p = rt_apply(M, p);
+            }
         }
         const double r = sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
         valid = (r < c.max_range) && (r > c.min_range);
@@ -326,16 +381,6 @@ __global__ __launch_bounds__(256) void k_compact_src(Ctx c) {
     }
     if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) c.st->n_src = off + total;
 }
-// releases the pass-2 slots (separate launch: K4 still reads vmin2 of slots other points own)
-__global__ __launch_bounds__(256) void k_vds2_release(Ctx c) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < c.n_in) {
-        const int s1 = c.slot1[i];
-        const int s2 = (s1 >= 0) ? c.slot2[i] : -1;
-        if (s2 >= 0 && c.vmin2[s2] == (unsigned)i) { c.vkey2[s2] = EMPTY_KEY; c.vmin2[s2] = 0xFFFFFFFFu; }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ K5
 // map probe: block id of voxel `key` or -1
 __device__ __forceinline__ int map_find(const Ctx& c, unsigned long long key) {
@@ -426,43 +471,127 @@ __device__ __forceinline__ bool nn_search32(const Ctx& c, V3 s, int lane32, int 
     return border != 0xFFFFFFFFu;
 }
 
-// Persistent Gauss-Newton loop (Registration.cpp RegisterFrame).  G workgroups x 256 threads, all resident;
-// one device-scope counter barrier per iteration; every workgroup sums all partials in the same fixed
-// order and solves the 6x6 system redundantly, so all agree bit-for-bit on dx and on convergence.
-// mode 0: source = guess * src0, loop to convergence.  mode 1: src_cur given in world frame, one pass,
-// sums exported to st->dbg_sums (teacher-forced test entry).
-__global__ __launch_bounds__(256) void k_gn_loop(Ctx c, int mode) {
-    __shared__ double red[8][32];
+// column `idx` of the 3x7 matrix [ I | -hat(s) | r ]: the Jacobian J = [I | -hat(s)] of Registration.cpp
+// BuildLinearSystem plus the residual, so that JTJ(a,b) = w col(a).col(b) and JTr(a) = w col(a).col(6)
+__device__ __forceinline__ V3 jcol(int idx, V3 s, V3 r) {
+    switch (idx) {
+        case 0: return v3(1.0, 0.0, 0.0);
+        case 1: return v3(0.0, 1.0, 0.0);
+        case 2: return v3(0.0, 0.0, 1.0);
+        case 3: return v3(0.0, -s.z, s.y);
+        case 4: return v3(s.z, 0.0, -s.x);
+        case 5: return v3(-s.y, s.x, 0.0);
+        default: return r;
+    }
+}
+
+// Two-level arrival / one-word-per-group release grid barrier on monotonic counters (zeroed by K0).
+// Groups are wg & 7 (what the dispatcher places on one XCD today; correctness does not depend on it).
+// Every payload word is exchanged with agent-scope 8-byte atomics, so no fences are needed.
+__device__ __forceinline__ void grid_barrier(DevState* st, int G, int wg, int it) {
+    const int grp = wg & 7;
+    const int ngroups = G < 8 ? G : 8;
+    const unsigned ng = (unsigned)((G - grp + 7) / 8);
+    const unsigned gen = (unsigned)(it + 1);
+    const unsigned a = __hip_atomic_fetch_add(&st->bar_grp[grp * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a + 1u == ng * gen) {
+        const unsigned t = __hip_atomic_fetch_add(&st->bar_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1u == (unsigned)ngroups * gen)
+            for (int g = 0; g < ngroups; ++g)
+                __hip_atomic_store(&st->bar_gen[g * 32], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned spins = 0;
+    while (__hip_atomic_load(&st->bar_gen[grp * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 25)) { atomicOr(&st->err_flags, ERR_GN_TIMEOUT); break; }
+    }
+}
+
+// kiss.py:116-130 after the ICP: new pose, innovation (err_dt / err_drot), threshold model deviation, stats
+// row.  full != 0 => a real scan (trajectory + stats row, closes with finish_pending); 0 => ptl_icp_align.
+__device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_empty, int full) {
+    Rt guess = rt_from16(st->guess);
+    Rt np = map_empty ? guess : rt_mul(rt_from16(st->T_icp), guess);
+    rt_to16(np, st->new_pose);
+    if (!full) return;
+    Rt gain = rt_mul(rt_inv(guess), np);  // kiss.py:116, :128
+    rt_to16(gain, st->model_dev);
+    const int k = st->n_poses;
+    if (k < c.traj_cap) {
+        for (int i = 0; i < 16; ++i) c.traj[(size_t)k * 16 + i] = st->new_pose[i];
+        ScanStats s;
+        s.sigma = st->sigma;
+        s.err_dt = sqrt(gain.t[0] * gain.t[0] + gain.t[1] * gain.t[1] + gain.t[2] * gain.t[2]);
+        s.err_drot = rot_angle(gain.R);
+        s.iterations = st->gn_iters; s.n_corr_last = st->gn_ncorr;
+        s.n_in = st->n_in; s.n_valid = st->n_valid; s.n_down = st->n_down; s.n_src = st->n_src;
+        s.sum_cand = st->gn_cand; s.map_voxels = 0; s.map_points = 0;  // filled by finish_pending
+        c.sstats[k] = s;
+    }
+    st->pending_finish = 1;
+}
+
+// Persistent Gauss-Newton loop (Registration.cpp RegisterFrame).  G workgroups, all resident; one grid
+// barrier per iteration; every workgroup sums all partials in the same fixed order and solves the 6x6
+// system redundantly, so all agree bit-for-bit on dx and on convergence.  Within a 32-lane group lane k
+// accumulates entry k of the 27 sums (21 JTJ upper triangle + 6 JTr); lane 27 counts pairs.
+// mode 0: a scan: source = guess * src0, loop to convergence, then the post-ICP bookkeeping.
+// mode 1: src_cur given in world frame, one pass, sums exported to st->dbg_sums (teacher-forced entry).
+// mode 2: like 0 without touching the trajectory (ptl_icp_align).
+#ifndef GN_MAX_THREADS
+#define GN_MAX_THREADS 512
+#endif
+#define GN_MAX_GROUPS (GN_MAX_THREADS / 32)
+__global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
+    __shared__ double red[GN_MAX_GROUPS][32];
     __shared__ double tot[32];
     __shared__ double Esh[12];
+    __shared__ double Tsh[12];
     __shared__ int flag_done;
     DevState* st = c.st;
     const int tid = threadIdx.x, lane32 = tid & 31, grp = tid >> 5, gbase = (tid & 63) & 32;
+    const int NG = blockDim.x >> 5;
     const int G = gridDim.x, wg = blockIdx.x;
     const int n = st->n_src;
-    if (st->n_live == 0 && mode == 0) {  // voxel_map.Empty() => return initial_guess
+    if (st->n_live == 0 && mode != 1) {  // voxel_map.Empty() => return initial_guess
         if (wg == 0 && tid == 0) {
             Rt I = rt_identity();
             rt_to16(I, st->T_icp);
             st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0;
+            gn_post(c, st, true, mode == 0);
         }
         return;
     }
     const double max_dist = st->gn_max_dist, kern = st->gn_kernel, k2 = kern * kern;
     const int max_iter = (mode == 1) ? 1 : c.max_iter;
-    Rt E = (mode == 0) ? rt_from16(st->guess) : rt_identity();
-    Rt Ticp = rt_identity();
+    // which of the 27 sums this lane owns
+    int ia = 0, ib = 0;
+    {
+        int o = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) { if (o == lane32) { ia = a; ib = b; } ++o; }
+        if (lane32 >= 21) { ia = lane32 - 21; ib = 6; }
+    }
+    if (tid < 12) {
+        Rt g = (mode != 1) ? rt_from16(st->guess) : rt_identity();
+        Esh[tid] = (tid < 9) ? g.R[tid] : g.t[tid - 9];
+        Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
+    }
+    __syncthreads();
     long long cand_total = 0;
     int iters = 0, ncorr_last = 0;
+    long long ph[5] = {0, 0, 0, 0, 0};
     for (int it = 0; it < max_iter; ++it) {
-        double acc[27];
-        for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+        const long long c0 = __builtin_readcyclecounter();
+        double acc = 0.0;
         long long ncand = 0;
-        int ncorr = 0;
-        for (int i = wg * 8 + grp; i < n; i += G * 8) {
+        Rt E;
+        for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
+        for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
+        for (int i = wg * NG + grp; i < n; i += G * NG) {
             // lazily apply the previous iteration's increment (TransformPoints(estimation, source))
             V3 s;
-            if (it == 0 && mode == 0) s = rt_apply(E, v3(c.src0[3 * (size_t)i], c.src0[3 * (size_t)i + 1], c.src0[3 * (size_t)i + 2]));
+            if (it == 0 && mode != 1) s = rt_apply(E, v3(c.src0[3 * (size_t)i], c.src0[3 * (size_t)i + 1], c.src0[3 * (size_t)i + 2]));
             else if (it == 0) s = v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]);
             else s = rt_apply(E, v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]));
             if (lane32 == 0 && !(it == 0 && mode == 1)) {
@@ -471,56 +600,33 @@ __global__ __launch_bounds__(256) void k_gn_loop(Ctx c, int mode) {
             V3 t;
             double d2;
             const bool found = nn_search32(c, s, lane32, gbase, t, d2, ncand);
-            if (lane32 == 0 && found && sqrt(d2) < max_dist) {
-                ++ncorr;
-                const double rx = s.x - t.x, ry = s.y - t.y, rz = s.z - t.z;
-                const double den = kern + (rx * rx + ry * ry + rz * rz);
+            if (found && sqrt(d2) < max_dist) {  // uniform over the group
+                const V3 r = v3(s.x - t.x, s.y - t.y, s.z - t.z);
+                const double den = kern + (r.x * r.x + r.y * r.y + r.z * r.z);
                 const double w = k2 / (den * den);
-                // J = [I | -hat(s)] ; A = -hat(s) = [[0, sz, -sy], [-sz, 0, sx], [sy, -sx, 0]]
-                const double A[9] = {0.0, s.z, -s.y, -s.z, 0.0, s.x, s.y, -s.x, 0.0};
-                const double r[3] = {rx, ry, rz};
-                // JTJ upper triangle, row-major: rows 0..2 (translation) then 3..5 (rotation)
-                acc[0] += w; acc[6] += w; acc[11] += w;                       // (0,0) (1,1) (2,2)
-                acc[3] += w * A[0]; acc[4] += w * A[1]; acc[5] += w * A[2];   // (0,3..5)
-                acc[8] += w * A[3]; acc[9] += w * A[4]; acc[10] += w * A[5];  // (1,3..5)
-                acc[12] += w * A[6]; acc[13] += w * A[7]; acc[14] += w * A[8];  // (2,3..5)
-                int o = 15;
-                for (int a = 0; a < 3; ++a)
-                    for (int b = a; b < 3; ++b) {
-                        acc[o++] += w * (A[a] * A[b] + A[3 + a] * A[3 + b] + A[6 + a] * A[6 + b]);  // (3+a,3+b)
-                    }
-                acc[21] += w * r[0]; acc[22] += w * r[1]; acc[23] += w * r[2];
-                for (int a = 0; a < 3; ++a) acc[24 + a] += w * (A[a] * r[0] + A[3 + a] * r[1] + A[6 + a] * r[2]);
+                if (lane32 < 27) acc += w * dot(jcol(ia, s, r), jcol(ib, s, r));
+                else if (lane32 == 27) acc += 1.0;
             }
         }
-        // workgroup reduction in fixed order
-        if (lane32 == 0) {
-            for (int k = 0; k < 27; ++k) red[grp][k] = acc[k];
-            red[grp][27] = (double)ncorr;
-            red[grp][28] = (double)ncand;
-        }
+        const long long c1 = __builtin_readcyclecounter();
+        // workgroup reduction in fixed order (column 28 carries the candidate count)
+        const long long ncand0 = __shfl(ncand, gbase);  // all lanes execute the shuffle
+        red[grp][lane32] = (lane32 == 28) ? (double)ncand0 : acc;
         __syncthreads();
         double* part = c.partials + ((size_t)(it & 1) * G + wg) * 32;
         if (tid < 29) {
             double s = 0.0;
-            for (int g = 0; g < 8; ++g) s += red[g][tid];
+            for (int g = 0; g < NG; ++g) s += red[g][tid];
             __hip_atomic_store(&part[tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // grid barrier: monotonic counter (zeroed by K0), relaxed polling
-        if (tid == 0) {
-            __hip_atomic_fetch_add(&st->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = (unsigned)G * (unsigned)(it + 1);
-            unsigned spins = 0;
-            while (__hip_atomic_load(&st->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 26)) { atomicOr(&st->err_flags, ERR_GN_TIMEOUT); break; }
-            }
-        }
+        const long long c2 = __builtin_readcyclecounter();
+        if (tid == 0) grid_barrier(st, G, wg, it);
         __syncthreads();
+        const long long c3 = __builtin_readcyclecounter();
         // every workgroup: total = sum over workgroups, fixed order (8 strided partial sums, then 8 -> 1)
-        {
+        if (tid < 256) {
             const int col = tid & 31, part8 = tid >> 5;
             double s = 0.0;
             if (col < 29) {
@@ -547,20 +653,24 @@ __global__ __launch_bounds__(256) void k_gn_loop(Ctx c, int mode) {
             tot[tid] = s;
         }
         __syncthreads();
+        const long long c4 = __builtin_readcyclecounter();
         if (tid == 0) {
             double dx[6];
             solve6_ldlt(tot, dx);
             Rt e = se3_exp(dx);
-            for (int k = 0; k < 9; ++k) Esh[k] = e.R[k];
-            for (int k = 0; k < 3; ++k) Esh[9 + k] = e.t[k];
+            Rt T;
+            for (int k = 0; k < 9; ++k) T.R[k] = Tsh[k];
+            for (int k = 0; k < 3; ++k) T.t[k] = Tsh[9 + k];
+            T = rt_mul(e, T);
+            for (int k = 0; k < 9; ++k) { Esh[k] = e.R[k]; Tsh[k] = T.R[k]; }
+            for (int k = 0; k < 3; ++k) { Esh[9 + k] = e.t[k]; Tsh[9 + k] = T.t[k]; }
             double nn = 0.0;
             for (int k = 0; k < 6; ++k) nn += dx[k] * dx[k];
             flag_done = (sqrt(nn) < c.conv) ? 1 : 0;
         }
         __syncthreads();
-        for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
-        for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
-        Ticp = rt_mul(E, Ticp);
+        const long long c5 = __builtin_readcyclecounter();
+        ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
         cand_total += (long long)tot[28];
         ncorr_last = (int)tot[27];
         iters = it + 1;
@@ -570,43 +680,17 @@ __global__ __launch_bounds__(256) void k_gn_loop(Ctx c, int mode) {
         if (done) break;
     }
     if (wg == 0 && tid == 0) {
-        rt_to16(Ticp, st->T_icp);
+        Rt T;
+        for (int k = 0; k < 9; ++k) T.R[k] = Tsh[k];
+        for (int k = 0; k < 3; ++k) T.t[k] = Tsh[9 + k];
+        rt_to16(T, st->T_icp);
         st->gn_iters = iters;
         st->gn_ncorr = ncorr_last;
         st->gn_cand = cand_total;
+        for (int k = 0; k < 5; ++k) st->gn_phase_clk[k] += ph[k];
+        st->gn_phase_clk[5] += iters;
+        if (mode != 1) gn_post(c, st, false, mode == 0);
     }
-}
-
-// ------------------------------------------------------------------------------------------------ K6
-__global__ void k_post_icp(Ctx c) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    DevState* st = c.st;
-    Rt guess = rt_from16(st->guess);
-    Rt np = (st->n_live == 0) ? guess : rt_mul(rt_from16(st->T_icp), guess);
-    rt_to16(np, st->new_pose);
-    Rt gain = rt_mul(rt_inv(guess), np);  // kiss.py:116, :128
-    rt_to16(gain, st->model_dev);
-    const int k = st->n_poses;
-    if (k < c.traj_cap) {
-        for (int i = 0; i < 16; ++i) c.traj[(size_t)k * 16 + i] = st->new_pose[i];
-        ScanStats s;
-        s.sigma = st->sigma;
-        s.err_dt = sqrt(gain.t[0] * gain.t[0] + gain.t[1] * gain.t[1] + gain.t[2] * gain.t[2]);
-        s.err_drot = rot_angle(gain.R);
-        s.iterations = st->gn_iters; s.n_corr_last = st->gn_ncorr;
-        s.n_in = st->n_in; s.n_valid = st->n_valid; s.n_down = st->n_down; s.n_src = st->n_src;
-        s.sum_cand = st->gn_cand; s.map_voxels = 0; s.map_points = 0;  // filled by k_finish_scan
-        c.sstats[k] = s;
-    }
-}
-__global__ void k_finish_scan(Ctx c) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    DevState* st = c.st;
-    const int k = st->n_poses;
-    if (k < c.traj_cap) { c.sstats[k].map_voxels = st->n_live; c.sstats[k].map_points = st->map_points; }
-    if (k == 0) for (int i = 0; i < 16; ++i) st->pose_first[i] = st->new_pose[i];
-    for (int i = 0; i < 16; ++i) { st->pose_prev[i] = st->pose_last[i]; st->pose_last[i] = st->new_pose[i]; }
-    st->n_poses = k + 1;
 }
 
 // ------------------------------------------------------------------------------------------------ K7-K9
@@ -642,6 +726,7 @@ __global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_i
                         h[0] = 0;
                         h[1] = slot;
                         atomicAdd(&st->n_live, 1);
+                        atomicMax(&st->pool_hw, b + 1);
                     } else {
                         atomicOr(&st->err_flags, ERR_POOL);
                     }
@@ -701,8 +786,8 @@ __global__ __launch_bounds__(256) void k_map_insert_c(Ctx c, const int* n_ptr, i
 // RemovePointsFarFromLocation: a voxel goes when its FIRST point is farther than max_range from the origin
 __global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_xyz, int use_new_pose) {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= c.pool_cap) return;
     DevState* st = c.st;
+    if (b >= st->pool_hw) return;  // block ids are handed out low-first: nothing lives above the high-water mark
     int* h = blk_hdr(c, b);
     const int cnt = h[0];
     if (cnt <= 0) return;
@@ -726,7 +811,7 @@ __global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_x
 // after the table has been reset to EMPTY: re-enter every live voxel
 __global__ __launch_bounds__(256) void k_map_rebuild(Ctx c) {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= c.pool_cap) return;
+    if (b >= c.st->pool_hw) return;
     int* h = blk_hdr(c, b);
     if (h[0] <= 0) return;
     const double* X = blk_x(c, b);
@@ -744,7 +829,7 @@ __global__ __launch_bounds__(256) void k_map_rebuild(Ctx c) {
 // export of the map points (KissICPWrapper.local_map_points)
 __global__ __launch_bounds__(256) void k_map_export(Ctx c, double* out, int* counter, int max_points) {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= c.pool_cap) return;
+    if (b >= c.st->pool_hw) return;
     const int cnt = blk_hdr(c, b)[0];
     if (cnt <= 0) return;
     const int o = atomicAdd(counter, cnt);

@@ -49,6 +49,7 @@ struct ptl_icp {
     int* d_counter;
     int64_t traj_cap;
     int64_t scans_done;
+    int64_t last_n;      // points of the previous scan (its pass-2 VDS slots are released by the next K1)
     // profiling of the dominant kernel
     bool prof;
     std::vector<hipEvent_t> ev;
@@ -76,6 +77,7 @@ extern "C" int ptl_icp_default_cfg(ptl_icp_cfg* cfg, double max_range, double mi
     cfg->map_table_capacity = 1 << 21;
     cfg->gn_workgroups = 256;
     cfg->rebuild_every = 16;
+    cfg->gn_threads = 1024;
     return PTL_OK;
 }
 
@@ -87,7 +89,7 @@ static int icp_free(ptl_icp* h) {
     (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
     void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, c.fd, c.src0,
-                    c.src_cur, c.fdw, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.partials,
+                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.partials,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -123,6 +125,7 @@ static int icp_reset_device(ptl_icp* h) {
     k_state_init<<<1, 64, 0, h->stream>>>(c.st, c.pool_cap);
     HIPCHK(hipGetLastError());
     h->scans_done = 0;
+    h->last_n = 0;
     return PTL_OK;
 }
 
@@ -131,6 +134,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     if (cfg->max_points_per_voxel < 1 || cfg->max_points_per_voxel > 1000) return set_err(PTL_ERR_ARG, "max_points_per_voxel out of range");
     if (cfg->map_table_capacity & (cfg->map_table_capacity - 1)) return set_err(PTL_ERR_ARG, "map_table_capacity must be a power of two");
     if (cfg->max_points_per_scan < 1 || cfg->gn_workgroups < 1) return set_err(PTL_ERR_ARG, "bad capacity");
+    if (cfg->gn_threads < 256 || cfg->gn_threads > GN_MAX_THREADS || (cfg->gn_threads & 63)) return set_err(PTL_ERR_ARG, "gn_threads must be a multiple of 64 in [256, GN_MAX_THREADS]");
     if (ptl_device_count() <= cfg->device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->device_id);
     HIPCHK(hipSetDevice(cfg->device_id));
     ptl_icp* h = new ptl_icp();
@@ -172,6 +176,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= dalloc(&c.bcnt1, h->nblk_scan) == hipSuccess && dalloc(&c.bcnt2, h->nblk_scan) == hipSuccess;
     ok &= dalloc(&c.fd, 3 * n) == hipSuccess && dalloc(&c.src0, 3 * n) == hipSuccess;
     ok &= dalloc(&c.src_cur, 3 * n) == hipSuccess && dalloc(&c.fdw, 3 * n) == hipSuccess;
+    ok &= dalloc(&c.coltab, (size_t)c.W * 12) == hipSuccess;
     ok &= dalloc(&c.pslot, n) == hipSuccess && dalloc(&c.nxt, n) == hipSuccess;
     ok &= dalloc(&c.prank, n) == hipSuccess && dalloc(&c.plen, n) == hipSuccess;
     ok &= dalloc(&c.tab, (size_t)cfg->map_table_capacity) == hipSuccess;
@@ -233,12 +238,12 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     c.in_f32 = in_f32; c.in_f64 = in_f64; c.t01 = t01; c.n_in = (int)n; c.ext_guess = ext_guess;
     const int nb = (int)((n + 255) / 256) > 0 ? (int)((n + 255) / 256) : 1;
     hipStream_t s = h->stream;
-    k_scan_prologue<<<1, 64, 0, s>>>(c);
-    k_deskew_vds1<<<nb, 256, 0, s>>>(c);
+    const int nb1 = (int)(((n > h->last_n ? n : h->last_n) + 255) / 256) > 0 ? (int)(((n > h->last_n ? n : h->last_n) + 255) / 256) : 1;
+    k_scan_prologue<<<1, 1024, 0, s>>>(c);
+    k_deskew_vds1<<<nb1, 256, 0, s>>>(c);
     k_vds2<<<nb, 256, 0, s>>>(c);
     k_compact_fd<<<nb, 256, 0, s>>>(c);
     k_compact_src<<<nb, 256, 0, s>>>(c);
-    k_vds2_release<<<nb, 256, 0, s>>>(c);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         if (h->ev_used + 2 > h->ev.size()) {
@@ -247,15 +252,14 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
         e0 = h->ev[h->ev_used++]; e1 = h->ev[h->ev_used++];
         HIPCHK(hipEventRecord(e0, s));
     }
-    k_gn_loop<<<c.G, 256, 0, s>>>(c, 0);
+    k_gn_loop<<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0);  // ends with the post-ICP bookkeeping (kiss.py:116-128)
     if (h->prof) HIPCHK(hipEventRecord(e1, s));
-    k_post_icp<<<1, 64, 0, s>>>(c);
     // local_map.update(frame_downsample, new_pose)  (kiss.py:129)
     k_map_insert_a<<<nb, 256, 0, s>>>(c, c.fd, &c.st->n_down, 0, 1);
     k_map_insert_b<<<nb, 256, 0, s>>>(c, &c.st->n_down, 0);
     k_map_insert_c<<<nb, 256, 0, s>>>(c, &c.st->n_down, 0);
     k_map_prune<<<(c.pool_cap + 255) / 256, 256, 0, s>>>(c, nullptr, 1);
-    k_finish_scan<<<1, 64, 0, s>>>(c);
+    h->last_n = n;
     h->scans_done++;
     if (h->cfg.rebuild_every > 0 && (h->scans_done % h->cfg.rebuild_every) == 0) { int rc = map_rebuild(h); if (rc) return rc; }
     HIPCHK(hipGetLastError());
@@ -272,6 +276,7 @@ static void icp_collect_profile(ptl_icp* h) {
 
 static int icp_check_flags(ptl_icp* h) {
     int flags = 0;
+    k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);  // closes the last scan's bookkeeping (no-op when none is pending)
     HIPCHK(hipMemcpyAsync(&flags, &h->c.st->err_flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->prof) icp_collect_profile(h);
@@ -302,6 +307,7 @@ extern "C" int ptl_icp_register_frame(ptl_icp* h, const void* xyz, int dtype, in
                               dtype == PTL_F64 ? (const double*)h->d_in : nullptr, t01 ? h->d_t01 : nullptr, n,
                               guess ? h->d_ext : nullptr);
     if (rc) return rc;
+    k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);  // close the scan before its stats row is read back
     const int64_t k = h->scans_done - 1;
     double pose[16];
     ScanStats ss;
@@ -407,7 +413,9 @@ extern "C" int ptl_icp_map_add(ptl_icp* h, const double* xyz_world, int64_t n, c
 
 __global__ void k_set_gn(DevState* st, int n_src, double max_dist, double kernel, const double* guess) {
     if (threadIdx.x || blockIdx.x) return;
-    st->n_src = n_src; st->gn_max_dist = max_dist; st->gn_kernel = kernel; st->bar = 0;
+    st->n_src = n_src; st->gn_max_dist = max_dist; st->gn_kernel = kernel;
+    for (int g = 0; g < 8; ++g) { st->bar_grp[g * 32] = 0; st->bar_gen[g * 32] = 0; }
+    st->bar_top = 0;
     if (guess) for (int i = 0; i < 16; ++i) st->guess[i] = guess[i];
 }
 extern "C" int ptl_icp_linear_system(ptl_icp* h, const double* src_world, int64_t n, double max_dist, double kernel,
@@ -418,7 +426,7 @@ extern "C" int ptl_icp_linear_system(ptl_icp* h, const double* src_world, int64_
     Ctx& c = h->c;
     HIPCHK(hipMemcpyAsync(c.src_cur, src_world, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     k_set_gn<<<1, 64, 0, h->stream>>>(c.st, (int)n, max_dist, kernel, nullptr);
-    k_gn_loop<<<c.G, 256, 0, h->stream>>>(c, 1);
+    k_gn_loop<<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1);
     double out[32];
     HIPCHK(hipMemcpyAsync(out, (char*)c.st + offsetof(DevState, dbg_sums), sizeof out, hipMemcpyDeviceToHost, h->stream));
     int rc = icp_check_flags(h);
@@ -437,14 +445,23 @@ extern "C" int ptl_icp_align(ptl_icp* h, const double* frame, int64_t n, const d
     HIPCHK(hipMemcpyAsync(c.src0, frame, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_ext, guess, 128, hipMemcpyHostToDevice, h->stream));
     k_set_gn<<<1, 64, 0, h->stream>>>(c.st, (int)n, max_dist, kernel, h->d_ext);
-    k_gn_loop<<<c.G, 256, 0, h->stream>>>(c, 0);
-    k_post_icp<<<1, 64, 0, h->stream>>>(c);  // new_pose = T_icp * guess (does not append to the trajectory index)
+    k_gn_loop<<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 2);  // new_pose = T_icp * guess, trajectory untouched
     DevState st;
     HIPCHK(hipMemcpyAsync(&st, c.st, sizeof st, hipMemcpyDeviceToHost, h->stream));
     int rc = icp_check_flags(h);
     if (rc) return rc;
     memcpy(out_pose, st.new_pose, 128);
     if (iterations) *iterations = st.gn_iters;
+    return PTL_OK;
+}
+
+// diagnostic: accumulated per-phase clock ticks of workgroup 0 in the GN loop since the handle was reset
+// out[0..4] = nn, wg-reduce+publish, barrier, grid-reduce, solve; out[5] = iterations
+extern "C" int ptl_icp_gn_phases(ptl_icp* h, int64_t out[8]) {
+    if (!h || !out) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(out, (char*)h->c.st + offsetof(DevState, gn_phase_clk), 64, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return PTL_OK;
 }
 

@@ -1,0 +1,15 @@
+import sys, ctypes as C, numpy as np
+sys.path.insert(0,'/root/repo')
+import ptudes_lab_amd
+from ptudes_lab_amd import core, synth, _lib as L
+n=60
+seq = synth.make_sequence(seed=1000, n_scans=n)
+kw = dict(gn_workgroups=int(sys.argv[1]), gn_threads=int(sys.argv[2])) if len(sys.argv)>2 else {}
+r = core.SeqRunner(n, seq.H*seq.W, seq.imu_range_for_scan(n-1)[1], max_range=70., min_range=1., use_imu_prediction=True, with_ekf=True, **kw)
+for k in range(n): r.upload_scan(k, seq.scan(k))
+r.upload_imu(seq.imu[:seq.imu_range_for_scan(n-1)[1]], [seq.imu_range_for_scan(k)[1] for k in range(n)])
+r.run()
+icp = C.c_void_p(); L.check(L.lib().ptl_seq_icp(r._h, C.byref(icp)))
+out = (C.c_int64*8)(); L.check(L.lib().ptl_icp_gn_phases(icp, out))
+o = np.array(list(out), dtype=float); it=o[5]
+print("iters", it, "ticks/iter: nn %.0f wgred %.0f barrier %.0f gridred %.0f solve %.0f" % tuple(o[:5]/it), "total/iter", o[:5].sum()/it)
