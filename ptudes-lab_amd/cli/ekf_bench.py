@@ -1,0 +1,218 @@
+"""`ekf-bench` commands: drop-in for the pose path of reference src/ptudes/cli/ekf_bench.py.
+
+  sim     EKF with simulated IMU (reference :107-179) - the filter's known-answer harness
+  ouster  IMU + scans -> KissICP poses -> EKF smoothing, KITTI / NC-GT pose files out (reference :381-666)
+  cmp     compare trajectories in Newer College format (reference :686-760)
+
+Same option names, printed lines and output files.  Differences, all because ouster-sdk / rosbags are not
+installable offline: `ouster` reads .pcap/.bag only when ouster-sdk is importable and otherwise (or with
+--synthetic SEED) runs on a synthetic 128x1024 sequence; plotting options (-p) are not provided (the
+OpenGL / matplotlib viewers are outside the path).  `nc` (bag IMU + GT updates) needs rosbags and is not provided.
+"""
+import os
+from datetime import datetime
+from itertools import count
+from types import SimpleNamespace
+from typing import List, Optional
+
+import click
+import numpy as np
+import numpy.random as npr
+
+from ..ins.data import GRAV, IMU, calc_ate, ekf_traj_ate
+from ..ins.es_ekf import ESEKF
+from ..utils import (filter_nc_gt_by_close_ts, filter_nc_gt_by_cmp, read_newer_college_gt,
+                     save_poses_kitti_format, save_poses_nc_gt_format)
+
+DOWN = np.array([0, 0, -1])
+
+
+@click.group(name="ekf-bench")
+def ptudes_ekf_bench() -> None:
+    """ES EKF benchmarks and experiments (MI355X-native pose path)."""
+
+
+def sim_imu(acc_mean=np.zeros(3), acc_std=1.5, acc_noise_std=0.4, acc_bias=np.array([0.9, -0.2, -0.4]),
+            gyr_mean=np.zeros(3), gyr_std=1.0, gyr_noise_std=0.2, gyr_bias=np.array([0.01, 0.03, -0.012]),
+            gravity=GRAV * DOWN, freq=100):
+    """(ideal, noisy) IMU pairs; the commanded acc/gyr are redrawn every 10 samples.  Draws from the legacy
+    global numpy RNG in the reference's order, so `np.random.seed(s)` reproduces its streams (reference :44-79)."""
+    dt = 1 / freq
+
+    def draw():
+        a = npr.normal(0.0, acc_std, 3) + acc_mean - gravity
+        g = npr.normal(0.0, gyr_std, 3) + gyr_mean
+        return a, g
+
+    acc, gyr = draw()
+    for idx in count():
+        if idx % 10 == 0:
+            acc, gyr = draw()
+        acc_noise = npr.normal(0, acc_noise_std, 3)
+        gyr_noise = npr.normal(0.0, gyr_noise_std, 3)
+        yield (IMU(acc, gyr, idx * dt), IMU(acc + acc_noise + acc_bias, gyr + gyr_noise + gyr_bias, idx * dt))
+
+
+@click.command(name="sim")
+@click.option("-t", "--duration", type=float, default=2.0, help="Time to generate IMUs measurements (seconds, default 2.0)")
+@click.option("-f", "--freq", type=float, default=100.0, help="IMU frequency")
+@click.option("--corr-t", type=float, default=0.1, help="Pose correction time interval to EKF (seconds, default 0.1)")
+@click.option("--acc-noise-std", type=float, default=0.4, help="IMU accelerometer noise sigma")
+@click.option("--gyr-noise-std", type=float, default=0.4, help="IMU gyroscope noise sigma")
+def ptudes_ekf_sim(duration: float, corr_t: float, freq: float, acc_noise_std: float, gyr_noise_std: float) -> None:
+    """EKF with simulated IMU measurements; the noise-free filter is the ground truth for pose corrections."""
+    print("Using sim IMUs with params:")
+    print(f"  freq: {freq} Hz")
+    print(f"  acc_noise_std: {acc_noise_std}")
+    print(f"  gyr_noise_std: {gyr_noise_std}")
+    print(f"  correction dt: {corr_t:.02} s")
+    print("Running EKF ... \n")
+    ekf_gt, ekf = ESEKF(_logging=True), ESEKF(_logging=True)
+    start_ts = last_corr_t = ts = None
+    for imu_ideal, imu_noisy in sim_imu(freq=freq, acc_noise_std=acc_noise_std, gyr_noise_std=gyr_noise_std):
+        ts = imu_ideal.ts
+        if start_ts is None:
+            start_ts = last_corr_t = ts
+        ekf_gt.processImu(imu_ideal)
+        ekf.processImu(imu_noisy)
+        if ts - last_corr_t > corr_t:
+            ekf.processPose(ekf_gt.nav.pose_mat())
+            last_corr_t = ts
+        if ts - start_ts > duration:
+            break
+    print("Results:")
+    print(f"processed duration: {ts - start_ts:0.04} s")
+    print(f"updates num: {len(ekf._nav_update_idxs)}\n")
+    print("NAV GT:\n", ekf_gt.nav)
+    print("NAV:\n", ekf.nav)
+    ate_rot, ate_trans = ekf_traj_ate(ekf_gt, ekf)
+    print(f"ATE_rot:   {ate_rot:.04f} deg")
+    print(f"ATE trans: {ate_trans:.04f} m")
+
+
+def _synthetic_source(seed: int, n_scans: int):
+    from .. import synth
+    from ..sequence import synthetic_events
+    seq = synth.make_sequence(seed=seed, n_scans=n_scans)
+    meta = SimpleNamespace(format=SimpleNamespace(columns_per_frame=seq.W, pixels_per_column=seq.H),
+                           prod_line="SYNTH-OS-0-128", mode=f"{seq.W}x10")
+    return seq, meta, synthetic_events(seq)
+
+
+@click.command(name="ouster")
+@click.argument("file", required=False, type=click.Path())
+@click.option("-m", "--meta", required=False, type=click.Path(exists=True, dir_okay=False, readable=True),
+              help="Metadata for PCAP/BAG, required if automatic metadata resolution fails")
+@click.option("--start-scan", type=int, default=0, help="Start scan number")
+@click.option("--end-scan", type=int, help="End scan number, inclusive")
+@click.option("--use-imu-prediction", is_flag=True,
+              help="Use EKF IMU pose prediction for KissICP register frame, i.e. lously coupled Lidar Inertial Odometry")
+@click.option("-g", "--gt-file", required=False, type=click.Path(exists=True, dir_okay=False, readable=True),
+              help="Ground truth file with poses to compare (Newer College format)")
+@click.option("--kiss-min-range", type=float, default=1, help="KissICP min range param in m (default 1)")
+@click.option("--kiss-max-range", type=float, default=70, help="KissICP max range param in m (default 70)")
+@click.option("--beams", type=int, default=0, help="Active beams number in a lidar scan")
+@click.option("--save-kitti-poses", required=False, type=click.Path(exists=False, dir_okay=False),
+              help="Save resulting poses to the file (in kitti format)")
+@click.option("--save-nc-gt-poses", required=False, type=click.Path(exists=False, dir_okay=False),
+              help="Save resulting poses to the file (in NC ground truth format)")
+@click.option("--synthetic", type=int, default=None,
+              help="Run on the synthetic 128x1024 sequence with this seed instead of FILE (no ouster-sdk needed)")
+def ptudes_ekf_ouster(file: Optional[str], meta: Optional[str], start_scan: int, end_scan: Optional[int],
+                      use_imu_prediction: bool, gt_file: Optional[str], beams: int, save_kitti_poses: Optional[str],
+                      save_nc_gt_poses: Optional[str], kiss_min_range: float, kiss_max_range: float,
+                      synthetic: Optional[int]) -> None:
+    """EKF with Ouster IMUs and scan KissICP poses updates (smoothing of the KissICP trajectory)."""
+    from ..sequence import run_events
+    from ..utils import active_beam_rows
+    if synthetic is None:
+        try:
+            import ouster.client  # noqa: F401
+        except Exception:
+            raise click.ClickException("reading .pcap/.bag needs ouster-sdk, which is not installed; "
+                                       "use --synthetic SEED to run the same path on a synthetic sequence")
+        raise click.ClickException("packet-file ingestion is not part of this build (SURVEY.md 8(f) rank 3)")
+    n_scans = (end_scan + 1) if end_scan is not None else 100
+    seq, info, events = _synthetic_source(synthetic, n_scans)
+    file = f"synthetic:{synthetic}"
+    display_header = f"data path: {file}\n"
+    display_header += f"metadata path: {meta}\n\n"
+    display_header += f"scans range: {start_scan} - {end_scan}\n"
+    display_header += f"kiss min/max: {kiss_min_range} - {kiss_max_range}\n"
+    display_header += f"use-imu-prediction: {use_imu_prediction}, use-gt-guess: False\n"
+    display_header += f"beams: {beams or info.format.pixels_per_column}\n"
+    display_header += f"sensor: {info.prod_line}, {info.mode}\n"
+    print(display_header)
+
+    def feed():
+        scan_idx = 0
+        for ev in events:
+            if ev[0] == "scan":
+                if scan_idx >= start_scan:
+                    xyz = ev[1]
+                    if beams:
+                        img = xyz.reshape(seq.H, seq.W, 3)
+                        drop = np.ones(seq.H, dtype=bool)
+                        drop[active_beam_rows(seq.H, beams)] = False
+                        img[drop] = 0
+                    yield ev
+                scan_idx += 1
+            elif scan_idx >= start_scan:  # IMUs before start_scan are dropped (reference data.py:76)
+                yield ev
+
+    out = run_events(feed(), info, kiss_min_range=kiss_min_range, kiss_max_range=kiss_max_range,
+                     use_imu_prediction=use_imu_prediction)
+    res_t, res_poses, kiss_poses = out["res_t"], out["res_poses"], out["kiss_poses"]
+    header = display_header + f"(scans/updates num: {len(res_poses)})\n"
+    header += "time: " + datetime.now().strftime("%Y%m%d_%H%M%S")
+    if save_kitti_poses:
+        save_poses_kitti_format(save_kitti_poses, res_poses, header=header)
+        print(f"Kitti poses saved to: {save_kitti_poses}")
+    if save_nc_gt_poses:
+        save_poses_nc_gt_format(save_nc_gt_poses, t=res_t, poses=res_poses, header=header)
+        print(f"NC GT poses saved to: {save_nc_gt_poses}")
+    tm = out["timings"]
+    if res_poses:
+        print("\nTimings:")
+        print(f"  ESEKF imu process:      {tm['imu']:.05f} s per step")
+        print(f"  ESEKF update:           {tm['corr']:.05f} s per update")
+        print(f"  KissICP register frame: {tm['kiss']:.05f} s per frame")
+    gts = read_newer_college_gt(gt_file) if gt_file else []
+    if gts and res_poses:
+        gts, res_t_matched = filter_nc_gt_by_close_ts(gts, res_t)
+        idx, kiss_m, res_m = 0, [], []
+        for t_m in res_t_matched:
+            while res_t[idx] != t_m:
+                idx += 1
+            kiss_m.append(kiss_poses[idx])
+            res_m.append(res_poses[idx])
+            idx += 1
+        if gts:
+            pose0 = res_m[0] @ np.linalg.inv(gts[0][1])
+            gt2 = [pose0 @ g[1] for g in gts]
+            for label, poses in ((f"with ES EKF smoothing {len(gt2)} poses", res_m),
+                                 (f"no-EKF, only KissICP {len(gt2)} poses", kiss_m)):
+                ate_rot, ate_trans = calc_ate(poses, gt2)
+                print(f"\nGround truth comparison ({label}):")
+                print(f"ATE_rot:   {ate_rot:.04f} deg")
+                print(f"ATE trans: {ate_trans:.04f} m")
+
+
+@click.command(name="cmp")
+@click.argument("gt_file", required=True, type=click.Path(exists=True))
+@click.argument("gt_file_cmp", required=False, type=click.Path(exists=True), nargs=-1)
+def ptudes_ekf_cmp(gt_file: str, gt_file_cmp: List[str]) -> None:
+    """Compare trajectories in Newer College Dataset Formats"""
+    gts_all = read_newer_college_gt(gt_file)
+    for cmp_file in gt_file_cmp:
+        gts, gts_cmp = filter_nc_gt_by_cmp(gts_all, read_newer_college_gt(cmp_file))
+        ate_rot, ate_trans = calc_ate([p for _, p in gts], [p for _, p in gts_cmp])
+        name = os.path.splitext(os.path.basename(cmp_file))[0]
+        print(f"\nTraj poses comparisons GT v. {name} ({len(gts)} poses):")
+        print(f"ATE_rot:   {ate_rot:.04f} deg")
+        print(f"ATE trans: {ate_trans:.04f} m")
+
+
+ptudes_ekf_bench.add_command(ptudes_ekf_sim)
+ptudes_ekf_bench.add_command(ptudes_ekf_ouster)
+ptudes_ekf_bench.add_command(ptudes_ekf_cmp)

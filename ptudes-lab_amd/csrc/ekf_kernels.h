@@ -19,22 +19,25 @@
 #define EKF_BA 12
 #define EKF_G 15
 
-struct EkfState {
+struct EkfNav {
     double pos[3], q[4], vel[3], bg[3], ba[3], grav[3];
+    double cur_lacc[3], cur_avel[3], cur_ts, cur_dt;
+    int initialized, n_updates;
+};
+struct EkfState {
+    EkfNav nav;
     double P[EKF_N * EKF_N];
     double Fx[EKF_N * EKF_N];  // persistent: identity + rewritten blocks (es_ekf.py:142, :216-223)
     double W[EKF_N * EKF_N];   // persistent: zero + rewritten diagonal blocks (es_ekf.py:145, :226-233)
-    double cur_lacc[3], cur_avel[3], cur_ts, cur_dt;
-    int initialized, n_updates;
     double pose[16];  // NavState.pose_mat() after the last step (ins/data.py:70-74)
 };
 
 __device__ __forceinline__ void ekf_write_pose(EkfState* e) {
     double R[9];
-    quat_to_R(e->q, R);
+    quat_to_R(e->nav.q, R);
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) e->pose[4 * i + j] = R[3 * i + j];
-        e->pose[4 * i + 3] = e->pos[i];
+        e->pose[4 * i + 3] = e->nav.pos[i];
     }
     e->pose[12] = e->pose[13] = e->pose[14] = 0.0;
     e->pose[15] = 1.0;
@@ -43,8 +46,8 @@ __device__ __forceinline__ void ekf_write_pose(EkfState* e) {
 // ESEKF.__init__ (es_ekf.py:73-179)
 __global__ void k_ekf_init(EkfState* e, const double* grav, const double* bacc, const double* bgyr) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int i = 0; i < 3; ++i) { e->pos[i] = 0.0; e->vel[i] = 0.0; e->grav[i] = grav[i]; e->ba[i] = bacc[i]; e->bg[i] = bgyr[i]; }
-    e->q[0] = e->q[1] = e->q[2] = 0.0; e->q[3] = 1.0;
+    for (int i = 0; i < 3; ++i) { e->nav.pos[i] = 0.0; e->nav.vel[i] = 0.0; e->nav.grav[i] = grav[i]; e->nav.ba[i] = bacc[i]; e->nav.bg[i] = bgyr[i]; }
+    e->nav.q[0] = e->nav.q[1] = e->nav.q[2] = 0.0; e->nav.q[3] = 1.0;
     for (int i = 0; i < EKF_N * EKF_N; ++i) { e->P[i] = 0.0; e->Fx[i] = 0.0; e->W[i] = 0.0; }
     for (int i = 0; i < EKF_N; ++i) e->Fx[i * EKF_N + i] = 1.0;
     // initial attitude std = rotation vector of intrinsic-XYZ euler (10, 10, 10) deg (es_ekf.py:104-107)
@@ -62,8 +65,8 @@ __global__ void k_ekf_init(EkfState* e, const double* grav, const double* bacc, 
         e->P[(EKF_BA + i) * EKF_N + EKF_BA + i] = 0.25;
         e->P[(EKF_G + i) * EKF_N + EKF_G + i] = 6.25;
     }
-    e->cur_ts = 0.0; e->cur_dt = 0.0; e->initialized = 0; e->n_updates = 0;
-    for (int i = 0; i < 3; ++i) { e->cur_lacc[i] = 0.0; e->cur_avel[i] = 0.0; }
+    e->nav.cur_ts = 0.0; e->nav.cur_dt = 0.0; e->nav.initialized = 0; e->nav.n_updates = 0;
+    for (int i = 0; i < 3; ++i) { e->nav.cur_lacc[i] = 0.0; e->nav.cur_avel[i] = 0.0; }
     ekf_write_pose(e);
 }
 
@@ -76,95 +79,131 @@ __device__ __forceinline__ void set_diag3(double* M, int r, int c, double v) {
         for (int j = 0; j < 3; ++j) M[(r + i) * EKF_N + c + j] = (i == j) ? v : 0.0;
 }
 
-// imu: rows of 7 doubles (ts, lacc[3], avel[3]); samples [i0, i1) are consumed in order.
-// pose (nullable): 4x4 measurement applied after the IMU samples; meas_cov (nullable): 6x6.
-// out_* (nullable): res_poses / res_t / NC-GT row slot written after the update (ekf_bench.py:560-563).
+// One filter step batch.  Order inside a launch: [pose update, if `pose` and update_first] -> IMU samples
+// [i0, i1) in order -> [pose update, if `pose` and !update_first].  The sequence runner uses
+// update_first = 1 so that one launch per scan does "update with scan k's pose, then predict through the
+// IMU samples that precede scan k+1" (reference loop order, cli/ekf_bench.py:493-563).
+// imu: rows of 7 doubles (ts, lacc[3], avel[3]).  pose (nullable): 4x4 measurement; meas_cov (nullable): 6x6.
+// out_* (nullable): res_poses / res_t / NC-GT row written right after the update (ekf_bench.py:560-563).
+// P, Fx and W live in LDS for the whole launch (Fx / W are persistent members in the reference: identity /
+// zero plus the blocks each predict rewrites, es_ekf.py:142-145, :216-233).
+__device__ __forceinline__ void lds_blk3(double* M, int r, int c, const double* B) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[(r + i) * EKF_N + c + j] = B[3 * i + j];
+}
+__device__ __forceinline__ void lds_diag3(double* M, int r, int c, double v) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[(r + i) * EKF_N + c + j] = (i == j) ? v : 0.0;
+}
+
+// columns of Fx row i that can be non-zero: the diagonal plus the blocks es_ekf.py:216-223 writes
+// ((POS,VEL) diag; (VEL,PHI), (VEL,BA), (PHI,PHI) dense 3x3; (PHI,BG) diag)
+__device__ __forceinline__ unsigned ekf_row_mask(int i) {
+    if (i < 3) return (1u << i) | (1u << (EKF_VEL + i));
+    if (i < 6) return (1u << i) | (7u << EKF_PHI) | (7u << EKF_BA);
+    if (i < 9) return (7u << EKF_PHI) | (1u << (EKF_BG + i - EKF_PHI));
+    return 1u << i;
+}
+
 __global__ __launch_bounds__(384) void k_ekf_step(EkfState* e, const double* imu, int i0, int i1, const double* pose,
                                                   const double* meas_cov, double* out_pose, double* out_t,
-                                                  double* out_row8) {
-    __shared__ double sP[EKF_N * EKF_N], sF[EKF_N * EKF_N], sT[EKF_N * EKF_N];
+                                                  double* out_row8, int update_first) {
+    __shared__ double sP[EKF_N * EKF_N], sF[EKF_N * EKF_N], sW[EKF_N * EKF_N], sT[EKF_N * EKF_N];
     __shared__ double sK[EKF_N * 6], sSi[36], sr[6], sdx[EKF_N];
+    __shared__ int active;
     const int tid = threadIdx.x;
     const int ti = tid / EKF_N, tj = tid % EKF_N;
     const bool cell = tid < EKF_N * EKF_N;
-    if (cell) sP[tid] = e->P[tid];
+    if (cell) { sP[tid] = e->P[tid]; sF[tid] = e->Fx[tid]; sW[tid] = e->W[tid]; }
+    // thread 0 keeps the nav state in registers for the whole launch (written back once at the end)
+    EkfNav nv;
+    if (tid == 0) nv = e->nav;
     __syncthreads();
-    for (int s = i0; s < i1; ++s) {
-        // ---- processImu: scalar part on thread 0 (mechanisation + Fx/W blocks)
-        __shared__ int active;
-        if (tid == 0) {
-            const double* row = imu + 7 * (size_t)s;
-            const double ts = row[0];
-            e->cur_dt = ts - e->cur_ts;  // es_ekf.py:196
-            e->cur_ts = ts;
-            for (int k = 0; k < 3; ++k) { e->cur_lacc[k] = row[1 + k]; e->cur_avel[k] = row[4 + k]; }
-            if (!e->initialized) {  // :201-203 the first sample only latches
-                e->initialized = 1;
-                active = 0;
-            } else {
-                active = 1;
-                const double dt = e->cur_dt;
-                double Rp[9], a[3], w[3], dth[3], Rd[9], Rn[9];
-                quat_to_R(e->q, Rp);  // nav_prev.att_h
-                for (int k = 0; k < 3; ++k) { a[k] = e->cur_lacc[k] - e->ba[k]; w[k] = e->cur_avel[k] - e->bg[k]; dth[k] = w[k] * dt; }
-                rotvec_to_R(dth, Rd);
-                // _insMech (:239-257)
-                for (int k = 0; k < 3; ++k) {
-                    const double ag = (Rp[3 * k] * a[0] + Rp[3 * k + 1] * a[1] + Rp[3 * k + 2] * a[2]) + e->grav[k];
-                    e->pos[k] = e->pos[k] + e->vel[k] * dt + 0.5 * ag * dt * dt;
-                    e->vel[k] = e->vel[k] + ag * dt;
+    const int sel[6] = {EKF_POS, EKF_POS + 1, EKF_POS + 2, EKF_PHI, EKF_PHI + 1, EKF_PHI + 2};
+    for (int phase = 0; phase < 3; ++phase) {
+        const bool do_update = pose && ((phase == 0 && update_first) || (phase == 2 && !update_first));
+        if (phase == 1) {
+            for (int s = i0; s < i1; ++s) {
+                // ---- processImu: scalar part on thread 0 (mechanisation + Fx/W blocks)
+                if (tid == 0) {
+                    const double* row = imu + 7 * (size_t)s;
+                    const double ts = row[0];
+                    nv.cur_dt = ts - nv.cur_ts;  // es_ekf.py:196
+                    nv.cur_ts = ts;
+                    for (int k = 0; k < 3; ++k) { nv.cur_lacc[k] = row[1 + k]; nv.cur_avel[k] = row[4 + k]; }
+                    if (!nv.initialized) {  // :201-203 the first sample only latches
+                        nv.initialized = 1;
+                        active = 0;
+                    } else {
+                        active = 1;
+                        const double dt = nv.cur_dt;
+                        double Rp[9], a[3], w[3], dth[3], Rd[9], Rn[9];
+                        quat_to_R(nv.q, Rp);  // nav_prev.att_h
+                        for (int k = 0; k < 3; ++k) { a[k] = row[1 + k] - nv.ba[k]; w[k] = row[4 + k] - nv.bg[k]; dth[k] = w[k] * dt; }
+                        rotvec_to_R(dth, Rd);
+                        // _insMech (:239-257)
+                        for (int k = 0; k < 3; ++k) {
+                            const double ag = (Rp[3 * k] * a[0] + Rp[3 * k + 1] * a[1] + Rp[3 * k + 2] * a[2]) + nv.grav[k];
+                            nv.pos[k] = nv.pos[k] + nv.vel[k] * dt + 0.5 * ag * dt * dt;
+                            nv.vel[k] = nv.vel[k] + ag * dt;
+                        }
+                        mat3_mul(Rp, Rd, Rn);
+                        R_to_quat(Rn, nv.q);
+                        // Fx blocks (:216-223)
+                        double K[9], B[9];
+                        lds_diag3(sF, EKF_POS, EKF_VEL, dt);
+                        skew(a, K);
+                        mat3_mul(Rp, K, B);
+                        for (int k = 0; k < 9; ++k) B[k] = -dt * B[k];
+                        lds_blk3(sF, EKF_VEL, EKF_PHI, B);
+                        for (int k = 0; k < 9; ++k) B[k] = -dt * Rp[k];
+                        lds_blk3(sF, EKF_VEL, EKF_BA, B);
+                        for (int r = 0; r < 3; ++r)
+                            for (int cc = 0; cc < 3; ++cc) B[3 * r + cc] = Rd[3 * cc + r];
+                        lds_blk3(sF, EKF_PHI, EKF_PHI, B);
+                        lds_diag3(sF, EKF_PHI, EKF_BG, -dt);
+                        // W blocks (:226-233); the reference's names do not match their use, this copies the use
+                        lds_diag3(sW, EKF_VEL, EKF_VEL, dt * dt * (0.049 * 0.049));
+                        lds_diag3(sW, EKF_PHI, EKF_PHI, dt * dt * (0.38 * 0.38));
+                        lds_diag3(sW, EKF_BA, EKF_BA, dt * (0.0043 * 0.0043));
+                        lds_diag3(sW, EKF_BG, EKF_BG, dt * (0.000466 * 0.000466));
+                    }
                 }
-                mat3_mul(Rp, Rd, Rn);
-                R_to_quat(Rn, e->q);
-                // Fx blocks (:216-223)
-                double K[9], B[9];
-                set_diag3(e->Fx, EKF_POS, EKF_VEL, dt);
-                skew(a, K);
-                mat3_mul(Rp, K, B);
-                for (int k = 0; k < 9; ++k) B[k] = -dt * B[k];
-                set_blk3(e->Fx, EKF_VEL, EKF_PHI, B);
-                for (int k = 0; k < 9; ++k) B[k] = -dt * Rp[k];
-                set_blk3(e->Fx, EKF_VEL, EKF_BA, B);
-                for (int r = 0; r < 3; ++r)
-                    for (int cc = 0; cc < 3; ++cc) B[3 * r + cc] = Rd[3 * cc + r];
-                set_blk3(e->Fx, EKF_PHI, EKF_PHI, B);
-                set_diag3(e->Fx, EKF_PHI, EKF_BG, -dt);
-                // W blocks (:226-233); the reference's names do not match their use, this copies the use
-                set_diag3(e->W, EKF_VEL, EKF_VEL, dt * dt * (0.049 * 0.049));
-                set_diag3(e->W, EKF_PHI, EKF_PHI, dt * dt * (0.38 * 0.38));
-                set_diag3(e->W, EKF_BA, EKF_BA, dt * (0.0043 * 0.0043));
-                set_diag3(e->W, EKF_BG, EKF_BG, dt * (0.000466 * 0.000466));
-                __threadfence_block();
+                __syncthreads();
+                if (active) {
+                    // ---- P = Fx P Fx^T + W (:235), dense like the reference
+                    // Only the structurally non-zero columns of each Fx row are visited, in ascending order:
+                    // skipping exact-zero products leaves every partial sum bit-identical to the dense loop.
+                    if (cell) {
+                        double acc = 0.0;
+                        for (unsigned m = ekf_row_mask(ti); m; m &= m - 1) {
+                            const int k = __ffs(m) - 1;
+                            acc += sF[ti * EKF_N + k] * sP[k * EKF_N + tj];
+                        }
+                        sT[tid] = acc;
+                    }
+                    __syncthreads();
+                    if (cell) {
+                        double acc = 0.0;
+                        for (unsigned m = ekf_row_mask(tj); m; m &= m - 1) {
+                            const int k = __ffs(m) - 1;
+                            acc += sT[ti * EKF_N + k] * sF[tj * EKF_N + k];
+                        }
+                        sP[tid] = acc + sW[tid];
+                    }
+                }
+                __syncthreads();
             }
+            continue;
         }
-        __syncthreads();
-        if (active) {
-            // ---- P = Fx P Fx^T + W (:235), dense like the reference
-            if (cell) sF[tid] = e->Fx[tid];
-            __syncthreads();
-            if (cell) {
-                double acc = 0.0;
-                for (int k = 0; k < EKF_N; ++k) acc += sF[ti * EKF_N + k] * sP[k * EKF_N + tj];
-                sT[tid] = acc;
-            }
-            __syncthreads();
-            if (cell) {
-                double acc = 0.0;
-                for (int k = 0; k < EKF_N; ++k) acc += sT[ti * EKF_N + k] * sF[tj * EKF_N + k];
-                sP[tid] = acc + e->W[tid];
-            }
-        }
-        __syncthreads();
-    }
-    if (pose) {
+        if (!do_update) continue;
         // ---- processPose (:259-329); the error state is zero on entry (reset at :327)
-        const int sel[6] = {EKF_POS, EKF_POS + 1, EKF_POS + 2, EKF_PHI, EKF_PHI + 1, EKF_PHI + 2};
         if (tid == 0) {
             double Rk[9], RkT[9], Rm[9], D[9], S[36];
-            quat_to_R(e->q, Rk);
+            quat_to_R(nv.q, Rk);
             for (int r = 0; r < 3; ++r)
                 for (int cc = 0; cc < 3; ++cc) { RkT[3 * r + cc] = Rk[3 * cc + r]; Rm[3 * r + cc] = pose[4 * r + cc]; }
-            for (int k = 0; k < 3; ++k) sr[k] = pose[4 * k + 3] - e->pos[k];  // :294
+            for (int k = 0; k < 3; ++k) sr[k] = pose[4 * k + 3] - nv.pos[k];  // :294
             mat3_mul(RkT, Rm, D);
             R_to_rotvec(D, sr + 3);  // :297
             for (int a = 0; a < 6; ++a)
@@ -227,17 +266,17 @@ __global__ __launch_bounds__(384) void k_ekf_step(EkfState* e, const double* imu
             // inject (:314-319)
             double dth[3], R[9], Rd[9], Rn[9];
             for (int k = 0; k < 3; ++k) {
-                e->pos[k] += sdx[EKF_POS + k];
-                e->vel[k] += sdx[EKF_VEL + k];
+                nv.pos[k] += sdx[EKF_POS + k];
+                nv.vel[k] += sdx[EKF_VEL + k];
                 dth[k] = sdx[EKF_PHI + k];
-                e->bg[k] += sdx[EKF_BG + k];
-                e->ba[k] += sdx[EKF_BA + k];
-                e->grav[k] += sdx[EKF_G + k];
+                nv.bg[k] += sdx[EKF_BG + k];
+                nv.ba[k] += sdx[EKF_BA + k];
+                nv.grav[k] += sdx[EKF_G + k];
             }
-            quat_to_R(e->q, R);
+            quat_to_R(nv.q, R);
             rotvec_to_R(dth, Rd);
             mat3_mul(R, Rd, Rn);
-            R_to_quat(Rn, e->q);
+            R_to_quat(Rn, nv.q);
             // covariance projection of the PHI diagonal block only (:322-324): G = I - hat(dth / 2)
             const double h[3] = {0.5 * dth[0], 0.5 * dth[1], 0.5 * dth[2]};
             double Gm[9], GT[9], B[9], C[9];
@@ -250,19 +289,20 @@ __global__ __launch_bounds__(384) void k_ekf_step(EkfState* e, const double* imu
             mat3_mul(C, GT, C);
             for (int r = 0; r < 3; ++r)
                 for (int cc = 0; cc < 3; ++cc) sP[(EKF_PHI + r) * EKF_N + EKF_PHI + cc] = C[3 * r + cc];
-            e->n_updates += 1;
+            nv.n_updates += 1;
+            // outputs of this update (ekf_bench.py:560-563): nav pose and the last IMU's timestamp
+            e->nav = nv;
+            ekf_write_pose(e);
+            if (out_pose) for (int k = 0; k < 16; ++k) out_pose[k] = e->pose[k];
+            if (out_t) *out_t = nv.cur_ts;
+            if (out_row8) {  // [t, x, y, z, qx, qy, qz, qw] for the trajectory gather
+                out_row8[0] = nv.cur_ts;
+                for (int k = 0; k < 3; ++k) out_row8[1 + k] = nv.pos[k];
+                for (int k = 0; k < 4; ++k) out_row8[4 + k] = nv.q[k];
+            }
         }
         __syncthreads();
     }
-    if (cell) e->P[tid] = sP[tid];
-    if (tid == 0) {
-        ekf_write_pose(e);
-        if (out_pose) for (int k = 0; k < 16; ++k) out_pose[k] = e->pose[k];
-        if (out_t) *out_t = e->cur_ts;
-        if (out_row8) {  // [t, x, y, z, qx, qy, qz, qw] for the trajectory gather
-            out_row8[0] = e->cur_ts;
-            for (int k = 0; k < 3; ++k) out_row8[1 + k] = e->pos[k];
-            for (int k = 0; k < 4; ++k) out_row8[4 + k] = e->q[k];
-        }
-    }
+    if (cell) { e->P[tid] = sP[tid]; e->Fx[tid] = sF[tid]; e->W[tid] = sW[tid]; }
+    if (tid == 0) { e->nav = nv; ekf_write_pose(e); }
 }

@@ -537,7 +537,7 @@ extern "C" int ptl_ekf_process_imu_batch(ptl_ekf* h, const double* imu, int64_t 
     for (int64_t off = 0; off < n; off += h->buf_rows) {
         const int m = (int)((n - off) < h->buf_rows ? (n - off) : h->buf_rows);
         HIPCHK(hipMemcpyAsync(h->d_buf, imu + 7 * off, (size_t)m * 56, hipMemcpyHostToDevice, h->stream));
-        k_ekf_step<<<1, 384, 0, h->stream>>>(h->st, h->d_buf, 0, m, nullptr, nullptr, nullptr, nullptr, nullptr);
+        k_ekf_step<<<1, 384, 0, h->stream>>>(h->st, h->d_buf, 0, m, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
         HIPCHK(hipStreamSynchronize(h->stream));  // staging buffer reuse
     }
     HIPCHK(hipGetLastError());
@@ -553,7 +553,7 @@ extern "C" int ptl_ekf_process_pose(ptl_ekf* h, const double pose[16], const dou
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipMemcpyAsync(h->d_buf, pose, 128, hipMemcpyHostToDevice, h->stream));
     if (meas_cov36) HIPCHK(hipMemcpyAsync(h->d_buf + 16, meas_cov36, 288, hipMemcpyHostToDevice, h->stream));
-    k_ekf_step<<<1, 384, 0, h->stream>>>(h->st, nullptr, 0, 0, h->d_buf, meas_cov36 ? h->d_buf + 16 : nullptr, nullptr, nullptr, nullptr);
+    k_ekf_step<<<1, 384, 0, h->stream>>>(h->st, nullptr, 0, 0, h->d_buf, meas_cov36 ? h->d_buf + 16 : nullptr, nullptr, nullptr, nullptr, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return PTL_OK;
@@ -565,8 +565,8 @@ extern "C" int ptl_ekf_get_state(ptl_ekf* h, double nav[19], double cov[324]) {
     HIPCHK(hipMemcpyAsync(&st, h->st, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (nav) {
-        memcpy(nav, st.pos, 24); memcpy(nav + 3, st.q, 32); memcpy(nav + 7, st.vel, 24);
-        memcpy(nav + 10, st.bg, 24); memcpy(nav + 13, st.ba, 24); memcpy(nav + 16, st.grav, 24);
+        memcpy(nav, st.nav.pos, 24); memcpy(nav + 3, st.nav.q, 32); memcpy(nav + 7, st.nav.vel, 24);
+        memcpy(nav + 10, st.nav.bg, 24); memcpy(nav + 13, st.nav.ba, 24); memcpy(nav + 16, st.nav.grav, 24);
     }
     if (cov) memcpy(cov, st.P, sizeof st.P);
     return PTL_OK;
@@ -581,7 +581,7 @@ extern "C" int ptl_ekf_pose_mat(ptl_ekf* h, double T[16]) {
 extern "C" int ptl_ekf_ts(ptl_ekf* h, double* ts) {
     if (!h || !ts) return set_err(PTL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    HIPCHK(hipMemcpyAsync(ts, (char*)h->st + offsetof(EkfState, cur_ts), 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ts, (char*)h->st + (offsetof(EkfState, nav) + offsetof(EkfNav, cur_ts)), 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return PTL_OK;
 }
@@ -685,9 +685,11 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
     const size_t pps = (size_t)s->cfg.points_per_scan;
     const int64_t end = s->next_scan + n;
     for (int64_t k = s->next_scan; k < end; ++k) {
+        // IMU samples that precede scan k and were not consumed yet (only before the very first scan of a run,
+        // or when the previous scan was skipped: otherwise the previous scan's EKF launch already ran them)
         const int64_t e = with_ekf ? s->imu_end[(size_t)k] : s->imu_pos;
         if (e > s->imu_pos) {
-            k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr);
+            k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
             s->imus_per_scan += e - s->imu_pos;
             s->imu_pos = e;
         }
@@ -698,9 +700,14 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
         if (rc) return rc;
         const int64_t o = s->n_out;
         const double* kiss_pose = s->icp->c.traj + 16 * (s->icp->scans_done - 1);
-        if (with_ekf)
-            k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, nullptr, 0, 0, kiss_pose, nullptr, s->d_res_poses + 16 * o,
-                                                s->d_res_t + o, s->d_rows + 8 * o);
+        if (with_ekf) {
+            // one launch: update with scan k's pose, then predict through the IMU samples up to scan k+1
+            const int64_t e2 = (k + 1 < s->cfg.n_scans) ? s->imu_end[(size_t)k + 1] : s->imu_pos;
+            k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e2, kiss_pose, nullptr,
+                                                s->d_res_poses + 16 * o, s->d_res_t + o, s->d_rows + 8 * o, 1);
+            s->imus_per_scan += e2 - s->imu_pos;
+            s->imu_pos = e2;
+        }
         s->scan_of_out.push_back(k);
         s->n_out++;
     }

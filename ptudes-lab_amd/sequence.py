@@ -1,0 +1,89 @@
+"""The reference's driver loop (cli/ekf_bench.py:493-563) over an event stream, two ways:
+
+`run_events`   per-call API (KissICPWrapper + ESEKF objects, one host round trip per event) - what the
+               reference's loop does, for arbitrary feeds;
+`run_resident` the same loop on a sequence uploaded to HBM once (`core.SeqRunner`, no host round trip per scan).
+
+Events are ("imu", IMU) and ("scan", xyz (N,3), t01 (N,) or None, ts) in packet order.
+"""
+import time
+
+import numpy as np
+
+from . import core
+from .ins.data import IMU
+from .ins.es_ekf import ESEKF
+from .kiss import KissICPWrapper
+
+
+def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use_imu_prediction=False,
+               guess_fn=None, logging=False, device_id=0):
+    """Returns dict(res_t, res_poses, kiss_poses, kiss_icp, ekf, timings).  `guess_fn(ts)` (optional) supplies an
+    external guess (the reference's --use-gt-guess, ekf_bench.py:536-542)."""
+    kiss_icp = KissICPWrapper(metadata, _use_extrinsics=True, _min_range=kiss_min_range, _max_range=kiss_max_range,
+                              device_id=device_id)
+    ekf = ESEKF(_logging=logging, device_id=device_id)
+    res_t, res_poses, kiss_poses = [], [], []
+    t_imu = t_corr = t_kiss = 0.0
+    n_imu = n_corr = 0
+    imus_per_scan = 1  # ekf_bench.py:491
+    for ev in events:
+        if ev[0] == "imu":
+            t1 = time.monotonic()
+            ekf.processImu(ev[1])
+            t_imu += time.monotonic() - t1
+            n_imu += 1
+            imus_per_scan += 1
+            continue
+        if not imus_per_scan:  # ekf_bench.py:512-518
+            continue
+        imus_per_scan = 0
+        _, xyz, t01, ts = ev
+        if use_imu_prediction:
+            guess = ekf.nav.pose_mat()
+        elif guess_fn is not None:
+            guess = guess_fn(ts)
+        else:
+            last = kiss_icp._kiss.poses[-1] if kiss_icp._kiss.poses else np.eye(4)
+            guess = last @ kiss_icp._kiss.get_prediction_model()
+        t1 = time.monotonic()
+        kiss_icp.register_points(xyz, t01, ts, initial_guess=guess)
+        t_kiss += time.monotonic() - t1
+        t1 = time.monotonic()
+        ekf.processPose(kiss_icp.pose)
+        t_corr += time.monotonic() - t1
+        n_corr += 1
+        kiss_poses.append(kiss_icp.pose)
+        res_poses.append(ekf.nav.pose_mat())
+        res_t.append(ekf.ts)
+    timings = dict(imu=t_imu / max(n_imu, 1), corr=t_corr / max(n_corr, 1), kiss=t_kiss / max(n_corr, 1))
+    return dict(res_t=res_t, res_poses=res_poses, kiss_poses=kiss_poses, kiss_icp=kiss_icp, ekf=ekf, timings=timings)
+
+
+def synthetic_events(seq, n_scans=None):
+    """event stream of a synth.Sequence in the reference feed's order"""
+    n = seq.n_scans if n_scans is None else n_scans
+    for k in range(n):
+        a, b = seq.imu_range_for_scan(k)
+        for i in range(a, b):
+            yield ("imu", IMU(seq.imu[i, 1:4].copy(), seq.imu[i, 4:7].copy(), float(seq.imu[i, 0])))
+        yield ("scan", seq.scan(k), None, float(seq.t_base + (k + 1) * seq.scan_dt))
+
+
+def run_resident(seq, n_scans=None, *, use_imu_prediction=False, with_ekf=True, device_id=0, **icp_over):
+    """Upload a synth.Sequence and run the loop on device.  Returns the SeqRunner results dict + 'seconds'."""
+    n = seq.n_scans if n_scans is None else n_scans
+    n_imu = seq.imu_range_for_scan(n - 1)[1] if with_ekf else 0
+    r = core.SeqRunner(n, seq.H * seq.W, n_imu, max_range=seq.max_range, min_range=seq.min_range,
+                       use_imu_prediction=use_imu_prediction, with_ekf=with_ekf, device_id=device_id,
+                       scan_cols=seq.W, **icp_over)
+    for k in range(n):
+        r.upload_scan(k, seq.scan(k))
+    ends = [seq.imu_range_for_scan(k)[1] if with_ekf else 0 for k in range(n)]
+    r.upload_imu(seq.imu[:n_imu] if with_ekf else np.zeros((0, 7)), ends)
+    t0 = time.perf_counter()
+    r.run()
+    out = r.results()
+    out["seconds"] = time.perf_counter() - t0
+    out["runner"] = r
+    return out

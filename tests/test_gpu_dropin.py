@@ -1,0 +1,104 @@
+"""GPU tests of the drop-in surface: ESEKF / KissICPWrapper classes and the `ekf-bench` commands."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+from click.testing import CliRunner
+
+import ptudes_lab_amd  # noqa: F401
+from oracle import cpu as orc
+from ptudes_lab_amd import sequence, synth
+from ptudes_lab_amd import utils as pu
+from ptudes_lab_amd.cli.run import ptudes_cli
+from ptudes_lab_amd.ins.data import IMU, ekf_traj_ate
+from ptudes_lab_amd.ins.es_ekf import ESEKF
+from ptudes_lab_amd.kiss import KissICPWrapper
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ekf_bench_sim_stdout_matches_reference(golden_dir):
+    """`ptudes ekf-bench sim -t 2.0` with the legacy RNG seeded to 0 prints what the reference printed"""
+    np.random.seed(0)
+    res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "sim", "-t", "2.0"])
+    assert res.exit_code == 0, res.output
+    ref = open(os.path.join(golden_dir, "ekf_sim_stdout.txt")).read()
+    assert res.output == ref
+
+
+def test_esekf_class_logging_and_ate(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ekf_sim.npz"))
+    ekf_gt, ekf = ESEKF(_logging=True), ESEKF(_logging=True)
+    last = g["ts"][0]
+    for i, ts in enumerate(g["ts"]):
+        ekf_gt.processImu(IMU(g["ideal_lacc"][i], g["ideal_avel"][i], ts))
+        ekf.processImu(IMU(g["noisy_lacc"][i], g["noisy_avel"][i], ts))
+        if ts - last > 0.1:
+            ekf.processPose(ekf_gt.nav.pose_mat())
+            last = ts
+    assert len(ekf._nav_update_idxs) == int(g["n_updates"])
+    assert len(ekf._navs) == len(ekf._navs_pred) == len(ekf._navs_t)
+    r, t = ekf_traj_ate(ekf_gt, ekf)
+    assert abs(r - float(g["ate_rot"])) < 1e-9 and abs(t - float(g["ate_trans"])) < 1e-9
+    assert ekf.ts == g["ts"][-1]
+    assert np.abs(ekf._cov - g["cov"]).max() <= 1e-9 * np.abs(g["cov"]).max()
+
+
+@pytest.fixture(scope="module")
+def seq():
+    return synth.make_sequence(seed=1001, n_scans=12)
+
+
+def test_kiss_wrapper_matches_oracle(seq):
+    meta = SimpleNamespace(format=SimpleNamespace(columns_per_frame=seq.W, pixels_per_column=seq.H))
+    w = KissICPWrapper(meta, _min_range=1.0, _max_range=70.0)
+    ref = orc.ICP(70.0, 1.0)
+    t01 = seq.column_times()
+    gt = seq.gt_poses(0.5)
+    for k in range(6):
+        x = seq.scan(k)
+        guess = np.linalg.inv(gt[0]) @ gt[k] if k % 2 else None  # alternate external / constant-velocity guess
+        scan = SimpleNamespace(xyz=x.reshape(seq.H, seq.W, 3), ts=100.0 + 0.1 * k)
+        T = w.register_frame(scan, initial_guess=guess)
+        Tr = ref.register_frame(x.astype(np.float64), t01, guess)
+        assert np.abs(T - Tr).max() < 2e-4
+        assert abs(w._sigmas[-1] - ref.stats[-1]["sigma"]) < 1e-9
+        assert abs(w._err_dt[-1] - ref.stats[-1]["err_dt"]) < 2e-4
+    assert len(w.poses) == 6 and w.poses_ts[-1] == 100.5
+    assert np.abs(w._kiss.get_prediction_model() - ref.prediction()).max() < 4e-4
+    assert np.allclose(w.velocity, w._kiss.get_prediction_model()[:3, 3] / 0.1)
+    assert w.local_map_points.shape == (ref.stats[-1]["map_points"], 3)
+    assert w._config.mapping.voxel_size == 0.7 and w._config.data.max_range == 70.0
+    # masked input form (reference kiss.py:59-61): only RANGE != 0 pixels, with their per-pixel times
+    x = seq.scan(6)
+    rng = (np.abs(x).sum(1) > 0).astype(np.uint32)
+    T = w.register_frame(SimpleNamespace(xyz=x, range=rng, ts=100.6))
+    Tr = ref.register_frame(x[rng != 0].astype(np.float64), t01[rng != 0], None)
+    assert np.abs(T - Tr).max() < 2e-4
+
+
+def test_event_loop_equals_resident_runner(seq):
+    """per-call driver loop (host round trip per event) == device-resident runner, both --use-imu-prediction"""
+    n = 8
+    meta = SimpleNamespace(format=SimpleNamespace(columns_per_frame=seq.W, pixels_per_column=seq.H))
+    a = sequence.run_events(sequence.synthetic_events(seq, n), meta, use_imu_prediction=True)
+    b = sequence.run_resident(seq, n, use_imu_prediction=True)
+    assert np.array_equal(np.array(a["res_t"]), b["res_t"])
+    assert np.abs(np.array(a["kiss_poses"]) - b["kiss_poses"]).max() < 1e-9
+    assert np.abs(np.array(a["res_poses"]) - b["res_poses"]).max() < 1e-9
+
+
+def test_ouster_command_on_synthetic_writes_pose_files(tmp_path):
+    fk, fn = tmp_path / "k.txt", tmp_path / "n.csv"
+    res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "ouster", "--synthetic", "1002", "--end-scan", "5",
+                                          "--use-imu-prediction", "--save-kitti-poses", str(fk),
+                                          "--save-nc-gt-poses", str(fn)])
+    assert res.exit_code == 0, res.output
+    assert "Timings:" in res.output and "KissICP register frame:" in res.output
+    back = pu.read_newer_college_gt(str(fn))
+    assert len(back) == 6 and np.loadtxt(str(fk)).shape == (6, 12)
+    assert fn.read_text().startswith("# data path: synthetic:1002")
+    # cmp of the file against itself: zero error
+    res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "cmp", str(fn), str(fn)])
+    assert res.exit_code == 0 and "ATE trans: 0.0000 m" in res.output
