@@ -24,6 +24,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def pmc_traffic():
+    """HBM bytes per k_gn_loop launch from the committed rocprofv3 PMC passes (profiles/), or None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1])).get("k_gn_loop_traffic_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def icp_bytes(stats):
     """Algorithmic bytes of one Gauss-Newton launch (B_icp): per iteration the source is
     read once (12 B/pt), 27 hash slots are probed per point (16 B each) and every candidate map point is
@@ -93,7 +105,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # launched by torch.distributed.run
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -108,7 +120,7 @@ def main():
     pps = args.rows * args.cols
     seqs, runners = [], []
     for j in range(S):
-        seed = 1000 + rank * S + j
+        seed = 1000 + rank + world * j  # sequence ids s with s % world == rank
         sq = synth.make_sequence(seed=seed, n_scans=n_total, H=args.rows, W=args.cols, min_range=args.min_range,
                                  max_range=args.max_range)
         n_imu = sq.imu_range_for_scan(n_total - 1)[1]
@@ -144,9 +156,8 @@ def main():
     sync(); barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from ptudes_lab_amd import parallel
+        dt = parallel.max_over_ranks(dt, dist, device="cuda")
 
     # per-rank accounting
     outs = [r.results() for r in runners]
@@ -163,15 +174,13 @@ def main():
     n_timed = sum(len(o["stats"]) - W for o in outs)
     assert n_timed == K * S, (n_timed, K, S)
 
-    # final trajectory gather: the only collective (T x 8 NC-GT rows per sequence)
+    # final trajectory gather: the only collective (T x 8 NC-GT rows per sequence, RCCL all-gather)
     gathered = None
     if dist is not None:
+        from ptudes_lab_amd import parallel
         rows = torch.zeros((S, n_total, 8), dtype=torch.float64, device="cuda")
-        for j, r in enumerate(runners):
-            r.copy_traj(rows[j].data_ptr(), n_total)
-        allrows = [torch.empty_like(rows) for _ in range(world)]
-        dist.all_gather(allrows, rows)
-        gathered = torch.stack(allrows).cpu().numpy()
+        counts = [r.copy_traj(rows[j].data_ptr(), n_total) for j, r in enumerate(runners)]
+        gathered = parallel.gather_trajectories(rows, counts, dist)
 
     if rank == 0:
         from oracle import cpu as orc
@@ -195,7 +204,7 @@ def main():
                        "sequences_per_gpu": S, "sequence_seeds": f"{1000}..{1000 + world * S - 1}",
                        "scans_per_sequence": n_total, "parallelism": f"{world} independent sequence shard(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "k_gn_loop",
+                         "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(), "kernel": "k_gn_loop",
                          "avg_launch_us": 1e6 * avg_gn_s, "algorithmic_bytes_per_launch": avg_gn_bytes,
                          "launches": gn_n},
             "whole_scan": {"algorithmic_bytes_per_scan": b_scan / max(n_timed, 1),
@@ -215,7 +224,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         if gathered is not None:
-            line["gathered_trajectories"] = list(gathered.shape)
+            line["gathered_trajectories"] = {"sequences": len(gathered), "rows_each": sorted({len(v) for v in gathered.values()})}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,76 @@
+"""N > 1 path on CPU: two gloo ranks shard sequences, gather padded trajectories, agree on the max time."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ptudes_lab_amd  # noqa: F401
+from ptudes_lab_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_rows(seq_id, n):
+    rng = np.random.default_rng(sequence_seed := parallel.sequence_seed(seq_id))
+    rows = np.zeros((n, 8))
+    rows[:, 0] = 1000.0 + 0.1 * np.arange(n)
+    rows[:, 1:4] = np.cumsum(rng.normal(0, 0.1, (n, 3)), axis=0)
+    q = rng.normal(0, 1, (n, 4))
+    rows[:, 4:8] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    return rows
+
+
+def _worker(rank, world, port, n_seq, t_max, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = parallel.shard_sequences(n_seq, rank, world)
+    rows = torch.zeros((len(mine), t_max, 8), dtype=torch.float64)
+    counts = []
+    for j, s in enumerate(mine):
+        n = 5 + 3 * s  # ragged lengths
+        rows[j, :n] = torch.from_numpy(_fake_rows(s, n))
+        counts.append(n)
+    got = parallel.gather_trajectories(rows, counts, dist)
+    mx = parallel.max_over_ranks(0.5 + rank, dist)
+    ok = mx == 0.5 + (world - 1)
+    for r in range(world):
+        for j, s in enumerate(parallel.shard_sequences(n_seq, r, world)):
+            ok &= np.array_equal(got[(r, j)], _fake_rows(s, 5 + 3 * s))
+    q.put((rank, bool(ok), len(got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather():
+    world, n_seq, t_max = 2, 4, 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_seq, t_max, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res) and all(r[2] == n_seq for r in res)
+
+
+def test_sharding_and_rows():
+    assert parallel.shard_sequences(8, 3, 8) == [3]
+    assert parallel.shard_sequences(8, 1, 2) == [1, 3, 5, 7]
+    assert sorted(sum((parallel.shard_sequences(10, r, 4) for r in range(4)), [])) == list(range(10))
+    rows = _fake_rows(0, 6)
+    t, T = parallel.rows_to_poses(rows)
+    assert np.array_equal(t, rows[:, 0]) and np.allclose(T[:, :3, 3], rows[:, 1:4])
+    assert np.allclose(np.einsum("nij,nkj->nik", T[:, :3, :3], T[:, :3, :3]), np.eye(3))
