@@ -96,6 +96,10 @@ def main():
                     help="use the constant-velocity guess instead of --use-imu-prediction (reference default)")
     ap.add_argument("--gn-wgs", type=int, default=0, help="workgroups of the persistent GN kernel (0 = library default)")
     ap.add_argument("--gn-threads", type=int, default=0)
+    ap.add_argument("--voxel-size", type=float, default=0.0, help="override the map voxel size (default max_range/100)")
+    ap.add_argument("--map-blocks", type=int, default=0, help="voxel-block pool capacity")
+    ap.add_argument("--map-table", type=int, default=0, help="map hash-table slots (power of two)")
+    ap.add_argument("--workload-name", type=str, default="")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -127,7 +131,10 @@ def main():
         r = core.SeqRunner(n_total, pps, n_imu, max_range=args.max_range, min_range=args.min_range,
                            use_imu_prediction=use_imu, with_ekf=True, device_id=local_rank, scan_cols=args.cols,
                            **({"gn_workgroups": args.gn_wgs} if args.gn_wgs else {}),
-                           **({"gn_threads": args.gn_threads} if args.gn_threads else {}))
+                           **({"gn_threads": args.gn_threads} if args.gn_threads else {}),
+                           **({"voxel_size": args.voxel_size} if args.voxel_size else {}),
+                           **({"map_block_capacity": args.map_blocks} if args.map_blocks else {}),
+                           **({"map_table_capacity": args.map_table} if args.map_table else {}))
         for k in range(n_total):
             r.upload_scan(k, sq.scan(k))
         r.upload_imu(sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n_total)])
@@ -194,13 +201,14 @@ def main():
         avg_gn_bytes = gn_bytes / max(n_timed, 1)
         achieved = avg_gn_bytes / avg_gn_s if avg_gn_s > 0 else 0.0
         line = {
-            "metric": "lidar scans/sec (ICP+EKF) on 128x1024 sweeps",
+            "metric": f"lidar scans/sec (ICP+EKF) on {args.rows}x{args.cols} sweeps",
             "value": K * S * world / dt, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic {args.rows}x{args.cols} sweeps, random-walk SE(3) GT, "
                                    f"ICP + IMU-EKF ({'--use-imu-prediction' if use_imu else 'constant-velocity guess'}), "
-                                   f"min/max range {args.min_range}/{args.max_range} m, voxel {args.max_range / 100:.2f} m",
+                                   f"min/max range {args.min_range}/{args.max_range} m, voxel {(args.voxel_size or args.max_range / 100):.2f} m"
+                                   + (f" [{args.workload_name}]" if args.workload_name else ""),
                        "sequences_per_gpu": S, "sequence_seeds": f"{1000}..{1000 + world * S - 1}",
                        "scans_per_sequence": n_total, "parallelism": f"{world} independent sequence shard(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -211,6 +219,9 @@ def main():
                            "achieved_GBps": (b_scan * world / dt) / 1e9 if world == 1 else None,
                            "gn_share_of_wall": (gn_ms / 1e3) / (dt * S) if S == 1 else None,
                            "mean_gn_iterations": float(np.mean(iters))},
+            "map": {"voxels_end": o["stats"][-1]["map_voxels"], "points_end": o["stats"][-1]["map_points"],
+                    "n_src_mean": float(np.mean([s["n_src"] for s in o["stats"][W:]])),
+                    "n_down_mean": float(np.mean([s["n_down"] for s in o["stats"][W:]]))},
             "accuracy": {"ate_vs_gt_ref_style_rot": ate_r, "ate_vs_gt_ref_style_trans_m2": ate_t,
                          "rmse_vs_gt_m": rmse_gt},
         }

@@ -121,6 +121,26 @@ int ptl_icp_linear_system(ptl_icp *h, const double *src_world, int64_t n, double
 int ptl_icp_align(ptl_icp *h, const double *frame, int64_t n, const double guess[16], double max_dist,
                   double kernel, double out_pose[16], int32_t *iterations);
 
+/* ------------------------------------------------------------------------------------------------
+ * Range-image input == ouster client.XYZLut as the reference uses it (kiss.py:28-29, 59-60) + reduce_active_beams
+ * (utils.py:328-341).  SURVEY.md 8(f) rank 1: a sweep enters as a 512 KB u32 range image instead of 3 MB of xyz.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ptl_lut ptl_lut;
+/* beam angles in degrees (H each), beam-origin offset in mm, lidar_to_sensor 4x4 with mm translation (SensorInfo
+ * fields of the same names); extrinsic16_m (nullable): 4x4 with metre translation, applied on top
+ * (use_extrinsics=True, ekf_bench.py:440-452) */
+int ptl_lut_create(int device_id, int32_t H, int32_t W, const double *beam_altitude_deg, const double *beam_azimuth_deg,
+                   double lidar_origin_to_beam_origin_mm, const double *lidar_to_sensor16_mm,
+                   const double *extrinsic16_m, ptl_lut **out);
+int ptl_lut_destroy(ptl_lut *l);
+/* XYZLut.__call__: range image (H*W u32, mm, 0 = no return) -> H*W x 3 f64 metres */
+int ptl_lut_apply(ptl_lut *l, const uint32_t *range_mm, double *xyz_out);
+/* rows kept active by reduce_active_beams(ls, beams_num); beams_num <= 0 = all rows.  Applies to range-image input. */
+int ptl_icp_set_active_beams(ptl_icp *h, int32_t H, int32_t beams_num);
+/* register_frame on a raw range image; per-pixel times are column-implicit (kiss.py:34-35) */
+int ptl_icp_register_range(ptl_icp *h, ptl_lut *lut, const uint32_t *range_mm, double scan_ts, const double *guess,
+                           double out_pose[16], ptl_icp_stats *stats);
+
 /* profiling: HIP-event time of the dominant kernel (the persistent Gauss-Newton loop) since last reset */
 int ptl_icp_profile(ptl_icp *h, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
 /* diagnostic: accumulated clock ticks of workgroup 0 per phase of that kernel (nn, wg-reduce+publish, barrier,

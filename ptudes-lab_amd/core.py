@@ -65,6 +65,23 @@ class Icp:
         self.stats.append(st.as_dict())
         return out
 
+    def register_range(self, lut, range_mm, guess=None, scan_ts=0.0):
+        """register a raw range image (H*W u32 mm); xyz, the RANGE != 0 mask and column times happen on device"""
+        r = np.ascontiguousarray(range_mm, dtype=np.uint32).reshape(-1)
+        if r.size != lut.H * lut.W:
+            raise ValueError("range image size mismatch")
+        g = None if guess is None else L.as_f64(guess).reshape(16)
+        out = np.empty((4, 4))
+        st = L.IcpStats()
+        L.check(L.lib().ptl_icp_register_range(self._h, lut._h, r.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               float(scan_ts), None if g is None else L.dptr(g), L.dptr(out),
+                                               C.byref(st)))
+        self.stats.append(st.as_dict())
+        return out
+
+    def set_active_beams(self, H, beams_num):
+        L.check(L.lib().ptl_icp_set_active_beams(self._h, int(H), int(beams_num)))
+
     @property
     def num_poses(self):
         n = C.c_int64()
@@ -131,6 +148,38 @@ class Icp:
         L.check(L.lib().ptl_icp_align(self._h, L.dptr(f), len(f), L.dptr(g), max_dist, kernel, L.dptr(out),
                                       C.byref(it)))
         return out, it.value
+
+
+class Lut:
+    """range image -> xyz on device (ouster client.XYZLut equivalent, reference kiss.py:28-29)"""
+
+    def __init__(self, H, W, beam_altitude_deg, beam_azimuth_deg, lidar_origin_to_beam_origin_mm=0.0,
+                 lidar_to_sensor_mm=None, extrinsic_m=None, device_id=0):
+        self.H, self.W = int(H), int(W)
+        alt, az = L.as_f64(beam_altitude_deg), L.as_f64(beam_azimuth_deg)
+        if len(alt) != H or len(az) != H:
+            raise ValueError("need one altitude / azimuth angle per row")
+        T = L.as_f64(np.eye(4) if lidar_to_sensor_mm is None else lidar_to_sensor_mm).reshape(16)
+        E = None if extrinsic_m is None else L.as_f64(extrinsic_m).reshape(16)
+        self._h = C.c_void_p()
+        L.check(L.lib().ptl_lut_create(device_id, self.H, self.W, L.dptr(alt), L.dptr(az),
+                                       float(lidar_origin_to_beam_origin_mm), L.dptr(T),
+                                       None if E is None else L.dptr(E), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().ptl_lut_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __call__(self, range_mm):
+        r = np.ascontiguousarray(range_mm, dtype=np.uint32).reshape(-1)
+        if r.size != self.H * self.W:
+            raise ValueError("range image size mismatch")
+        out = np.empty((self.H * self.W, 3))
+        L.check(L.lib().ptl_lut_apply(self._h, r.ctypes.data_as(C.POINTER(C.c_uint32)), L.dptr(out)))
+        return out
 
 
 class Ekf:

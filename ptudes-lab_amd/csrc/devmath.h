@@ -192,35 +192,55 @@ PTL_HD void se3_log(const Rt& T, double xi[6]) {
 // Solve JTJ dx = -JTr from the 27 packed sums (21 upper-triangle JTJ row-major, then 6 JTr) by an
 // unpivoted LDL^T; a zero pivot yields a zero component (all-zero system of a scan with no pairs).
 PTL_HD void solve6_ldlt(const double* s, double dx[6]) {
+    // fully unrolled so that every array stays in registers on the device (no scratch traffic)
     double A[36], L[36], D[6], y[6];
     int o = 0;
-    for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
         for (int j = i; j < 6; ++j) {
             A[6 * i + j] = s[o];
             A[6 * j + i] = s[o];
             ++o;
         }
+    }
+#pragma unroll
     for (int i = 0; i < 36; ++i) L[i] = 0.0;
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = A[6 * j + j];
-        for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k] * D[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < j) d -= L[6 * j + k] * L[6 * j + k] * D[k];
         D[j] = d;
         L[6 * j + j] = 1.0;
-        for (int i = j + 1; i < 6; ++i) {
-            double v = A[6 * i + j];
-            for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k] * D[k];
-            L[6 * i + j] = (d != 0.0) ? v / d : 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i > j) {
+                double v = A[6 * i + j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k < j) v -= L[6 * i + k] * L[6 * j + k] * D[k];
+                L[6 * i + j] = (d != 0.0) ? v / d : 0.0;
+            }
         }
     }
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         double v = -s[21 + i];
-        for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < i) v -= L[6 * i + k] * y[k];
         y[i] = v;
     }
+#pragma unroll
     for (int i = 0; i < 6; ++i) y[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double v = y[i];
-        for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * dx[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k > i) v -= L[6 * k + i] * dx[k];
         dx[i] = v;
     }
 }

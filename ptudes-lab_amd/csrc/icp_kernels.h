@@ -86,6 +86,11 @@ struct Ctx {
     // scan input
     const float* in_f32;
     const double* in_f64;
+    // range-image input (ouster client.XYZLut equivalent, reference kiss.py:28-29,59-60): xyz = range * dir + off
+    const unsigned* in_range;       // [H*W] millimetres, 0 = no return
+    const double* lut_dir;          // [H*W][3] unit direction * 0.001 (metres per mm)
+    const double* lut_off;          // [H*W][3] metres
+    const unsigned char* row_mask;  // [H] 1 = active beam (reduce_active_beams, reference utils.py:328-341), or null
     const double* t01;
     int n_in, n_max;
     // scan work buffers
@@ -237,6 +242,30 @@ __global__ __launch_bounds__(1024) void k_scan_prologue(Ctx c) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ XYZLut
+// ouster-sdk client.XYZLut (third-party, [UPSTREAM-KNOWLEDGE]): for pixel (row u, col v)
+//   theta_enc = 2 pi (1 - v / W), theta_az = -az_u, phi = alt_u (degrees -> radians), n = beam origin offset (mm)
+//   dir = (cos(theta_enc + theta_az) cos phi, sin(theta_enc + theta_az) cos phi, sin phi)
+//   off = (n (cos theta_enc - dir.x), n (sin theta_enc - dir.y), -n dir.z)
+// then the rigid transform T (lidar->sensor, optionally followed by the extrinsic) rotates both and adds its
+// translation to the offset.  Stored scaled to metres: xyz_m = range_mm * dir_m + off_m.
+__global__ __launch_bounds__(256) void k_build_lut(int H, int W, const double* alt_deg, const double* az_deg, double n_mm,
+                                                   const double* T16_mm, double* dir_out, double* off_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int u = i / W, v = i % W;
+    const double kPi = 3.14159265358979323846;
+    const double enc = 2.0 * kPi * (1.0 - (double)v / (double)W);
+    const double az = -az_deg[u] * kPi / 180.0, phi = alt_deg[u] * kPi / 180.0;
+    const double dx = cos(enc + az) * cos(phi), dy = sin(enc + az) * cos(phi), dz = sin(phi);
+    const double ox = n_mm * (cos(enc) - dx), oy = n_mm * (sin(enc) - dy), oz = -n_mm * dz;
+    const double* T = T16_mm;
+    for (int r = 0; r < 3; ++r) {
+        dir_out[3 * (size_t)i + r] = (T[4 * r] * dx + T[4 * r + 1] * dy + T[4 * r + 2] * dz) * 1e-3;
+        off_out[3 * (size_t)i + r] = (T[4 * r] * ox + T[4 * r + 1] * oy + T[4 * r + 2] * oz + T[4 * r + 3]) * 1e-3;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K1
 __global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -249,8 +278,18 @@ __global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) {
     if (i >= c.n_in && i < st->prev_n_in) c.slot2[i] = -1;
     if (i < c.n_in) {
         V3 p;
-        if (c.in_f32) p = v3((double)c.in_f32[3 * (size_t)i], (double)c.in_f32[3 * (size_t)i + 1], (double)c.in_f32[3 * (size_t)i + 2]);
-        else p = v3(c.in_f64[3 * (size_t)i], c.in_f64[3 * (size_t)i + 1], c.in_f64[3 * (size_t)i + 2]);
+        if (c.in_range) {
+            unsigned rg = c.in_range[i];
+            if (c.row_mask && !c.row_mask[i / c.W]) rg = 0;
+            const double r = (double)rg;
+            const double* d = c.lut_dir + 3 * (size_t)i;
+            const double* o = c.lut_off + 3 * (size_t)i;
+            p = rg ? v3(r * d[0] + o[0], r * d[1] + o[1], r * d[2] + o[2]) : v3(0.0, 0.0, 0.0);
+        } else if (c.in_f32) {
+            p = v3((double)c.in_f32[3 * (size_t)i], (double)c.in_f32[3 * (size_t)i + 1], (double)c.in_f32[3 * (size_t)i + 2]);
+        } else {
+            p = v3(c.in_f64[3 * (size_t)i], c.in_f64[3 * (size_t)i + 1], c.in_f64[3 * (size_t)i + 2]);
+        }
         if (st->do_deskew) {
             if (c.t01) {
                 const double s = c.t01[i] - 0.5;
@@ -397,14 +436,21 @@ __device__ __forceinline__ int map_find(const Ctx& c, unsigned long long key) {
 // 32 lanes cooperate on one source point: lanes 0..26 probe the 27 neighbour voxels in (i,j,k) ascending
 // order, then all lanes scan each found block (lane j <-> j-th stored point, coalesced x/y/z reads).
 // Returns in every lane of the group: best squared distance, best target, found flag; adds candidates to ncand.
+// `ck` / `cblk` carry the centre voxel and this lane's block id from the previous call: the map is constant
+// during a Gauss-Newton loop, so when the point has not left its voxel the 27 probes are skipped.
 __device__ __forceinline__ bool nn_search32(const Ctx& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
-                                            long long& ncand) {
+                                            long long& ncand, unsigned long long& ck, int& cblk, bool use_cache) {
     const int kx = (int)(s.x / c.vs), ky = (int)(s.y / c.vs), kz = (int)(s.z / c.vs);
+    const unsigned long long key = pack_key(kx, ky, kz);
     int blk = -1;
-    if (lane32 < 27) {
+    if (use_cache && key == ck) {
+        blk = cblk;
+    } else if (lane32 < 27) {
         const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
         blk = map_find(c, pack_key(kx + di, ky + dj, kz + dk));
     }
+    ck = key;
+    cblk = blk;
     const unsigned long long ball = __ballot(blk >= 0);
     unsigned m = (unsigned)(ball >> gbase);
     double bd = 1.7976931348623157e308;
@@ -544,6 +590,7 @@ __device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_emp
 #define GN_MAX_GROUPS (GN_MAX_THREADS / 32)
 __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     __shared__ double red[GN_MAX_GROUPS][32];
+    __shared__ double red2[4][32];
     __shared__ double tot[32];
     __shared__ double Esh[12];
     __shared__ double Tsh[12];
@@ -581,6 +628,10 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     long long cand_total = 0;
     int iters = 0, ncorr_last = 0;
     long long ph[5] = {0, 0, 0, 0, 0};
+    // one point per 32-lane group for the whole loop => its probe results can be cached across iterations
+    const bool single_pass = n <= G * NG;
+    unsigned long long ckey = EMPTY_KEY;
+    int cblk = -1;
     for (int it = 0; it < max_iter; ++it) {
         const long long c0 = __builtin_readcyclecounter();
         double acc = 0.0;
@@ -599,7 +650,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             }
             V3 t;
             double d2;
-            const bool found = nn_search32(c, s, lane32, gbase, t, d2, ncand);
+            const bool found = nn_search32(c, s, lane32, gbase, t, d2, ncand, ckey, cblk, single_pass && it > 0);
             if (found && sqrt(d2) < max_dist) {  // uniform over the group
                 const V3 r = v3(s.x - t.x, s.y - t.y, s.z - t.z);
                 const double den = kern + (r.x * r.x + r.y * r.y + r.z * r.z);
@@ -614,9 +665,15 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         red[grp][lane32] = (lane32 == 28) ? (double)ncand0 : acc;
         __syncthreads();
         double* part = c.partials + ((size_t)(it & 1) * G + wg) * 32;
-        if (tid < 29) {
+        if (tid < 128) {  // 4 segments of NG/4 groups per column, then 4 -> 1, always in the same order
+            const int col = tid & 31, seg = tid >> 5, per = (NG + 3) >> 2;
             double s = 0.0;
-            for (int g = 0; g < NG; ++g) s += red[g][tid];
+            for (int g = seg * per; g < (seg + 1) * per && g < NG; ++g) s += red[g][col];
+            red2[seg][col] = s;
+        }
+        __syncthreads();
+        if (tid < 29) {
+            const double s = ((red2[0][tid] + red2[1][tid]) + red2[2][tid]) + red2[3][tid];
             __hip_atomic_store(&part[tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

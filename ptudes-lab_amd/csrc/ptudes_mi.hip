@@ -49,6 +49,7 @@ struct ptl_icp {
     int* d_counter;
     int64_t traj_cap;
     int64_t scans_done;
+    unsigned char* d_row_mask;  // active-beam mask for range-image input, or null
     int64_t last_n;      // points of the previous scan (its pass-2 VDS slots are released by the next K1)
     // profiling of the dominant kernel
     bool prof;
@@ -90,7 +91,7 @@ static int icp_free(ptl_icp* h) {
     Ctx& c = h->c;
     void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, c.fd, c.src0,
                     c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.partials,
-                    c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter};
+                    c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter, h->d_row_mask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -142,7 +143,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     h->own_stream = shared_stream == nullptr;
     h->stream = shared_stream;
     h->prof = false; h->ev_used = 0; h->gn_ms = 0; h->gn_launches = 0;
-    h->d_in = nullptr; h->d_t01 = nullptr; h->d_ext = nullptr; h->d_counter = nullptr;
+    h->d_in = nullptr; h->d_t01 = nullptr; h->d_ext = nullptr; h->d_counter = nullptr; h->d_row_mask = nullptr;
     memset(&h->c, 0, sizeof(Ctx));
     if (h->own_stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -230,12 +231,22 @@ static int map_rebuild(ptl_icp* h) {
 
 // Enqueue one whole scan on the handle's stream (no host synchronisation):
 // in_f32 / in_f64 / t01 / ext_guess are DEVICE pointers (one of in_* non-null).
+struct ptl_lut {
+    int device_id, H, W;
+    double *dir, *off;
+};
 static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f64, const double* t01, int64_t n,
-                            const double* ext_guess) {
+                            const double* ext_guess, const unsigned* in_range = nullptr, const ptl_lut* lut = nullptr) {
     if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "scan has %lld points, capacity %lld", (long long)n, (long long)h->n_max);
     if (h->scans_done >= h->traj_cap) { int rc = icp_grow_traj(h); if (rc) return rc; }
     Ctx c = h->c;
     c.in_f32 = in_f32; c.in_f64 = in_f64; c.t01 = t01; c.n_in = (int)n; c.ext_guess = ext_guess;
+    c.in_range = in_range;
+    if (in_range) {
+        if (!lut || (int64_t)lut->H * lut->W != n || lut->W != c.W) return set_err(PTL_ERR_ARG, "range image needs a LUT of the same H x W (W = cfg.scan_cols)");
+        c.lut_dir = lut->dir; c.lut_off = lut->off;
+        c.row_mask = h->d_row_mask;
+    }
     const int nb = (int)((n + 255) / 256) > 0 ? (int)((n + 255) / 256) : 1;
     hipStream_t s = h->stream;
     const int nb1 = (int)(((n > h->last_n ? n : h->last_n) + 255) / 256) > 0 ? (int)(((n > h->last_n ? n : h->last_n) + 255) / 256) : 1;
@@ -474,6 +485,119 @@ extern "C" int ptl_icp_profile(ptl_icp* h, int enable, double* gn_ms_total, int6
     if (gn_launches) *gn_launches = h->gn_launches;
     if (reset) { h->gn_ms = 0; h->gn_launches = 0; }
     h->prof = enable != 0;
+    return PTL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ range-image input
+extern "C" int ptl_lut_create(int device_id, int32_t H, int32_t W, const double* beam_altitude_deg,
+                              const double* beam_azimuth_deg, double lidar_origin_to_beam_origin_mm,
+                              const double* lidar_to_sensor16_mm, const double* extrinsic16_m, ptl_lut** out) {
+    if (!beam_altitude_deg || !beam_azimuth_deg || !lidar_to_sensor16_mm || !out || H < 1 || W < 1) return set_err(PTL_ERR_ARG, "bad argument");
+    if (ptl_device_count() <= device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", device_id);
+    HIPCHK(hipSetDevice(device_id));
+    // total transform in millimetres: extrinsic (metres -> mm) * lidar_to_sensor
+    double T[16];
+    memcpy(T, lidar_to_sensor16_mm, sizeof T);
+    if (extrinsic16_m) {
+        double E[16], R[16];
+        memcpy(E, extrinsic16_m, sizeof E);
+        E[3] *= 1e3; E[7] *= 1e3; E[11] *= 1e3;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0;
+                for (int k = 0; k < 4; ++k) s += E[4 * i + k] * T[4 * k + j];
+                R[4 * i + j] = s;
+            }
+        memcpy(T, R, sizeof T);
+    }
+    ptl_lut* l = new ptl_lut();
+    l->device_id = device_id; l->H = H; l->W = W; l->dir = nullptr; l->off = nullptr;
+    double* d_tmp = nullptr;
+    const size_t n = (size_t)H * W;
+    if (dalloc(&l->dir, 3 * n) != hipSuccess || dalloc(&l->off, 3 * n) != hipSuccess || dalloc(&d_tmp, (size_t)2 * H + 16) != hipSuccess) {
+        if (l->dir) (void)hipFree(l->dir);
+        if (l->off) (void)hipFree(l->off);
+        delete l;
+        return set_err(PTL_ERR_HIP, "LUT allocation failed");
+    }
+    HIPCHK(hipMemcpy(d_tmp, beam_altitude_deg, (size_t)H * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tmp + H, beam_azimuth_deg, (size_t)H * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tmp + 2 * H, T, sizeof T, hipMemcpyHostToDevice));
+    k_build_lut<<<(int)((n + 255) / 256), 256>>>(H, W, d_tmp, d_tmp + H, lidar_origin_to_beam_origin_mm, d_tmp + 2 * H, l->dir, l->off);
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipFree(d_tmp);
+    *out = l;
+    return PTL_OK;
+}
+extern "C" int ptl_lut_destroy(ptl_lut* l) {
+    if (!l) return PTL_OK;
+    (void)hipSetDevice(l->device_id);
+    (void)hipFree(l->dir); (void)hipFree(l->off);
+    delete l;
+    return PTL_OK;
+}
+// XYZLut.__call__: range image -> (H*W, 3) f64 xyz in metres (RANGE == 0 -> (0,0,0))
+__global__ __launch_bounds__(256) void k_lut_apply(int n, const unsigned* range, const double* dir, const double* off, double* xyz) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned rg = range[i];
+    const double r = (double)rg;
+    for (int k = 0; k < 3; ++k) xyz[3 * (size_t)i + k] = rg ? r * dir[3 * (size_t)i + k] + off[3 * (size_t)i + k] : 0.0;
+}
+extern "C" int ptl_lut_apply(ptl_lut* l, const uint32_t* range_mm, double* xyz_out) {
+    if (!l || !range_mm || !xyz_out) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(l->device_id));
+    const size_t n = (size_t)l->H * l->W;
+    unsigned* d_r = nullptr;
+    double* d_x = nullptr;
+    HIPCHK(dalloc(&d_r, n));
+    HIPCHK(dalloc(&d_x, 3 * n));
+    HIPCHK(hipMemcpy(d_r, range_mm, n * 4, hipMemcpyHostToDevice));
+    k_lut_apply<<<(int)((n + 255) / 256), 256>>>((int)n, d_r, l->dir, l->off, d_x);
+    HIPCHK(hipMemcpy(xyz_out, d_x, n * 24, hipMemcpyDeviceToHost));
+    (void)hipFree(d_r); (void)hipFree(d_x);
+    return PTL_OK;
+}
+// reduce_active_beams (reference utils.py:328-341): rows np.linspace(0, H, beams, endpoint=False, dtype=int) stay
+// active, every other row's RANGE is treated as 0.  beams_num <= 0 re-enables all rows.
+extern "C" int ptl_icp_set_active_beams(ptl_icp* h, int32_t H, int32_t beams_num) {
+    if (!h || H < 1) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->d_row_mask) { (void)hipFree(h->d_row_mask); h->d_row_mask = nullptr; }
+    if (beams_num <= 0) return PTL_OK;
+    std::vector<unsigned char> m((size_t)H, 0);
+    const double step = (double)H / (double)beams_num;  // numpy linspace(0, H, num, endpoint=False): i * (H / num)
+    for (int i = 0; i < beams_num; ++i) {
+        const int r = (int)((double)i * step);
+        if (r >= 0 && r < H) m[(size_t)r] = 1;
+    }
+    HIPCHK(hipMalloc((void**)&h->d_row_mask, (size_t)H));
+    HIPCHK(hipMemcpy(h->d_row_mask, m.data(), (size_t)H, hipMemcpyHostToDevice));
+    return PTL_OK;
+}
+// KissICPWrapper.register_frame on a raw range image (reference kiss.py:54-74): XYZLut + RANGE != 0 mask + pipeline
+extern "C" int ptl_icp_register_range(ptl_icp* h, ptl_lut* lut, const uint32_t* range_mm, double scan_ts,
+                                      const double* guess, double out_pose[16], ptl_icp_stats* stats) {
+    (void)scan_ts;
+    if (!h || !lut || !range_mm) return set_err(PTL_ERR_ARG, "null argument");
+    const int64_t n = (int64_t)lut->H * lut->W;
+    if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "scan has %lld points, capacity %lld", (long long)n, (long long)h->n_max);
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->d_in, range_mm, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    if (guess) HIPCHK(hipMemcpyAsync(h->d_ext, guess, 16 * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = icp_enqueue_scan(h, nullptr, nullptr, nullptr, n, guess ? h->d_ext : nullptr, (const unsigned*)h->d_in, lut);
+    if (rc) return rc;
+    k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);
+    const int64_t k = h->scans_done - 1;
+    double pose[16];
+    ScanStats ss;
+    HIPCHK(hipMemcpyAsync(pose, h->c.traj + 16 * k, sizeof pose, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&ss, h->c.sstats + k, sizeof ss, hipMemcpyDeviceToHost, h->stream));
+    rc = icp_check_flags(h);
+    if (rc) return rc;
+    if (out_pose) memcpy(out_pose, pose, sizeof pose);
+    if (stats) stats_out(ss, stats);
     return PTL_OK;
 }
 

@@ -1,0 +1,73 @@
+"""range image -> xyz on device (XYZLut equivalent) + reduce_active_beams, against the
+numpy restatement (oracle/lut.py) and the oracle pipeline."""
+import numpy as np
+import pytest
+
+import ptudes_lab_amd  # noqa: F401
+from oracle import cpu as orc
+from oracle import lut as olut
+from ptudes_lab_amd import core, synth
+from ptudes_lab_amd import utils as pu
+
+pytestmark = pytest.mark.gpu
+
+
+def _sensor(H):
+    rng = np.random.default_rng(9)
+    alt = np.linspace(44.5, -44.5, H) + rng.normal(0, 0.02, H)
+    az = np.tile([4.2, 1.4, -1.4, -4.2], H // 4) + rng.normal(0, 0.01, H)
+    l2s = np.eye(4)
+    l2s[:3, :3] = np.diag([-1.0, -1.0, 1.0])  # ouster lidar->sensor is a 180 deg yaw
+    l2s[:3, 3] = [0.0, 0.0, 36.18]
+    ext = np.eye(4)
+    ext[:3, 3] = [0.014, -0.012, -0.015]
+    return alt, az, 15.806, l2s, ext
+
+
+def test_lut_matches_numpy_restatement():
+    H, W = 128, 1024
+    alt, az, n, l2s, ext = _sensor(H)
+    rng = np.random.default_rng(1)
+    r = rng.integers(0, 60000, H * W).astype(np.uint32)
+    r[rng.random(H * W) < 0.1] = 0
+    for e in (None, ext):
+        lut = core.Lut(H, W, alt, az, n, l2s, e)
+        d, o = olut.xyz_lut(H, W, alt, az, n, l2s, e)
+        ref = olut.apply(d, o, r)
+        got = lut(r)
+        assert np.abs(got - ref).max() < 1e-11
+        assert np.all(got[r == 0] == 0.0)
+
+
+def test_register_range_matches_oracle_pipeline():
+    seq = synth.make_sequence(seed=1003, n_scans=6)
+    H, W = seq.H, seq.W
+    alt = np.linspace(45.0, -45.0, H)
+    az = np.zeros(H)
+    lut = core.Lut(H, W, alt, az, 0.0, np.eye(4), None)
+    d, o = olut.xyz_lut(H, W, alt, az, 0.0, np.eye(4), None)
+    t01 = seq.column_times()
+    icp = core.Icp(70.0, 1.0)
+    ref = orc.ICP(70.0, 1.0)
+    for k in range(5):
+        x = seq.scan(k).reshape(H, W, 3)
+        # ouster column v looks along 2 pi (1 - v / W): the synthetic column (W - v) % W
+        rng_img = np.round(np.linalg.norm(x[:, (W - np.arange(W)) % W, :], axis=2) * 1000.0).astype(np.uint32)
+        T = icp.register_range(lut, rng_img)
+        xyz = olut.apply(d, o, rng_img.reshape(-1))
+        sel = rng_img.reshape(-1) != 0  # reference kiss.py:59-61
+        Tr = ref.register_frame(xyz[sel], t01[sel], None)
+        assert np.abs(T - Tr).max() < 2e-4, k
+        for key in ("n_valid", "n_down", "n_src"):
+            assert icp.stats[-1][key] == ref.stats[-1][key]
+    # reduce_active_beams: 32 of 128 rows
+    icp.set_active_beams(H, 32)
+    rng_img = np.round(np.linalg.norm(seq.scan(5).reshape(H, W, 3)[:, (W - np.arange(W)) % W, :], axis=2) * 1000.0).astype(np.uint32)
+    T = icp.register_range(lut, rng_img)
+    masked = rng_img.copy()
+    pu.reduce_active_beams(masked, 32)
+    xyz = olut.apply(d, o, masked.reshape(-1))
+    sel = masked.reshape(-1) != 0
+    Tr = ref.register_frame(xyz[sel], t01[sel], None)
+    assert icp.stats[-1]["n_valid"] == ref.stats[-1]["n_valid"] <= 32 * W
+    assert np.abs(T - Tr).max() < 2e-4
