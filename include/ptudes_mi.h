@@ -191,6 +191,10 @@ int ptl_seq_create(const ptl_seq_cfg *cfg, ptl_seq **out);
 int ptl_seq_destroy(ptl_seq *s);
 /* host -> HBM: scan k (points_per_scan x 3 float32, row-major beam-outer) */
 int ptl_seq_upload_scan(ptl_seq *s, int64_t k, const float *xyz);
+/* the same sweep as a raw range image (points_per_scan u32, mm, 0 = no return): 1/3 of the bytes; the LUT (and
+ * optionally reduce_active_beams) must be set with ptl_seq_set_lut before the run */
+int ptl_seq_upload_range(ptl_seq *s, int64_t k, const uint32_t *range_mm);
+int ptl_seq_set_lut(ptl_seq *s, ptl_lut *lut, int32_t active_beams);
 /* imu: n_imu x 7 (ts, lacc, avel); imu_end[k] = number of IMU samples that precede scan k in the event stream */
 int ptl_seq_upload_imu(ptl_seq *s, const double *imu, const int64_t *imu_end);
 /* cold-start the filters/map and run scans [0, n) (n <= n_scans); returns after the stream has drained */

@@ -89,6 +89,8 @@ PROTOTYPES = {
     "ptl_seq_create": (C.c_int, [C.POINTER(SeqCfg), _vpp]),
     "ptl_seq_destroy": (C.c_int, [_vp]),
     "ptl_seq_upload_scan": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_float)]),
+    "ptl_seq_upload_range": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_uint32)]),
+    "ptl_seq_set_lut": (C.c_int, [_vp, _vp, C.c_int32]),
     "ptl_seq_upload_imu": (C.c_int, [_vp, c_d_p, c_i64_p]),
     "ptl_seq_run": (C.c_int, [_vp, C.c_int64]),
     "ptl_seq_advance": (C.c_int, [_vp, C.c_int64]),

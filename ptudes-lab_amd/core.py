@@ -266,6 +266,16 @@ class SeqRunner:
             raise ValueError("scan size mismatch")
         L.check(L.lib().ptl_seq_upload_scan(self._h, k, x.ctypes.data_as(C.POINTER(C.c_float))))
 
+    def upload_range(self, k, range_mm):
+        r = np.ascontiguousarray(range_mm, dtype=np.uint32).reshape(-1)
+        if r.size != self.cfg.points_per_scan:
+            raise ValueError("range image size mismatch")
+        L.check(L.lib().ptl_seq_upload_range(self._h, k, r.ctypes.data_as(C.POINTER(C.c_uint32))))
+
+    def set_lut(self, lut, active_beams=0):
+        self._lut = lut  # keep alive
+        L.check(L.lib().ptl_seq_set_lut(self._h, lut._h, int(active_beams)))
+
     def upload_imu(self, imu_rows, imu_end):
         r = L.as_f64(imu_rows).reshape(-1, 7) if len(imu_rows) else np.zeros((0, 7))
         e = np.ascontiguousarray(imu_end, dtype=np.int64)

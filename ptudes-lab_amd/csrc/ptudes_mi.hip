@@ -725,6 +725,8 @@ struct ptl_seq {
     std::vector<int64_t> scan_of_out;  // scan index of each processed output
     int64_t n_out;
     int64_t next_scan, imu_pos, imus_per_scan;  // driver-loop position (ekf_bench.py:491-518)
+    ptl_lut* lut;                    // non-null => sweeps were uploaded as u32 range images
+    std::vector<unsigned char> is_range;
 };
 
 extern "C" int ptl_seq_destroy(ptl_seq* s) {
@@ -766,6 +768,8 @@ extern "C" int ptl_seq_create(const ptl_seq_cfg* cfg, ptl_seq** out) {
         rc = set_err(PTL_ERR_HIP, "sequence allocation failed (%.1f MB of scans)", cfg->n_scans * cfg->points_per_scan * 12 / 1e6);
     if (rc) { ptl_seq_destroy(s); return rc; }
     s->imu_end.assign((size_t)cfg->n_scans, 0);
+    s->is_range.assign((size_t)cfg->n_scans, 0);
+    s->lut = nullptr;
     *out = s;
     return PTL_OK;
 }
@@ -775,6 +779,21 @@ extern "C" int ptl_seq_upload_scan(ptl_seq* s, int64_t k, const float* xyz) {
     const size_t bytes = (size_t)s->cfg.points_per_scan * 12;
     HIPCHK(hipMemcpy((char*)s->d_scans + (size_t)k * bytes, xyz, bytes, hipMemcpyHostToDevice));
     return PTL_OK;
+}
+// sweep k as a raw range image (H*W u32 mm); needs ptl_seq_set_lut before running
+extern "C" int ptl_seq_upload_range(ptl_seq* s, int64_t k, const uint32_t* range_mm) {
+    if (!s || !range_mm || k < 0 || k >= s->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(s->cfg.icp.device_id));
+    const size_t slot = (size_t)s->cfg.points_per_scan * 12;
+    HIPCHK(hipMemcpy((char*)s->d_scans + (size_t)k * slot, range_mm, (size_t)s->cfg.points_per_scan * 4, hipMemcpyHostToDevice));
+    s->is_range[(size_t)k] = 1;
+    return PTL_OK;
+}
+extern "C" int ptl_seq_set_lut(ptl_seq* s, ptl_lut* lut, int32_t active_beams) {
+    if (!s || !lut) return set_err(PTL_ERR_ARG, "null argument");
+    if ((int64_t)lut->H * lut->W != s->cfg.points_per_scan) return set_err(PTL_ERR_ARG, "LUT size does not match points_per_scan");
+    s->lut = lut;
+    return ptl_icp_set_active_beams(s->icp, lut->H, active_beams);
 }
 extern "C" int ptl_seq_upload_imu(ptl_seq* s, const double* imu, const int64_t* imu_end) {
     if (!s || !imu_end || (!imu && s->cfg.n_imu > 0)) return set_err(PTL_ERR_ARG, "bad argument");
@@ -820,7 +839,14 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
         s->next_scan = k + 1;
         if (with_ekf && !s->imus_per_scan) continue;  // ekf_bench.py:512-518
         s->imus_per_scan = 0;
-        int rc = icp_enqueue_scan(s->icp, s->d_scans + (size_t)k * pps * 3, nullptr, nullptr, (int64_t)pps, guess_ptr);
+        int rc;
+        if (s->is_range[(size_t)k]) {
+            if (!s->lut) return set_err(PTL_ERR_STATE, "scan %lld is a range image but no LUT was set", (long long)k);
+            rc = icp_enqueue_scan(s->icp, nullptr, nullptr, nullptr, (int64_t)pps, guess_ptr,
+                                  (const unsigned*)(s->d_scans + (size_t)k * pps * 3), s->lut);
+        } else {
+            rc = icp_enqueue_scan(s->icp, s->d_scans + (size_t)k * pps * 3, nullptr, nullptr, (int64_t)pps, guess_ptr);
+        }
         if (rc) return rc;
         const int64_t o = s->n_out;
         const double* kiss_pose = s->icp->c.traj + 16 * (s->icp->scans_done - 1);

@@ -45,6 +45,15 @@ class KissICPWrapper:
             self._xyz_lut = client.XYZLut(metadata, use_extrinsics=_use_extrinsics)
         except Exception:
             pass
+        # device LUT when the metadata carries the beam geometry (SensorInfo field names); then a scan that only
+        # has a `.range` image is converted and masked on the GPU
+        self._dev_lut = None
+        if self._xyz_lut is None and hasattr(metadata, "beam_altitude_angles"):
+            l2s = np.array(getattr(metadata, "lidar_to_sensor_transform", np.eye(4)), dtype=np.float64)
+            ext = np.array(metadata.extrinsic, dtype=np.float64) if (_use_extrinsics and hasattr(metadata, "extrinsic")) else None
+            self._dev_lut = core.Lut(h, w, metadata.beam_altitude_angles, metadata.beam_azimuth_angles,
+                                     getattr(metadata, "lidar_origin_to_beam_origin_mm", 0.0), l2s, ext,
+                                     device_id=device_id)
         # per-pixel normalised time, reference kiss.py:34-35
         self._timestamps = np.tile(np.linspace(0, 1.0, w, endpoint=False), (h, 1))
         self._max_range, self._min_range = _max_range, _min_range
@@ -65,6 +74,11 @@ class KissICPWrapper:
     # ------------------------------------------------------------------ registration
     def register_frame(self, scan, initial_guess: Optional[np.ndarray] = None) -> np.ndarray:
         """reference kiss.py:54-74"""
+        if self._dev_lut is not None and hasattr(scan, "range") and not hasattr(scan, "xyz"):
+            ts = float(getattr(scan, "ts", 0.0))
+            pose = self._icp.register_range(self._dev_lut, scan.range, initial_guess, ts)
+            self._log_pose(pose, ts)
+            return self.pose
         xyz, t, ts = self._scan_arrays(scan)
         self.register_points(xyz, t, ts, initial_guess=initial_guess)
         return self.pose
@@ -72,13 +86,16 @@ class KissICPWrapper:
     def register_points(self, frame, timestamps, ts: float = 0.0, initial_guess: Optional[np.ndarray] = None):
         """reference kiss.py:83-131 on (N, 3) points + per-point normalised times (None => column-implicit)"""
         pose = self._icp.register_frame(frame, timestamps, initial_guess, ts)
-        st = self._icp.stats[-1]
+        self._log_pose(pose, ts)
+        return pose
+
+    def _log_pose(self, pose, ts):
+        st = self._icp.stats[-1]  # reference kiss.py:116-124, :130, :72
         self._err_dt.append(st["err_dt"])
         self._err_drot.append(st["err_drot"])
         self._sigmas.append(st["sigma"])
         self._kiss.poses.append(pose)
         self._poses_ts.append(ts)
-        return pose
 
     def _scan_arrays(self, scan):
         if self._xyz_lut is not None and hasattr(scan, "field"):

@@ -71,3 +71,31 @@ def test_register_range_matches_oracle_pipeline():
     Tr = ref.register_frame(xyz[sel], t01[sel], None)
     assert icp.stats[-1]["n_valid"] == ref.stats[-1]["n_valid"] <= 32 * W
     assert np.abs(T - Tr).max() < 2e-4
+
+
+def test_wrapper_and_runner_take_range_images():
+    """KissICPWrapper with beam geometry in the metadata and SeqRunner.upload_range == the xyz path"""
+    from types import SimpleNamespace
+    from ptudes_lab_amd.kiss import KissICPWrapper
+    seq = synth.make_sequence(seed=1004, n_scans=5)
+    H, W = seq.H, seq.W
+    alt, az = np.linspace(45.0, -45.0, H), np.zeros(H)
+    meta = SimpleNamespace(format=SimpleNamespace(columns_per_frame=W, pixels_per_column=H), beam_altitude_angles=alt,
+                           beam_azimuth_angles=az, lidar_origin_to_beam_origin_mm=0.0,
+                           lidar_to_sensor_transform=np.eye(4))
+    w = KissICPWrapper(meta, _min_range=1.0, _max_range=70.0)
+    r = core.SeqRunner(5, H * W, 0, max_range=70.0, min_range=1.0, with_ekf=False)
+    r.set_lut(core.Lut(H, W, alt, az))
+    imgs = []
+    for k in range(5):
+        x = seq.scan(k).reshape(H, W, 3)
+        img = np.round(np.linalg.norm(x[:, (W - np.arange(W)) % W, :], axis=2) * 1000.0).astype(np.uint32)
+        imgs.append(img)
+        r.upload_range(k, img)
+    r.upload_imu(np.zeros((0, 7)), [0] * 5)
+    r.run()
+    res = r.results()["kiss_poses"]
+    for k in range(5):
+        T = w.register_frame(SimpleNamespace(range=imgs[k], ts=float(k)))
+        assert np.array_equal(T, res[k])
+    assert len(w._sigmas) == 5
