@@ -217,6 +217,27 @@ int ptl_seq_copy_traj(ptl_seq *s, void *dst_device, int64_t max_rows, int64_t *r
 int ptl_seq_icp(ptl_seq *s, ptl_icp **icp);
 int ptl_seq_profile(ptl_seq *s, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
 
+/* ------------------------------------------------------------------------------------------------
+ * Batched runner: up to 8 independent sequences on ONE GPU advanced in lockstep.  Every stage is one launch for
+ * all sequences and their Gauss-Newton loops share one persistent launch (one grid barrier per iteration for all
+ * of them); each sequence's results are bit-identical to running it alone.  cfg describes every sequence
+ * (same n_scans / points_per_scan / n_imu); with_ekf requires >= 1 IMU sample between consecutive scans.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ptl_batch ptl_batch;
+int ptl_batch_create(const ptl_seq_cfg *cfg, int32_t n_sequences, ptl_batch **out);
+int ptl_batch_destroy(ptl_batch *b);
+int ptl_batch_upload_scan(ptl_batch *b, int32_t seq, int64_t k, const float *xyz);
+int ptl_batch_set_lut(ptl_batch *b, ptl_lut *lut, int32_t active_beams);
+int ptl_batch_upload_range(ptl_batch *b, int32_t seq, int64_t k, const uint32_t *range_mm);
+int ptl_batch_upload_imu(ptl_batch *b, int32_t seq, const double *imu, const int64_t *imu_end);
+int ptl_batch_run(ptl_batch *b, int64_t n);     /* cold start + scans [0, n), waits */
+int ptl_batch_enqueue(ptl_batch *b, int64_t n); /* next n scans, does not wait */
+int ptl_batch_wait(ptl_batch *b);
+int ptl_batch_results(ptl_batch *b, int32_t seq, double *res_poses, double *res_t, double *kiss_poses,
+                      ptl_icp_stats *stats, int64_t max_n, int64_t *n_out);
+int ptl_batch_copy_traj(ptl_batch *b, int32_t seq, void *dst_device, int64_t max_rows, int64_t *rows);
+int ptl_batch_profile(ptl_batch *b, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
+
 #ifdef __cplusplus
 }
 #endif

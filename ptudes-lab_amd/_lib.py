@@ -102,6 +102,18 @@ PROTOTYPES = {
     "ptl_seq_traj_device": (C.c_int, [_vp, _vpp, c_i64_p]),
     "ptl_seq_icp": (C.c_int, [_vp, _vpp]),
     "ptl_seq_profile": (C.c_int, [_vp, C.c_int, c_d_p, c_i64_p, C.c_int]),
+    "ptl_batch_create": (C.c_int, [C.POINTER(SeqCfg), C.c_int32, _vpp]),
+    "ptl_batch_destroy": (C.c_int, [_vp]),
+    "ptl_batch_upload_scan": (C.c_int, [_vp, C.c_int32, C.c_int64, C.POINTER(C.c_float)]),
+    "ptl_batch_set_lut": (C.c_int, [_vp, _vp, C.c_int32]),
+    "ptl_batch_upload_range": (C.c_int, [_vp, C.c_int32, C.c_int64, C.POINTER(C.c_uint32)]),
+    "ptl_batch_upload_imu": (C.c_int, [_vp, C.c_int32, c_d_p, c_i64_p]),
+    "ptl_batch_run": (C.c_int, [_vp, C.c_int64]),
+    "ptl_batch_enqueue": (C.c_int, [_vp, C.c_int64]),
+    "ptl_batch_wait": (C.c_int, [_vp]),
+    "ptl_batch_results": (C.c_int, [_vp, C.c_int32, c_d_p, c_d_p, c_d_p, C.POINTER(IcpStats), C.c_int64, c_i64_p]),
+    "ptl_batch_copy_traj": (C.c_int, [_vp, C.c_int32, _vp, C.c_int64, c_i64_p]),
+    "ptl_batch_profile": (C.c_int, [_vp, C.c_int, c_d_p, c_i64_p, C.c_int]),
 }
 
 _lib = None

@@ -322,3 +322,80 @@ class SeqRunner:
         ms, n = C.c_double(), C.c_int64()
         L.check(L.lib().ptl_seq_profile(self._h, int(enable), C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
+
+
+class BatchRunner:
+    """Up to 8 independent sequences on one GPU in lockstep (one launch per stage for all of them, one shared
+    persistent Gauss-Newton launch).  Per-sequence results are bit-identical to `SeqRunner`."""
+
+    def __init__(self, n_sequences, n_scans, points_per_scan, n_imu, *, max_range=70.0, min_range=1.0,
+                 use_imu_prediction=False, with_ekf=True, device_id=0, ekf=None, **icp_over):
+        cfg = L.SeqCfg()
+        cfg.icp = icp_cfg(max_range, min_range, device_id=device_id, **icp_over)
+        cfg.ekf = ekf if ekf is not None else ekf_cfg(device_id=device_id)
+        cfg.n_scans, cfg.points_per_scan, cfg.n_imu = n_scans, points_per_scan, n_imu
+        cfg.use_imu_prediction = int(bool(use_imu_prediction))
+        cfg.with_ekf = int(bool(with_ekf))
+        self.cfg, self.S, self.n_scans = cfg, int(n_sequences), n_scans
+        self._h = C.c_void_p()
+        L.check(L.lib().ptl_batch_create(C.byref(cfg), self.S, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().ptl_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def upload_scan(self, s, k, xyz_f32):
+        x = np.ascontiguousarray(xyz_f32, dtype=np.float32)
+        if x.size != self.cfg.points_per_scan * 3:
+            raise ValueError("scan size mismatch")
+        L.check(L.lib().ptl_batch_upload_scan(self._h, s, k, x.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def set_lut(self, lut, active_beams=0):
+        self._lut = lut
+        L.check(L.lib().ptl_batch_set_lut(self._h, lut._h, int(active_beams)))
+
+    def upload_range(self, s, k, range_mm):
+        r = np.ascontiguousarray(range_mm, dtype=np.uint32).reshape(-1)
+        L.check(L.lib().ptl_batch_upload_range(self._h, s, k, r.ctypes.data_as(C.POINTER(C.c_uint32))))
+
+    def upload_imu(self, s, imu_rows, imu_end):
+        r = L.as_f64(imu_rows).reshape(-1, 7) if len(imu_rows) else np.zeros((0, 7))
+        e = np.ascontiguousarray(imu_end, dtype=np.int64)
+        if len(e) != self.n_scans:
+            raise ValueError("imu_end needs one entry per scan")
+        L.check(L.lib().ptl_batch_upload_imu(self._h, s, L.dptr(r) if len(r) else None, e.ctypes.data_as(L.c_i64_p)))
+
+    def run(self, n=None):
+        L.check(L.lib().ptl_batch_run(self._h, self.n_scans if n is None else n))
+
+    def enqueue(self, n):
+        L.check(L.lib().ptl_batch_enqueue(self._h, n))
+
+    def wait(self):
+        L.check(L.lib().ptl_batch_wait(self._h))
+
+    def results(self, s):
+        n = self.n_scans
+        res_poses, res_t, kiss = np.empty((n, 4, 4)), np.empty(n), np.empty((n, 4, 4))
+        stats = (L.IcpStats * n)()
+        w = C.c_int64()
+        L.check(L.lib().ptl_batch_results(self._h, s, L.dptr(res_poses), L.dptr(res_t), L.dptr(kiss), stats, n,
+                                          C.byref(w)))
+        m = w.value
+        out = dict(kiss_poses=kiss[:m], stats=[stats[i].as_dict() for i in range(m)])
+        if self.cfg.with_ekf:
+            out.update(res_poses=res_poses[:m], res_t=res_t[:m])
+        return out
+
+    def copy_traj(self, s, dst_device_ptr, max_rows):
+        rows = C.c_int64()
+        L.check(L.lib().ptl_batch_copy_traj(self._h, s, C.c_void_p(dst_device_ptr), max_rows, C.byref(rows)))
+        return rows.value
+
+    def profile(self, enable=True, reset=False):
+        ms, n = C.c_double(), C.c_int64()
+        L.check(L.lib().ptl_batch_profile(self._h, int(enable), C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value

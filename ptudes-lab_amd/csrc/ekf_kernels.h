@@ -105,9 +105,9 @@ __device__ __forceinline__ unsigned ekf_row_mask(int i) {
     return 1u << i;
 }
 
-__global__ __launch_bounds__(384) void k_ekf_step(EkfState* e, const double* imu, int i0, int i1, const double* pose,
-                                                  const double* meas_cov, double* out_pose, double* out_t,
-                                                  double* out_row8, int update_first) {
+__device__ __forceinline__ void d_ekf_step(EkfState* e, const double* imu, int i0, int i1, const double* pose,
+                                           const double* meas_cov, double* out_pose, double* out_t,
+                                           double* out_row8, int update_first) {
     __shared__ double sP[EKF_N * EKF_N], sF[EKF_N * EKF_N], sW[EKF_N * EKF_N], sT[EKF_N * EKF_N];
     __shared__ double sK[EKF_N * 6], sSi[36], sr[6], sdx[EKF_N];
     __shared__ int active;
@@ -305,4 +305,26 @@ __global__ __launch_bounds__(384) void k_ekf_step(EkfState* e, const double* imu
     }
     if (cell) { e->P[tid] = sP[tid]; e->Fx[tid] = sF[tid]; e->W[tid] = sW[tid]; }
     if (tid == 0) { e->nav = nv; ekf_write_pose(e); }
+}
+
+__global__ __launch_bounds__(384) void k_ekf_step(EkfState* e, const double* imu, int i0, int i1, const double* pose,
+                                                  const double* meas_cov, double* out_pose, double* out_t,
+                                                  double* out_row8, int update_first) {
+    d_ekf_step(e, imu, i0, i1, pose, meas_cov, out_pose, out_t, out_row8, update_first);
+}
+// S filters in one launch (blockIdx.x = sequence)
+#define EKF_MAX_SEQ 8
+struct EkfBatchArgs {
+    EkfState* e[EKF_MAX_SEQ];
+    const double* imu[EKF_MAX_SEQ];
+    int i0[EKF_MAX_SEQ], i1[EKF_MAX_SEQ];
+    const double* pose[EKF_MAX_SEQ];
+    double* out_pose[EKF_MAX_SEQ];
+    double* out_t[EKF_MAX_SEQ];
+    double* out_row8[EKF_MAX_SEQ];
+    int update_first;
+};
+__global__ __launch_bounds__(384) void kb_ekf_step(EkfBatchArgs a) {
+    const int s = blockIdx.x;
+    d_ekf_step(a.e[s], a.imu[s], a.i0[s], a.i1[s], a.pose[s], nullptr, a.out_pose[s], a.out_t[s], a.out_row8[s], a.update_first);
 }

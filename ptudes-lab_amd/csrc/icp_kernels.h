@@ -176,7 +176,7 @@ __global__ void k_finish_scan(Ctx c) {
     finish_pending(c, c.st);
 }
 
-__global__ __launch_bounds__(1024) void k_scan_prologue(Ctx c) {
+__device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
     DevState* st = c.st;
     if (threadIdx.x == 0) {
     finish_pending(c, st);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_build_lut(int H, int W, const double* a
 }
 
 // ------------------------------------------------------------------------------------------------ K1
-__global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) {
+__device__ __forceinline__ void d_deskew_vds1(const Ctx& c) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     DevState* st = c.st;
     bool valid = false;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) {
 }
 
 // ------------------------------------------------------------------------------------------------ K2
-__global__ __launch_bounds__(256) void k_vds2(Ctx c) {
+__device__ __forceinline__ void d_vds2(const Ctx& c) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool w1 = false;
     if (i < c.n_in) {
@@ -370,7 +370,7 @@ __device__ __forceinline__ int block_rank(bool flag, int* red, int& total) {
 }
 
 // ------------------------------------------------------------------------------------------------ K3
-__global__ __launch_bounds__(256) void k_compact_fd(Ctx c) {
+__device__ __forceinline__ void d_compact_fd(const Ctx& c) {
     __shared__ int red[8];
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool w1 = false, w2 = false;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void k_compact_fd(Ctx c) {
 }
 
 // ------------------------------------------------------------------------------------------------ K4
-__global__ __launch_bounds__(256) void k_compact_src(Ctx c) {
+__device__ __forceinline__ void d_compact_src(const Ctx& c) {
     __shared__ int red[8];
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool w2 = false;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
 // ------------------------------------------------------------------------------------------------ K7-K9
 // AddPoints, phase a: world transform, find-or-create the voxel's table entry, join its batch list.
 // `pose` null => points are already in the world frame (stage-level API)
-__global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_in, const int* n_ptr, int n_fixed,
+__device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_in, const int* n_ptr, int n_fixed,
                                                       int use_pose) {
     const int n = n_ptr ? *n_ptr : n_fixed;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_i
     c.nxt[i] = (slot >= 0) ? atomicExch(&c.tab[slot].head, i) : -1;
 }
 // phase b: rank among this batch's points of the same voxel (by scan order) -> slot in the block
-__global__ __launch_bounds__(256) void k_map_insert_b(Ctx c, const int* n_ptr, int n_fixed) {
+__device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, int n_fixed) {
     const int n = n_ptr ? *n_ptr : n_fixed;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) void k_map_insert_b(Ctx c, const int* n_ptr, i
     }
 }
 // phase c: publish the new counts, reset the batch lists
-__global__ __launch_bounds__(256) void k_map_insert_c(Ctx c, const int* n_ptr, int n_fixed) {
+__device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, int n_fixed) {
     const int n = n_ptr ? *n_ptr : n_fixed;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256) void k_map_insert_c(Ctx c, const int* n_ptr, i
 
 // ------------------------------------------------------------------------------------------------ K10
 // RemovePointsFarFromLocation: a voxel goes when its FIRST point is farther than max_range from the origin
-__global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_xyz, int use_new_pose) {
+__device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_xyz, int use_new_pose) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     DevState* st = c.st;
     if (b >= st->pool_hw) return;  // block ids are handed out low-first: nothing lives above the high-water mark
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_x
 
 // ------------------------------------------------------------------------------------------------ K11
 // after the table has been reset to EMPTY: re-enter every live voxel
-__global__ __launch_bounds__(256) void k_map_rebuild(Ctx c) {
+__device__ __forceinline__ void d_map_rebuild(const Ctx& c) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= c.st->pool_hw) return;
     int* h = blk_hdr(c, b);
@@ -894,5 +894,239 @@ __global__ __launch_bounds__(256) void k_map_export(Ctx c, double* out, int* cou
     for (int j = 0; j < cnt; ++j) {
         if (o + j >= max_points) break;
         out[3 * (size_t)(o + j)] = X[j]; out[3 * (size_t)(o + j) + 1] = X[c.P + j]; out[3 * (size_t)(o + j) + 2] = X[2 * c.P + j];
+    }
+}
+
+// ================================================================================================ launch wrappers
+// Every stage exists as a device function d_*(ctx, ...); k_* runs it for one sequence (context by value), kb_* runs
+// it for S sequences in one launch (blockIdx.y = sequence, contexts in device memory): the batched driver
+// amortises every launch and, in the Gauss-Newton loop, every grid barrier over S scans.
+struct SeqCtx {
+    Ctx c;
+    const float* scan_base;        // sweeps of this sequence, resident in HBM
+    long long scan_stride_floats;  // floats between consecutive sweeps
+    int input_is_range, pad;
+};
+__device__ __forceinline__ Ctx load_seq_ctx(const SeqCtx* a, int s, int scan_k) {
+    Ctx c = a[s].c;
+    const float* p = a[s].scan_base + (size_t)scan_k * (size_t)a[s].scan_stride_floats;
+    if (a[s].input_is_range) { c.in_range = (const unsigned*)p; c.in_f32 = nullptr; }
+    else { c.in_f32 = p; c.in_range = nullptr; }
+    return c;
+}
+__global__ __launch_bounds__(1024) void k_scan_prologue(Ctx c) { d_scan_prologue(c); }
+__global__ __launch_bounds__(1024) void kb_scan_prologue(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_scan_prologue(c);
+}
+__global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) { d_deskew_vds1(c); }
+__global__ __launch_bounds__(256) void kb_deskew_vds1(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_deskew_vds1(c);
+}
+__global__ __launch_bounds__(256) void k_vds2(Ctx c) { d_vds2(c); }
+__global__ __launch_bounds__(256) void kb_vds2(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_vds2(c);
+}
+__global__ __launch_bounds__(256) void k_compact_fd(Ctx c) { d_compact_fd(c); }
+__global__ __launch_bounds__(256) void kb_compact_fd(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_compact_fd(c);
+}
+__global__ __launch_bounds__(256) void k_compact_src(Ctx c) { d_compact_src(c); }
+__global__ __launch_bounds__(256) void kb_compact_src(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_compact_src(c);
+}
+__global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_in, const int* n_ptr, int n_fixed, int use_pose) { d_map_insert_a(c, pts_in, n_ptr, n_fixed, use_pose); }
+__global__ __launch_bounds__(256) void kb_map_insert_a(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_map_insert_a(c, c.fd, &c.st->n_down, 0, 1);
+}
+__global__ __launch_bounds__(256) void k_map_insert_b(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_b(c, n_ptr, n_fixed); }
+__global__ __launch_bounds__(256) void kb_map_insert_b(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_map_insert_b(c, &c.st->n_down, 0);
+}
+__global__ __launch_bounds__(256) void k_map_insert_c(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_c(c, n_ptr, n_fixed); }
+__global__ __launch_bounds__(256) void kb_map_insert_c(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_map_insert_c(c, &c.st->n_down, 0);
+}
+__global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_xyz, int use_new_pose) { d_map_prune(c, origin_xyz, use_new_pose); }
+__global__ __launch_bounds__(256) void kb_map_prune(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_map_prune(c, nullptr, 1);
+}
+__global__ __launch_bounds__(256) void k_map_rebuild(Ctx c) { d_map_rebuild(c); }
+__global__ __launch_bounds__(256) void kb_map_rebuild(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_map_rebuild(c);
+}
+
+// ------------------------------------------------------------------------------------------------ batched K5
+// The Gauss-Newton loops of S scans (one per sequence) in ONE persistent launch: every iteration runs the
+// nearest-neighbour + accumulation pass of every still-active sequence, then ONE grid barrier, then S small
+// reductions and S 6x6 solves (thread 64*s solves sequence s).  Point -> workgroup assignment, reduction trees
+// and arithmetic per sequence are exactly those of k_gn_loop, so each sequence's result is bit-identical to
+// running it alone with the same (G, threads); only the synchronisation is shared.
+#define GN_MAX_SEQ 8
+__global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(const SeqCtx* a, int S, double* partials) {
+    __shared__ double red[GN_MAX_GROUPS][32];
+    __shared__ double red2[4][32];
+    __shared__ double redg[GN_MAX_SEQ > 4 ? 4 : GN_MAX_SEQ][8][32];
+    __shared__ double tot[GN_MAX_SEQ][32];
+    __shared__ double Esh[GN_MAX_SEQ][12];
+    __shared__ double Tsh[GN_MAX_SEQ][12];
+    __shared__ int done_sh[GN_MAX_SEQ];
+    __shared__ int iters_sh[GN_MAX_SEQ];
+    __shared__ long long cand_sh[GN_MAX_SEQ];
+    __shared__ int ncorr_sh[GN_MAX_SEQ];
+    const int tid = threadIdx.x, lane32 = tid & 31, grp = tid >> 5, gbase = (tid & 63) & 32;
+    const int NG = blockDim.x >> 5;
+    const int G = gridDim.x, wg = blockIdx.x;
+    DevState* st0 = a[0].c.st;  // barrier words of sequence 0 serve the whole launch
+    int ia = 0, ib = 0;
+    {
+        int o = 0;
+        for (int p = 0; p < 6; ++p)
+            for (int q = p; q < 6; ++q) { if (o == lane32) { ia = p; ib = q; } ++o; }
+        if (lane32 >= 21) { ia = lane32 - 21; ib = 6; }
+    }
+    if (tid < S * 12) {
+        const int s = tid / 12, k = tid % 12;
+        Rt g = rt_from16(a[s].c.st->guess);
+        Esh[s][k] = (k < 9) ? g.R[k] : g.t[k - 9];
+        Tsh[s][k] = (k < 9) ? ((k % 4 == 0) ? 1.0 : 0.0) : 0.0;
+    }
+    if (tid < S) {
+        done_sh[tid] = (a[tid].c.st->n_live == 0) ? 1 : 0;  // voxel_map.Empty() => return initial_guess
+        iters_sh[tid] = 0; cand_sh[tid] = 0; ncorr_sh[tid] = 0;
+    }
+    __syncthreads();
+    const int max_iter = a[0].c.max_iter;
+    for (int it = 0; it < max_iter; ++it) {
+        bool all_done = true;
+        for (int s = 0; s < S; ++s) all_done = all_done && (done_sh[s] != 0);
+        if (all_done) break;
+        for (int s = 0; s < S; ++s) {
+            if (done_sh[s]) continue;  // uniform over the grid: every workgroup holds the same flags
+            const Ctx& c = a[s].c;
+            DevState* st = c.st;
+            const int n = st->n_src;
+            const double max_dist = st->gn_max_dist, kern = st->gn_kernel, k2 = kern * kern;
+            double acc = 0.0;
+            long long ncand = 0;
+            Rt E;
+            for (int k = 0; k < 9; ++k) E.R[k] = Esh[s][k];
+            for (int k = 0; k < 3; ++k) E.t[k] = Esh[s][9 + k];
+            unsigned long long ckey = EMPTY_KEY;
+            int cblk = -1;
+            for (int i = wg * NG + grp; i < n; i += G * NG) {
+                V3 sp;
+                if (it == 0) sp = rt_apply(E, v3(c.src0[3 * (size_t)i], c.src0[3 * (size_t)i + 1], c.src0[3 * (size_t)i + 2]));
+                else sp = rt_apply(E, v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]));
+                if (lane32 == 0) { c.src_cur[3 * (size_t)i] = sp.x; c.src_cur[3 * (size_t)i + 1] = sp.y; c.src_cur[3 * (size_t)i + 2] = sp.z; }
+                V3 t;
+                double d2;
+                const bool found = nn_search32(c, sp, lane32, gbase, t, d2, ncand, ckey, cblk, false);
+                if (found && sqrt(d2) < max_dist) {
+                    const V3 r = v3(sp.x - t.x, sp.y - t.y, sp.z - t.z);
+                    const double den = kern + (r.x * r.x + r.y * r.y + r.z * r.z);
+                    const double w = k2 / (den * den);
+                    if (lane32 < 27) acc += w * dot(jcol(ia, sp, r), jcol(ib, sp, r));
+                    else if (lane32 == 27) acc += 1.0;
+                }
+            }
+            const long long ncand0 = __shfl(ncand, gbase);
+            red[grp][lane32] = (lane32 == 28) ? (double)ncand0 : acc;
+            __syncthreads();
+            if (tid < 128) {
+                const int col = tid & 31, seg = tid >> 5, per = (NG + 3) >> 2;
+                double v = 0.0;
+                for (int g = seg * per; g < (seg + 1) * per && g < NG; ++g) v += red[g][col];
+                red2[seg][col] = v;
+            }
+            __syncthreads();
+            if (tid < 29) {
+                const double v = ((red2[0][tid] + red2[1][tid]) + red2[2][tid]) + red2[3][tid];
+                double* part = partials + (((size_t)(it & 1) * G + wg) * GN_MAX_SEQ + s) * 32;
+                __hip_atomic_store(&part[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) grid_barrier(st0, G, wg, it);
+        __syncthreads();
+        // grid reduction, four sequences per round with the single-sequence tree (8 strided parts, then 8 -> 1)
+        const int per_round = (int)(blockDim.x >> 8) < 4 ? (int)(blockDim.x >> 8) : 4;  // 256 threads per sequence
+        for (int s0 = 0; s0 < S; s0 += per_round) {
+            const int s = s0 + (tid >> 8);
+            if ((tid >> 8) < per_round && s < S && !done_sh[s]) {
+                const int t8 = tid & 255, col = t8 & 31, part8 = t8 >> 5;
+                double v = 0.0;
+                if (col < 29) {
+                    const double* base = partials + ((size_t)(it & 1) * G * GN_MAX_SEQ + s) * 32 + col;
+                    int w = part8;
+                    for (; w + 56 < G; w += 64) {
+                        double x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            x[u] = __hip_atomic_load(&base[(size_t)(w + 8 * u) * GN_MAX_SEQ * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v += x[u];
+                    }
+                    for (; w < G; w += 8)
+                        v += __hip_atomic_load(&base[(size_t)w * GN_MAX_SEQ * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                redg[tid >> 8][part8][col] = v;
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int sl = tid >> 5, col = tid & 31, s2 = s0 + sl;
+                if (sl < per_round && s2 < S && !done_sh[s2] && col < 29) {
+                    double v = 0.0;
+                    for (int g = 0; g < 8; ++g) v += redg[sl][g][col];
+                    tot[s2][col] = v;
+                }
+            }
+            __syncthreads();
+        }
+        // one solving thread per sequence, in different wavefronts
+        if ((tid & 63) == 0 && (tid >> 6) < S && !done_sh[tid >> 6]) {
+            const int s = tid >> 6;
+            double dx[6];
+            solve6_ldlt(tot[s], dx);
+            Rt e = se3_exp(dx);
+            Rt T;
+            for (int k = 0; k < 9; ++k) T.R[k] = Tsh[s][k];
+            for (int k = 0; k < 3; ++k) T.t[k] = Tsh[s][9 + k];
+            T = rt_mul(e, T);
+            for (int k = 0; k < 9; ++k) { Esh[s][k] = e.R[k]; Tsh[s][k] = T.R[k]; }
+            for (int k = 0; k < 3; ++k) { Esh[s][9 + k] = e.t[k]; Tsh[s][9 + k] = T.t[k]; }
+            double nn = 0.0;
+            for (int k = 0; k < 6; ++k) nn += dx[k] * dx[k];
+            cand_sh[s] += (long long)tot[s][28];
+            ncorr_sh[s] = (int)tot[s][27];
+            iters_sh[s] = it + 1;
+            if (sqrt(nn) < a[s].c.conv) done_sh[s] = 1;
+        }
+        __syncthreads();
+    }
+    if (wg == 0 && (tid & 63) == 0 && (tid >> 6) < S) {
+        const int s = tid >> 6;
+        const Ctx& c = a[s].c;
+        DevState* st = c.st;
+        const bool empty = st->n_live == 0;
+        Rt T;
+        for (int k = 0; k < 9; ++k) T.R[k] = Tsh[s][k];
+        for (int k = 0; k < 3; ++k) T.t[k] = Tsh[s][9 + k];
+        rt_to16(T, st->T_icp);
+        st->gn_iters = iters_sh[s];
+        st->gn_ncorr = ncorr_sh[s];
+        st->gn_cand = cand_sh[s];
+        gn_post(c, st, empty, 1);
     }
 }

@@ -932,3 +932,296 @@ extern "C" int ptl_seq_profile(ptl_seq* s, int enable, double* gn_ms_total, int6
     if (!s) return set_err(PTL_ERR_ARG, "null argument");
     return ptl_icp_profile(s->icp, enable, gn_ms_total, gn_launches, reset);
 }
+
+// ================================================================================================ batched runner
+// S independent sequences on ONE GPU advanced in lockstep: every stage is one launch for all S scans
+// (blockIdx.y = sequence) and the S Gauss-Newton loops share one persistent launch and its grid barrier.
+struct ptl_batch {
+    ptl_seq_cfg cfg;
+    int S;
+    hipStream_t stream;
+    ptl_icp* icp[GN_MAX_SEQ];
+    ptl_ekf* ekf[GN_MAX_SEQ];
+    float* d_scans[GN_MAX_SEQ];
+    double* d_imu[GN_MAX_SEQ];
+    std::vector<int64_t> imu_end[GN_MAX_SEQ];
+    double *d_res_poses[GN_MAX_SEQ], *d_res_t[GN_MAX_SEQ], *d_rows[GN_MAX_SEQ];
+    unsigned char is_range;
+    ptl_lut* lut;
+    SeqCtx* d_ctx;
+    double* d_partials;
+    int64_t next_scan, n_out;
+    int64_t imu_pos[GN_MAX_SEQ];
+    bool ctx_dirty;
+    bool prof;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used;
+    double gn_ms;
+    int64_t gn_launches;
+};
+
+extern "C" int ptl_batch_destroy(ptl_batch* b) {
+    if (!b) return PTL_OK;
+    (void)hipSetDevice(b->cfg.icp.device_id);
+    for (int s = 0; s < b->S; ++s) {
+        if (b->icp[s]) icp_free(b->icp[s]);
+        if (b->ekf[s]) ptl_ekf_destroy(b->ekf[s]);
+        void* ptrs[] = {b->d_scans[s], b->d_imu[s], b->d_res_poses[s], b->d_res_t[s], b->d_rows[s]};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    if (b->d_ctx) (void)hipFree(b->d_ctx);
+    if (b->d_partials) (void)hipFree(b->d_partials);
+    for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+    return PTL_OK;
+}
+extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl_batch** out) {
+    if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
+    if (n_sequences < 1 || n_sequences > GN_MAX_SEQ) return set_err(PTL_ERR_ARG, "n_sequences must be in [1, %d]", GN_MAX_SEQ);
+    if (cfg->n_scans < 1 || cfg->points_per_scan < 1) return set_err(PTL_ERR_ARG, "empty sequence");
+    if (ptl_device_count() <= cfg->icp.device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->icp.device_id);
+    HIPCHK(hipSetDevice(cfg->icp.device_id));
+    ptl_batch* b = new ptl_batch();
+    b->cfg = *cfg;
+    b->S = n_sequences;
+    b->stream = nullptr; b->d_ctx = nullptr; b->d_partials = nullptr; b->lut = nullptr; b->is_range = 0;
+    b->next_scan = 0; b->n_out = 0; b->ctx_dirty = true; b->prof = false; b->ev_used = 0; b->gn_ms = 0; b->gn_launches = 0;
+    for (int s = 0; s < GN_MAX_SEQ; ++s) {
+        b->icp[s] = nullptr; b->ekf[s] = nullptr; b->d_scans[s] = nullptr; b->d_imu[s] = nullptr;
+        b->d_res_poses[s] = nullptr; b->d_res_t[s] = nullptr; b->d_rows[s] = nullptr; b->imu_pos[s] = 0;
+    }
+    int rc = PTL_OK;
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { delete b; return set_err(PTL_ERR_HIP, "stream"); }
+    ptl_icp_cfg ic = cfg->icp;
+    if (ic.max_points_per_scan < cfg->points_per_scan) ic.max_points_per_scan = cfg->points_per_scan;
+    b->cfg.icp = ic;
+    ptl_ekf_cfg ec = cfg->ekf;
+    ec.device_id = ic.device_id;
+    const size_t nim = cfg->n_imu > 0 ? (size_t)cfg->n_imu : 1;
+    for (int s = 0; s < b->S && rc == PTL_OK; ++s) {
+        rc = icp_create_impl(&ic, b->stream, &b->icp[s]);
+        if (rc == PTL_OK) rc = ekf_create_impl(&ec, b->stream, &b->ekf[s]);
+        while (rc == PTL_OK && b->icp[s]->traj_cap < cfg->n_scans) rc = icp_grow_traj(b->icp[s]);
+        if (rc == PTL_OK &&
+            (hipMalloc((void**)&b->d_scans[s], (size_t)cfg->n_scans * cfg->points_per_scan * 12) != hipSuccess ||
+             dalloc(&b->d_imu[s], nim * 7) != hipSuccess || dalloc(&b->d_res_poses[s], (size_t)cfg->n_scans * 16) != hipSuccess ||
+             dalloc(&b->d_res_t[s], (size_t)cfg->n_scans) != hipSuccess || dalloc(&b->d_rows[s], (size_t)cfg->n_scans * 8) != hipSuccess))
+            rc = set_err(PTL_ERR_HIP, "batch allocation failed");
+        b->imu_end[s].assign((size_t)cfg->n_scans, 0);
+    }
+    if (rc == PTL_OK && (dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess ||
+                         dalloc(&b->d_partials, (size_t)2 * ic.gn_workgroups * GN_MAX_SEQ * 32) != hipSuccess))
+        rc = set_err(PTL_ERR_HIP, "batch allocation failed");
+    if (rc) { ptl_batch_destroy(b); return rc; }
+    *out = b;
+    return PTL_OK;
+}
+extern "C" int ptl_batch_upload_scan(ptl_batch* b, int32_t s, int64_t k, const float* xyz) {
+    if (!b || !xyz || s < 0 || s >= b->S || k < 0 || k >= b->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
+    if (b->is_range) return set_err(PTL_ERR_STATE, "this batch holds range images");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    const size_t bytes = (size_t)b->cfg.points_per_scan * 12;
+    HIPCHK(hipMemcpy((char*)b->d_scans[s] + (size_t)k * bytes, xyz, bytes, hipMemcpyHostToDevice));
+    return PTL_OK;
+}
+extern "C" int ptl_batch_upload_range(ptl_batch* b, int32_t s, int64_t k, const uint32_t* range_mm) {
+    if (!b || !range_mm || s < 0 || s >= b->S || k < 0 || k >= b->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
+    if (!b->lut) return set_err(PTL_ERR_STATE, "set the LUT first (ptl_batch_set_lut)");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    const size_t slot = (size_t)b->cfg.points_per_scan * 12;
+    HIPCHK(hipMemcpy((char*)b->d_scans[s] + (size_t)k * slot, range_mm, (size_t)b->cfg.points_per_scan * 4, hipMemcpyHostToDevice));
+    return PTL_OK;
+}
+extern "C" int ptl_batch_set_lut(ptl_batch* b, ptl_lut* lut, int32_t active_beams) {
+    if (!b || !lut) return set_err(PTL_ERR_ARG, "null argument");
+    if ((int64_t)lut->H * lut->W != b->cfg.points_per_scan || lut->W != b->cfg.icp.scan_cols) return set_err(PTL_ERR_ARG, "LUT size does not match the batch");
+    b->lut = lut;
+    b->is_range = 1;
+    b->ctx_dirty = true;
+    for (int s = 0; s < b->S; ++s) { int rc = ptl_icp_set_active_beams(b->icp[s], lut->H, active_beams); if (rc) return rc; }
+    return PTL_OK;
+}
+extern "C" int ptl_batch_upload_imu(ptl_batch* b, int32_t s, const double* imu, const int64_t* imu_end) {
+    if (!b || !imu_end || s < 0 || s >= b->S || (!imu && b->cfg.n_imu > 0)) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    if (b->cfg.n_imu > 0) HIPCHK(hipMemcpy(b->d_imu[s], imu, (size_t)b->cfg.n_imu * 56, hipMemcpyHostToDevice));
+    for (int64_t k = 0; k < b->cfg.n_scans; ++k) {
+        if (imu_end[k] < 0 || imu_end[k] > b->cfg.n_imu || (k && imu_end[k] < imu_end[k - 1])) return set_err(PTL_ERR_ARG, "imu_end must be non-decreasing within [0, n_imu]");
+        // lockstep batching cannot skip a scan of one sequence only (ekf_bench.py:512-518): demand >= 1 IMU per scan
+        if (b->cfg.with_ekf && k && imu_end[k] == imu_end[k - 1]) return set_err(PTL_ERR_ARG, "batched runs need at least one IMU sample between consecutive scans (scan %lld)", (long long)k);
+        b->imu_end[s][(size_t)k] = imu_end[k];
+    }
+    return PTL_OK;
+}
+static int batch_push_ctx(ptl_batch* b) {
+    SeqCtx h[GN_MAX_SEQ];
+    memset(h, 0, sizeof h);
+    const bool with_ekf = b->cfg.with_ekf != 0;
+    for (int s = 0; s < b->S; ++s) {
+        Ctx c = b->icp[s]->c;
+        c.in_f32 = nullptr; c.in_f64 = nullptr; c.in_range = nullptr; c.t01 = nullptr;
+        c.n_in = (int)b->cfg.points_per_scan;
+        c.ext_guess = (with_ekf && b->cfg.use_imu_prediction) ? (const double*)((char*)b->ekf[s]->st + offsetof(EkfState, pose)) : nullptr;
+        if (b->is_range) { c.lut_dir = b->lut->dir; c.lut_off = b->lut->off; c.row_mask = b->icp[s]->d_row_mask; }
+        h[s].c = c;
+        h[s].scan_base = b->d_scans[s];
+        h[s].scan_stride_floats = (long long)b->cfg.points_per_scan * 3;
+        h[s].input_is_range = b->is_range;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_ctx, h, sizeof h, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->ctx_dirty = false;
+    return PTL_OK;
+}
+static int batch_reset(ptl_batch* b) {
+    for (int s = 0; s < b->S; ++s) {
+        int rc = icp_reset_device(b->icp[s]);
+        if (rc) return rc;
+        rc = ekf_reset(b->ekf[s]);
+        if (rc) return rc;
+        b->imu_pos[s] = 0;
+    }
+    b->next_scan = 0;
+    b->n_out = 0;
+    return PTL_OK;
+}
+extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
+    if (!b || n < 0 || b->next_scan + n > b->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    if (b->ctx_dirty) { int rc = batch_push_ctx(b); if (rc) return rc; }
+    const bool with_ekf = b->cfg.with_ekf != 0;
+    const int S = b->S;
+    const int64_t pps = b->cfg.points_per_scan;
+    const int nb = (int)((pps + 255) / 256);
+    const ptl_icp_cfg& ic = b->cfg.icp;
+    hipStream_t st = b->stream;
+    const int64_t end = b->next_scan + n;
+    for (int64_t k = b->next_scan; k < end; ++k) {
+        if (with_ekf) {  // IMU samples before the first scan of a run (later ones ride on the previous scan's EKF launch)
+            EkfBatchArgs ea;
+            memset(&ea, 0, sizeof ea);
+            bool any = false;
+            for (int s = 0; s < S; ++s) {
+                ea.e[s] = b->ekf[s]->st; ea.imu[s] = b->d_imu[s];
+                ea.i0[s] = (int)b->imu_pos[s]; ea.i1[s] = (int)b->imu_end[s][(size_t)k];
+                any = any || ea.i1[s] > ea.i0[s];
+                b->imu_pos[s] = b->imu_end[s][(size_t)k] > b->imu_pos[s] ? b->imu_end[s][(size_t)k] : b->imu_pos[s];
+            }
+            if (any) kb_ekf_step<<<S, 384, 0, st>>>(ea);
+        }
+        const int ki = (int)k;
+        kb_scan_prologue<<<dim3(1, S), 1024, 0, st>>>(b->d_ctx, ki);
+        kb_deskew_vds1<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        kb_vds2<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        kb_compact_fd<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        kb_compact_src<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (b->prof) {
+            if (b->ev_used + 2 > b->ev.size())
+                for (int q = 0; q < 2; ++q) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); b->ev.push_back(e); }
+            e0 = b->ev[b->ev_used++]; e1 = b->ev[b->ev_used++];
+            HIPCHK(hipEventRecord(e0, st));
+        }
+        kb_gn_loop<<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, b->d_partials);
+        if (b->prof) HIPCHK(hipEventRecord(e1, st));
+        kb_map_insert_a<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        kb_map_insert_b<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        kb_map_insert_c<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        kb_map_prune<<<dim3((unsigned)((ic.map_block_capacity + 255) / 256), S), 256, 0, st>>>(b->d_ctx, ki);
+        const int64_t o = b->n_out;
+        if (with_ekf) {
+            EkfBatchArgs ea;
+            memset(&ea, 0, sizeof ea);
+            for (int s = 0; s < S; ++s) {
+                const int64_t e2 = (k + 1 < b->cfg.n_scans) ? b->imu_end[s][(size_t)k + 1] : b->imu_pos[s];
+                ea.e[s] = b->ekf[s]->st; ea.imu[s] = b->d_imu[s];
+                ea.i0[s] = (int)b->imu_pos[s]; ea.i1[s] = (int)e2;
+                ea.pose[s] = b->icp[s]->c.traj + 16 * o;
+                ea.out_pose[s] = b->d_res_poses[s] + 16 * o; ea.out_t[s] = b->d_res_t[s] + o; ea.out_row8[s] = b->d_rows[s] + 8 * o;
+                b->imu_pos[s] = e2;
+            }
+            ea.update_first = 1;
+            kb_ekf_step<<<S, 384, 0, st>>>(ea);
+        }
+        for (int s = 0; s < S; ++s) { b->icp[s]->scans_done++; b->icp[s]->last_n = pps; }
+        b->n_out++;
+        b->next_scan = k + 1;
+        if (ic.rebuild_every > 0 && (b->n_out % ic.rebuild_every) == 0) {
+            for (int s = 0; s < S; ++s) {
+                HIPCHK(hipMemsetAsync(b->icp[s]->c.tab, 0xFF, ((size_t)b->icp[s]->c.tmask + 1) * sizeof(TabEnt), st));
+                HIPCHK(hipMemsetAsync(&b->icp[s]->c.st->tab_used, 0, sizeof(unsigned), st));
+            }
+            kb_map_rebuild<<<dim3((unsigned)((ic.map_block_capacity + 255) / 256), S), 256, 0, st>>>(b->d_ctx, ki);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return PTL_OK;
+}
+extern "C" int ptl_batch_wait(ptl_batch* b) {
+    if (!b) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    int flags[GN_MAX_SEQ] = {0};
+    for (int s = 0; s < b->S; ++s) {
+        k_finish_scan<<<1, 64, 0, b->stream>>>(b->icp[s]->c);
+        HIPCHK(hipMemcpyAsync(&flags[s], &b->icp[s]->c.st->err_flags, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (size_t i = 0; i + 1 < b->ev_used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]) == hipSuccess) { b->gn_ms += ms; b->gn_launches++; }
+    }
+    b->ev_used = 0;
+    for (int s = 0; s < b->S; ++s)
+        if (flags[s]) return set_err(PTL_ERR_CAPACITY, "sequence %d: device capacity/error flags 0x%x (1 key range, 2 block pool, 4 map table, 8 vds table, 16 gn barrier timeout)", s, flags[s]);
+    return PTL_OK;
+}
+extern "C" int ptl_batch_run(ptl_batch* b, int64_t n) {
+    if (!b || n < 0 || n > b->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    int rc = batch_reset(b);
+    if (rc) return rc;
+    rc = ptl_batch_enqueue(b, n);
+    if (rc) return rc;
+    return ptl_batch_wait(b);
+}
+extern "C" int ptl_batch_results(ptl_batch* b, int32_t s, double* res_poses, double* res_t, double* kiss_poses,
+                                 ptl_icp_stats* stats, int64_t max_n, int64_t* n_out) {
+    if (!b || s < 0 || s >= b->S) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    const int64_t n = b->n_out < max_n ? b->n_out : max_n;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (n > 0) {
+        if (res_poses && b->cfg.with_ekf) HIPCHK(hipMemcpy(res_poses, b->d_res_poses[s], (size_t)n * 128, hipMemcpyDeviceToHost));
+        if (res_t && b->cfg.with_ekf) HIPCHK(hipMemcpy(res_t, b->d_res_t[s], (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (kiss_poses) HIPCHK(hipMemcpy(kiss_poses, b->icp[s]->c.traj, (size_t)n * 128, hipMemcpyDeviceToHost));
+        if (stats) {
+            std::vector<ScanStats> tmp((size_t)n);
+            HIPCHK(hipMemcpy(tmp.data(), b->icp[s]->c.sstats, (size_t)n * sizeof(ScanStats), hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; ++i) stats_out(tmp[(size_t)i], &stats[i]);
+        }
+    }
+    if (n_out) *n_out = n;
+    return PTL_OK;
+}
+extern "C" int ptl_batch_copy_traj(ptl_batch* b, int32_t s, void* dst_device, int64_t max_rows, int64_t* rows) {
+    if (!b || !dst_device || s < 0 || s >= b->S) return set_err(PTL_ERR_ARG, "bad argument");
+    if (!b->cfg.with_ekf) return set_err(PTL_ERR_STATE, "trajectory rows need with_ekf");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    const int64_t n = b->n_out < max_rows ? b->n_out : max_rows;
+    if (n > 0) HIPCHK(hipMemcpyAsync(dst_device, b->d_rows[s], (size_t)n * 64, hipMemcpyDeviceToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (rows) *rows = n;
+    return PTL_OK;
+}
+extern "C" int ptl_batch_profile(ptl_batch* b, int enable, double* gn_ms_total, int64_t* gn_launches, int reset) {
+    if (!b) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (gn_ms_total) *gn_ms_total = b->gn_ms;
+    if (gn_launches) *gn_launches = b->gn_launches;
+    if (reset) { b->gn_ms = 0; b->gn_launches = 0; }
+    b->prof = enable != 0;
+    return PTL_OK;
+}
