@@ -236,6 +236,7 @@ int ptl_batch_wait(ptl_batch *b);
 int ptl_batch_results(ptl_batch *b, int32_t seq, double *res_poses, double *res_t, double *kiss_poses,
                       ptl_icp_stats *stats, int64_t max_n, int64_t *n_out);
 int ptl_batch_copy_traj(ptl_batch *b, int32_t seq, void *dst_device, int64_t max_rows, int64_t *rows);
+int ptl_batch_gn_phases(ptl_batch *b, int64_t out[8]); /* like ptl_icp_gn_phases, for the shared launch */
 int ptl_batch_profile(ptl_batch *b, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
 
 #ifdef __cplusplus

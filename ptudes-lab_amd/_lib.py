@@ -113,6 +113,7 @@ PROTOTYPES = {
     "ptl_batch_wait": (C.c_int, [_vp]),
     "ptl_batch_results": (C.c_int, [_vp, C.c_int32, c_d_p, c_d_p, c_d_p, C.POINTER(IcpStats), C.c_int64, c_i64_p]),
     "ptl_batch_copy_traj": (C.c_int, [_vp, C.c_int32, _vp, C.c_int64, c_i64_p]),
+    "ptl_batch_gn_phases": (C.c_int, [_vp, c_i64_p]),
     "ptl_batch_profile": (C.c_int, [_vp, C.c_int, c_d_p, c_i64_p, C.c_int]),
 }
 

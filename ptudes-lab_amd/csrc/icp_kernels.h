@@ -120,8 +120,10 @@ struct Ctx {
     int traj_cap;
 };
 
-__device__ __forceinline__ double* blk_x(const Ctx& c, int b) { return (double*)(c.blocks + (size_t)b * c.bstride); }
-__device__ __forceinline__ int* blk_hdr(const Ctx& c, int b) {
+template <class CT>
+__device__ __forceinline__ double* blk_x(const CT& c, int b) { return (double*)(c.blocks + (size_t)b * c.bstride); }
+template <class CT>
+__device__ __forceinline__ int* blk_hdr(const CT& c, int b) {
     return (int*)(c.blocks + (size_t)b * c.bstride + (size_t)c.P * 24);
 }
 
@@ -422,7 +424,8 @@ __device__ __forceinline__ void d_compact_src(const Ctx& c) {
 }
 // ------------------------------------------------------------------------------------------------ K5
 // map probe: block id of voxel `key` or -1
-__device__ __forceinline__ int map_find(const Ctx& c, unsigned long long key) {
+template <class CT>
+__device__ __forceinline__ int map_find(const CT& c, unsigned long long key) {
     unsigned s = (unsigned)mix64(key) & c.tmask;
     for (unsigned probe = 0; probe <= c.tmask; ++probe) {
         const TabEnt e = c.tab[s];
@@ -438,7 +441,8 @@ __device__ __forceinline__ int map_find(const Ctx& c, unsigned long long key) {
 // Returns in every lane of the group: best squared distance, best target, found flag; adds candidates to ncand.
 // `ck` / `cblk` carry the centre voxel and this lane's block id from the previous call: the map is constant
 // during a Gauss-Newton loop, so when the point has not left its voxel the 27 probes are skipped.
-__device__ __forceinline__ bool nn_search32(const Ctx& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
+template <class CT>
+__device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
                                             long long& ncand, unsigned long long& ck, int& cblk, bool use_cache) {
     const int kx = (int)(s.x / c.vs), ky = (int)(s.y / c.vs), kz = (int)(s.z / c.vs);
     const unsigned long long key = pack_key(kx, ky, kz);
@@ -529,6 +533,25 @@ __device__ __forceinline__ V3 jcol(int idx, V3 s, V3 r) {
         case 5: return v3(-s.y, s.x, 0.0);
         default: return r;
     }
+}
+
+// Source point -> workgroup assignment.  Workgroups with the same (wg & 7) run on one XCD (observed dispatch,
+// used for speed only) and share its 4 MB L2, so each such set gets one CONTIGUOUS eighth of the scan-ordered
+// source points (a band of beams): the map voxels it probes then stay resident in that XCD's L2.
+struct PointWalk {
+    int first, last, step;
+};
+__device__ __forceinline__ PointWalk point_walk(int n, int G, int wg, int NG, int grp) {
+    PointWalk w;
+    if ((G & 7) == 0) {
+        const int chunk = (n + 7) >> 3, x = wg & 7, j = wg >> 3;
+        w.first = x * chunk + j * NG + grp;
+        w.last = (x + 1) * chunk < n ? (x + 1) * chunk : n;
+        w.step = (G >> 3) * NG;
+    } else {
+        w.first = wg * NG + grp; w.last = n; w.step = G * NG;
+    }
+    return w;
 }
 
 // Two-level arrival / one-word-per-group release grid barrier on monotonic counters (zeroed by K0).
@@ -629,7 +652,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     int iters = 0, ncorr_last = 0;
     long long ph[5] = {0, 0, 0, 0, 0};
     // one point per 32-lane group for the whole loop => its probe results can be cached across iterations
-    const bool single_pass = n <= G * NG;
+    const bool single_pass = ((G & 7) == 0) ? (((n + 7) >> 3) <= (G >> 3) * NG) : (n <= G * NG);
     unsigned long long ckey = EMPTY_KEY;
     int cblk = -1;
     for (int it = 0; it < max_iter; ++it) {
@@ -639,7 +662,8 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         Rt E;
         for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
         for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
-        for (int i = wg * NG + grp; i < n; i += G * NG) {
+        const PointWalk pw = point_walk(n, G, wg, NG, grp);
+        for (int i = pw.first; i < pw.last; i += pw.step) {
             // lazily apply the previous iteration's increment (TransformPoints(estimation, source))
             V3 s;
             if (it == 0 && mode != 1) s = rt_apply(E, v3(c.src0[3 * (size_t)i], c.src0[3 * (size_t)i + 1], c.src0[3 * (size_t)i + 2]));
@@ -662,13 +686,18 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         const long long c1 = __builtin_readcyclecounter();
         // workgroup reduction in fixed order (column 28 carries the candidate count)
         const long long ncand0 = __shfl(ncand, gbase);  // all lanes execute the shuffle
-        red[grp][lane32] = (lane32 == 28) ? (double)ncand0 : acc;
+        {
+            // workgroup reduction, fixed tree: the two groups of a wavefront, then 4 segments of wavefronts, then 4 -> 1
+            const double mine = (lane32 == 28) ? (double)ncand0 : acc;
+            const double pair = mine + __shfl_xor(mine, 32);
+            if ((tid & 63) < 32) red[tid >> 6][lane32] = pair;
+        }
         __syncthreads();
         double* part = c.partials + ((size_t)(it & 1) * G + wg) * 32;
-        if (tid < 128) {  // 4 segments of NG/4 groups per column, then 4 -> 1, always in the same order
-            const int col = tid & 31, seg = tid >> 5, per = (NG + 3) >> 2;
+        if (tid < 128) {
+            const int col = tid & 31, seg = tid >> 5, NW = NG >> 1, per = (NW + 3) >> 2;
             double s = 0.0;
-            for (int g = seg * per; g < (seg + 1) * per && g < NG; ++g) s += red[g][col];
+            for (int g = seg * per; g < (seg + 1) * per && g < NW; ++g) s += red[g][col];
             red2[seg][col] = s;
         }
         __syncthreads();
@@ -967,15 +996,30 @@ __global__ __launch_bounds__(256) void kb_map_rebuild(const SeqCtx* a, int scan_
 
 // ------------------------------------------------------------------------------------------------ batched K5
 // The Gauss-Newton loops of S scans (one per sequence) in ONE persistent launch: every iteration runs the
-// nearest-neighbour + accumulation pass of every still-active sequence, then ONE grid barrier, then S small
-// reductions and S 6x6 solves (thread 64*s solves sequence s).  Point -> workgroup assignment, reduction trees
-// and arithmetic per sequence are exactly those of k_gn_loop, so each sequence's result is bit-identical to
-// running it alone with the same (G, threads); only the synchronisation is shared.
+// nearest-neighbour + accumulation pass of every still-active sequence back to back, then ONE workgroup
+// reduction, ONE grid barrier, S small grid reductions and S 6x6 solves (thread 64*s solves sequence s).
+// Point -> workgroup assignment, reduction trees and arithmetic per sequence are exactly those of k_gn_loop, so
+// each sequence's result is bit-identical to running it alone with the same (G, threads); only the
+// synchronisation is shared.
 #define GN_MAX_SEQ 8
-__global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(const SeqCtx* a, int S, double* partials) {
-    __shared__ double red[GN_MAX_GROUPS][32];
+struct GnSeq {  // what the inner loop needs of one sequence, small enough to travel as a kernel argument
+    const double* src0;
+    double* src_cur;
+    const TabEnt* tab;
+    const unsigned char* blocks;
+    DevState* st;
+    unsigned tmask;
+    int bstride, P, pad;
+    double vs, conv;
+};
+struct GnBatch {
+    GnSeq q[GN_MAX_SEQ];
+    int S, max_iter;
+};
+__global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const SeqCtx* a, double* partials) {
+    __shared__ double red[GN_MAX_SEQ][GN_MAX_GROUPS / 2][32];
     __shared__ double red2[4][32];
-    __shared__ double redg[GN_MAX_SEQ > 4 ? 4 : GN_MAX_SEQ][8][32];
+    __shared__ double redg[4][8][32];
     __shared__ double tot[GN_MAX_SEQ][32];
     __shared__ double Esh[GN_MAX_SEQ][12];
     __shared__ double Tsh[GN_MAX_SEQ][12];
@@ -985,8 +1029,8 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(const SeqCtx* a, in
     __shared__ int ncorr_sh[GN_MAX_SEQ];
     const int tid = threadIdx.x, lane32 = tid & 31, grp = tid >> 5, gbase = (tid & 63) & 32;
     const int NG = blockDim.x >> 5;
-    const int G = gridDim.x, wg = blockIdx.x;
-    DevState* st0 = a[0].c.st;  // barrier words of sequence 0 serve the whole launch
+    const int G = gridDim.x, wg = blockIdx.x, S = b.S;
+    DevState* st0 = b.q[0].st;  // barrier words of sequence 0 serve the whole launch
     int ia = 0, ib = 0;
     {
         int o = 0;
@@ -996,26 +1040,37 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(const SeqCtx* a, in
     }
     if (tid < S * 12) {
         const int s = tid / 12, k = tid % 12;
-        Rt g = rt_from16(a[s].c.st->guess);
-        Esh[s][k] = (k < 9) ? g.R[k] : g.t[k - 9];
+        const double* g = b.q[s].st->guess;
+        Esh[s][k] = (k < 9) ? g[4 * (k / 3) + (k % 3)] : g[4 * (k - 9) + 3];
         Tsh[s][k] = (k < 9) ? ((k % 4 == 0) ? 1.0 : 0.0) : 0.0;
     }
     if (tid < S) {
-        done_sh[tid] = (a[tid].c.st->n_live == 0) ? 1 : 0;  // voxel_map.Empty() => return initial_guess
+        done_sh[tid] = (b.q[tid].st->n_live == 0) ? 1 : 0;  // voxel_map.Empty() => return initial_guess
         iters_sh[tid] = 0; cand_sh[tid] = 0; ncorr_sh[tid] = 0;
     }
     __syncthreads();
-    const int max_iter = a[0].c.max_iter;
-    for (int it = 0; it < max_iter; ++it) {
+    long long ph[5] = {0, 0, 0, 0, 0};
+    int n_it = 0;
+    for (int it = 0; it < b.max_iter; ++it) {
+        const long long c0 = __builtin_readcyclecounter();
         bool all_done = true;
         for (int s = 0; s < S; ++s) all_done = all_done && (done_sh[s] != 0);
         if (all_done) break;
         for (int s = 0; s < S; ++s) {
             if (done_sh[s]) continue;  // uniform over the grid: every workgroup holds the same flags
-            const Ctx& c = a[s].c;
-            DevState* st = c.st;
-            const int n = st->n_src;
-            const double max_dist = st->gn_max_dist, kern = st->gn_kernel, k2 = kern * kern;
+            GnSeq c;  // by value through constant kernel-argument offsets: stays in scalar registers for the pass
+            switch (s) {
+                case 0: c = b.q[0]; break;
+                case 1: c = b.q[1]; break;
+                case 2: c = b.q[2]; break;
+                case 3: c = b.q[3]; break;
+                case 4: c = b.q[4]; break;
+                case 5: c = b.q[5]; break;
+                case 6: c = b.q[6]; break;
+                default: c = b.q[7]; break;
+            }
+            const int n = c.st->n_src;
+            const double max_dist = c.st->gn_max_dist, kern = c.st->gn_kernel, k2 = kern * kern;
             double acc = 0.0;
             long long ncand = 0;
             Rt E;
@@ -1023,10 +1078,10 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(const SeqCtx* a, in
             for (int k = 0; k < 3; ++k) E.t[k] = Esh[s][9 + k];
             unsigned long long ckey = EMPTY_KEY;
             int cblk = -1;
-            for (int i = wg * NG + grp; i < n; i += G * NG) {
-                V3 sp;
-                if (it == 0) sp = rt_apply(E, v3(c.src0[3 * (size_t)i], c.src0[3 * (size_t)i + 1], c.src0[3 * (size_t)i + 2]));
-                else sp = rt_apply(E, v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]));
+            const PointWalk pw = point_walk(n, G, wg, NG, grp);
+            for (int i = pw.first; i < pw.last; i += pw.step) {
+                const double* sp0 = (it == 0) ? c.src0 : c.src_cur;
+                const V3 sp = rt_apply(E, v3(sp0[3 * (size_t)i], sp0[3 * (size_t)i + 1], sp0[3 * (size_t)i + 2]));
                 if (lane32 == 0) { c.src_cur[3 * (size_t)i] = sp.x; c.src_cur[3 * (size_t)i + 1] = sp.y; c.src_cur[3 * (size_t)i + 2] = sp.z; }
                 V3 t;
                 double d2;
@@ -1040,12 +1095,19 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(const SeqCtx* a, in
                 }
             }
             const long long ncand0 = __shfl(ncand, gbase);
-            red[grp][lane32] = (lane32 == 28) ? (double)ncand0 : acc;
-            __syncthreads();
+            const double mine = (lane32 == 28) ? (double)ncand0 : acc;
+            const double pair = mine + __shfl_xor(mine, 32);
+            if ((tid & 63) < 32) red[s][tid >> 6][lane32] = pair;
+        }
+        __syncthreads();
+        const long long c1 = __builtin_readcyclecounter();
+        // workgroup reduction of every active sequence, same tree as k_gn_loop, then publish
+        for (int s = 0; s < S; ++s) {
+            if (done_sh[s]) continue;
             if (tid < 128) {
-                const int col = tid & 31, seg = tid >> 5, per = (NG + 3) >> 2;
+                const int col = tid & 31, seg = tid >> 5, NW = NG >> 1, per = (NW + 3) >> 2;
                 double v = 0.0;
-                for (int g = seg * per; g < (seg + 1) * per && g < NG; ++g) v += red[g][col];
+                for (int g = seg * per; g < (seg + 1) * per && g < NW; ++g) v += red[s][g][col];
                 red2[seg][col] = v;
             }
             __syncthreads();
@@ -1058,9 +1120,11 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(const SeqCtx* a, in
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        const long long c2 = __builtin_readcyclecounter();
         if (tid == 0) grid_barrier(st0, G, wg, it);
         __syncthreads();
-        // grid reduction, four sequences per round with the single-sequence tree (8 strided parts, then 8 -> 1)
+        const long long c3 = __builtin_readcyclecounter();
+        // grid reduction, up to four sequences per round with the single-sequence tree (8 strided parts, then 8 -> 1)
         const int per_round = (int)(blockDim.x >> 8) < 4 ? (int)(blockDim.x >> 8) : 4;  // 256 threads per sequence
         for (int s0 = 0; s0 < S; s0 += per_round) {
             const int s = s0 + (tid >> 8);
@@ -1094,6 +1158,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(const SeqCtx* a, in
             }
             __syncthreads();
         }
+        const long long c4 = __builtin_readcyclecounter();
         // one solving thread per sequence, in different wavefronts
         if ((tid & 63) == 0 && (tid >> 6) < S && !done_sh[tid >> 6]) {
             const int s = tid >> 6;
@@ -1111,9 +1176,16 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(const SeqCtx* a, in
             cand_sh[s] += (long long)tot[s][28];
             ncorr_sh[s] = (int)tot[s][27];
             iters_sh[s] = it + 1;
-            if (sqrt(nn) < a[s].c.conv) done_sh[s] = 1;
+            if (sqrt(nn) < b.q[s].conv) done_sh[s] = 1;
         }
         __syncthreads();
+        const long long c5 = __builtin_readcyclecounter();
+        ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
+        ++n_it;
+    }
+    if (wg == 0 && tid == 0) {
+        for (int k = 0; k < 5; ++k) st0->gn_phase_clk[k] += ph[k];
+        st0->gn_phase_clk[5] += n_it;
     }
     if (wg == 0 && (tid & 63) == 0 && (tid >> 6) < S) {
         const int s = tid >> 6;

@@ -1124,7 +1124,18 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
             e0 = b->ev[b->ev_used++]; e1 = b->ev[b->ev_used++];
             HIPCHK(hipEventRecord(e0, st));
         }
-        kb_gn_loop<<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, b->d_partials);
+        {
+            GnBatch gb;
+            memset(&gb, 0, sizeof gb);
+            gb.S = S; gb.max_iter = ic.max_iterations;
+            for (int s = 0; s < S; ++s) {
+                const Ctx& c = b->icp[s]->c;
+                gb.q[s].src0 = c.src0; gb.q[s].src_cur = c.src_cur; gb.q[s].tab = c.tab; gb.q[s].blocks = c.blocks;
+                gb.q[s].st = c.st; gb.q[s].tmask = c.tmask; gb.q[s].bstride = c.bstride; gb.q[s].P = c.P;
+                gb.q[s].vs = c.vs; gb.q[s].conv = c.conv;
+            }
+            kb_gn_loop<<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(gb, b->d_ctx, b->d_partials);
+        }
         if (b->prof) HIPCHK(hipEventRecord(e1, st));
         kb_map_insert_a<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
         kb_map_insert_b<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
@@ -1214,6 +1225,10 @@ extern "C" int ptl_batch_copy_traj(ptl_batch* b, int32_t s, void* dst_device, in
     HIPCHK(hipStreamSynchronize(b->stream));
     if (rows) *rows = n;
     return PTL_OK;
+}
+extern "C" int ptl_batch_gn_phases(ptl_batch* b, int64_t out[8]) {
+    if (!b || !out) return set_err(PTL_ERR_ARG, "null argument");
+    return ptl_icp_gn_phases(b->icp[0], out);
 }
 extern "C" int ptl_batch_profile(ptl_batch* b, int enable, double* gn_ms_total, int64_t* gn_launches, int reset) {
     if (!b) return set_err(PTL_ERR_ARG, "null argument");
