@@ -37,9 +37,10 @@
 
 struct TabEnt {
     unsigned long long key;
-    int blk;
-    int head;
+    int blk;   // -1 = none, else block id (low 24 bits) | stored point count (high 8 bits)
+    int head;  // head of this batch's insertion list (map update only)
 };
+#define BLK_ID_MASK 0x00FFFFFF
 
 struct ScanStats {  // mirrors ptl_icp_stats
     double sigma, err_dt, err_drot;
@@ -429,7 +430,7 @@ __device__ __forceinline__ int map_find(const CT& c, unsigned long long key) {
     unsigned s = (unsigned)mix64(key) & c.tmask;
     for (unsigned probe = 0; probe <= c.tmask; ++probe) {
         const TabEnt e = c.tab[s];
-        if (e.key == key) return e.blk;
+        if (e.key == key) return e.blk;  // packed: block id | count << 24
         if (e.key == EMPTY_KEY) return -1;
         s = (s + 1) & c.tmask;
     }
@@ -439,73 +440,73 @@ __device__ __forceinline__ int map_find(const CT& c, unsigned long long key) {
 // 32 lanes cooperate on one source point: lanes 0..26 probe the 27 neighbour voxels in (i,j,k) ascending
 // order, then all lanes scan each found block (lane j <-> j-th stored point, coalesced x/y/z reads).
 // Returns in every lane of the group: best squared distance, best target, found flag; adds candidates to ncand.
-// `ck` / `cblk` carry the centre voxel and this lane's block id from the previous call: the map is constant
-// during a Gauss-Newton loop, so when the point has not left its voxel the 27 probes are skipped.
+// 32 lanes cooperate on one source point.  Lanes 0..26 probe the 27 neighbour voxels in (i,j,k) ascending
+// order; a probe returns block id and point count together.  The candidates of all found voxels then form ONE
+// flat list in (voxel order, insertion order) - upstream's visiting order - and lane l takes candidates
+// l, l+32, l+64, ...; four of them are loaded per round before any is consumed, so a point costs
+// ceil(C / 128) memory round trips instead of one or two per voxel.  `ck` / `cblk` carry the centre voxel and
+// this lane's probe result from the previous call: the map is constant during a Gauss-Newton loop, so when the
+// point has not left its voxel the probes are skipped.
+// Returns in every lane of the group: best squared distance, best target, found flag; adds candidates to ncand.
 template <class CT>
 __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
                                             long long& ncand, unsigned long long& ck, int& cblk, bool use_cache) {
     const int kx = (int)(s.x / c.vs), ky = (int)(s.y / c.vs), kz = (int)(s.z / c.vs);
     const unsigned long long key = pack_key(kx, ky, kz);
-    int blk = -1;
+    int pb = -1;
     if (use_cache && key == ck) {
-        blk = cblk;
+        pb = cblk;
     } else if (lane32 < 27) {
         const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
-        blk = map_find(c, pack_key(kx + di, ky + dj, kz + dk));
+        pb = map_find(c, pack_key(kx + di, ky + dj, kz + dk));
     }
     ck = key;
-    cblk = blk;
-    const unsigned long long ball = __ballot(blk >= 0);
-    unsigned m = (unsigned)(ball >> gbase);
+    cblk = pb;
+    const int cnt = (pb < 0) ? 0 : (int)((unsigned)pb >> 24);
+    const int blk = pb & BLK_ID_MASK;
+    // exclusive prefix of the counts over the 32 lanes of the group (lanes >= 27 hold 0)
+    int incl = cnt;
+    for (int o = 1; o < 32; o <<= 1) {
+        const int up = __shfl_up(incl, o, 32);
+        if (lane32 >= o) incl += up;
+    }
+    const int excl = incl - cnt;
+    const int C = __shfl(incl, gbase + 31);
+    if (lane32 == 0) ncand += C;
     double bd = 1.7976931348623157e308;
     unsigned border = 0xFFFFFFFFu;
     V3 bp = v3(0, 0, 0);
-    if (c.P <= 32) {
-        // Four voxel blocks per round: all of a round's loads (count + x/y/z of slot `lane`) are issued
-        // before any is consumed, so a round costs one memory round trip instead of two per block.
-        const bool lane_has_slot = lane32 < c.P;
-        while (m) {
-            int vv[4], bb[4], cc[4];
-            double qx[4], qy[4], qz[4];
+    for (int base = 0; base < C; base += 128) {
+        double qx[4], qy[4], qz[4];
+        int id[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (m) { vv[u] = __ffs(m) - 1; m &= m - 1; bb[u] = __shfl(blk, gbase + vv[u]); }
-                else { vv[u] = 0; bb[u] = -1; }
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + 32 * u + lane32;
+            id[u] = idx;
+            // owner voxel of candidate idx: largest lane v with excl(v) <= idx (binary search over the group)
+            int v = 0;
+#pragma unroll
+            for (int st = 16; st > 0; st >>= 1) {
+                const int mid = v + st;
+                const int e = __shfl(excl, gbase + (mid & 31));
+                if (mid < 27 && e <= idx) v = mid;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                cc[u] = 0; qx[u] = 0.0; qy[u] = 0.0; qz[u] = 0.0;
-                if (bb[u] >= 0) {
-                    cc[u] = blk_hdr(c, bb[u])[0];
-                    if (lane_has_slot) {
-                        const double* X = blk_x(c, bb[u]);
-                        qx[u] = X[lane32]; qy[u] = X[c.P + lane32]; qz[u] = X[2 * c.P + lane32];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (lane32 == 0) ncand += cc[u];
-                if (lane32 < cc[u]) {
-                    const double dx = qx[u] - s.x, dy = qy[u] - s.y, dz = qz[u] - s.z;
-                    const double d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < bd) { bd = d2; border = (unsigned)(vv[u] * 1024 + lane32); bp = v3(qx[u], qy[u], qz[u]); }
-                }
+            // empty voxels share their excl with the next one: step to the last lane with that prefix and a count
+            const int bv = __shfl(blk, gbase + v);
+            const int ev = __shfl(excl, gbase + v);
+            qx[u] = 0.0; qy[u] = 0.0; qz[u] = 0.0;
+            if (idx < C) {
+                const double* X = blk_x(c, bv);
+                const int slot = idx - ev;
+                qx[u] = X[slot]; qy[u] = X[c.P + slot]; qz[u] = X[2 * c.P + slot];
             }
         }
-    } else {
-        while (m) {
-            const int v = __ffs(m) - 1;
-            m &= m - 1;
-            const int b = __shfl(blk, gbase + v);
-            const int cnt = blk_hdr(c, b)[0];
-            if (lane32 == 0) ncand += cnt;
-            const double* X = blk_x(c, b);
-            for (int j = lane32; j < cnt; j += 32) {
-                const double qx = X[j], qy = X[c.P + j], qz = X[2 * c.P + j];
-                const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (id[u] < C) {
+                const double dx = qx[u] - s.x, dy = qy[u] - s.y, dz = qz[u] - s.z;
                 const double d2 = dx * dx + dy * dy + dz * dz;
-                if (d2 < bd) { bd = d2; border = (unsigned)(v * 1024 + j); bp = v3(qx, qy, qz); }
+                if (d2 < bd) { bd = d2; border = (unsigned)id[u]; bp = v3(qx[u], qy[u], qz[u]); }
             }
         }
     }
@@ -841,8 +842,9 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
     for (int j = c.tab[slot].head; j >= 0; j = c.nxt[j]) { ++len; rank += (j < i) ? 1 : 0; }
     c.prank[i] = rank;
     c.plen[i] = len;
-    const int b = c.tab[slot].blk;
-    if (b < 0) return;
+    const int pb = c.tab[slot].blk;
+    if (pb < 0) return;
+    const int b = pb & BLK_ID_MASK;
     const int cnt = blk_hdr(c, b)[0];
     const int pos = cnt + rank;
     if (pos < c.P) {
@@ -857,14 +859,16 @@ __device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, i
     if (i >= n) return;
     if (c.prank[i] != 0) return;
     const int slot = c.pslot[i];
-    const int b = c.tab[slot].blk;
+    const int pb = c.tab[slot].blk;
     c.tab[slot].head = -1;
-    if (b < 0) return;
+    if (pb < 0) return;
+    const int b = pb & BLK_ID_MASK;
     int* h = blk_hdr(c, b);
     const int cnt = h[0];
     int nc = cnt + c.plen[i];
     if (nc > c.P) nc = c.P;
     h[0] = nc;
+    c.tab[slot].blk = b | (nc << 24);  // the table entry mirrors the count so a probe returns both
     atomicAdd((unsigned long long*)&c.st->map_points, (unsigned long long)(nc - cnt));
 }
 
@@ -906,7 +910,7 @@ __device__ __forceinline__ void d_map_rebuild(const Ctx& c) {
     unsigned s = (unsigned)mix64(key) & c.tmask;
     for (unsigned probe = 0; probe <= c.tmask; ++probe) {
         const unsigned long long old = atomicCAS(&c.tab[s].key, EMPTY_KEY, key);
-        if (old == EMPTY_KEY) { c.tab[s].blk = b; h[1] = (int)s; atomicAdd(&c.st->tab_used, 1u); return; }
+        if (old == EMPTY_KEY) { c.tab[s].blk = b | (h[0] << 24); h[1] = (int)s; atomicAdd(&c.st->tab_used, 1u); return; }
         s = (s + 1) & c.tmask;
     }
     atomicOr(&c.st->err_flags, ERR_TABLE);

@@ -132,7 +132,8 @@ static int icp_reset_device(ptl_icp* h) {
 
 static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, ptl_icp** out) {
     if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
-    if (cfg->max_points_per_voxel < 1 || cfg->max_points_per_voxel > 1000) return set_err(PTL_ERR_ARG, "max_points_per_voxel out of range");
+    if (cfg->max_points_per_voxel < 1 || cfg->max_points_per_voxel > 254) return set_err(PTL_ERR_ARG, "max_points_per_voxel must be in [1, 254]");
+    if (cfg->map_block_capacity < 1 || cfg->map_block_capacity >= (1 << 24) - 1) return set_err(PTL_ERR_ARG, "map_block_capacity must be below 2^24 - 1");
     if (cfg->map_table_capacity & (cfg->map_table_capacity - 1)) return set_err(PTL_ERR_ARG, "map_table_capacity must be a power of two");
     if (cfg->max_points_per_scan < 1 || cfg->gn_workgroups < 1) return set_err(PTL_ERR_ARG, "bad capacity");
     if (cfg->gn_threads < 256 || cfg->gn_threads > GN_MAX_THREADS || (cfg->gn_threads & 63)) return set_err(PTL_ERR_ARG, "gn_threads must be a multiple of 64 in [256, GN_MAX_THREADS]");
