@@ -18,6 +18,7 @@
 #define EKF_BG 9
 #define EKF_BA 12
 #define EKF_G 15
+#define EKF_CHUNK 64
 
 struct EkfNav {
     double pos[3], q[4], vel[3], bg[3], ba[3], grav[3];
@@ -111,6 +112,10 @@ __device__ __forceinline__ void d_ekf_step(EkfState* e, const double* imu, int i
     __shared__ double sP[EKF_N * EKF_N], sF[EKF_N * EKF_N], sW[EKF_N * EKF_N], sT[EKF_N * EKF_N];
     __shared__ double sK[EKF_N * 6], sSi[36], sr[6], sdx[EKF_N];
     __shared__ int active;
+    __shared__ double sM[6][12];
+    __shared__ int sPiv;
+    __shared__ double sRd[EKF_CHUNK][10];  // per-sample Exp(dtheta) (9) and dt
+    __shared__ double sBias[8];
     const int tid = threadIdx.x;
     const int ti = tid / EKF_N, tj = tid % EKF_N;
     const bool cell = tid < EKF_N * EKF_N;
@@ -123,118 +128,153 @@ __device__ __forceinline__ void d_ekf_step(EkfState* e, const double* imu, int i
     for (int phase = 0; phase < 3; ++phase) {
         const bool do_update = pose && ((phase == 0 && update_first) || (phase == 2 && !update_first));
         if (phase == 1) {
-            for (int s = i0; s < i1; ++s) {
-                // ---- processImu: scalar part on thread 0 (mechanisation + Fx/W blocks)
-                if (tid == 0) {
-                    const double* row = imu + 7 * (size_t)s;
-                    const double ts = row[0];
-                    nv.cur_dt = ts - nv.cur_ts;  // es_ekf.py:196
-                    nv.cur_ts = ts;
-                    for (int k = 0; k < 3; ++k) { nv.cur_lacc[k] = row[1 + k]; nv.cur_avel[k] = row[4 + k]; }
-                    if (!nv.initialized) {  // :201-203 the first sample only latches
-                        nv.initialized = 1;
-                        active = 0;
-                    } else {
-                        active = 1;
-                        const double dt = nv.cur_dt;
-                        double Rp[9], a[3], w[3], dth[3], Rd[9], Rn[9];
-                        quat_to_R(nv.q, Rp);  // nav_prev.att_h
-                        for (int k = 0; k < 3; ++k) { a[k] = row[1 + k] - nv.ba[k]; w[k] = row[4 + k] - nv.bg[k]; dth[k] = w[k] * dt; }
-                        rotvec_to_R(dth, Rd);
-                        // _insMech (:239-257)
-                        for (int k = 0; k < 3; ++k) {
-                            const double ag = (Rp[3 * k] * a[0] + Rp[3 * k + 1] * a[1] + Rp[3 * k + 2] * a[2]) + nv.grav[k];
-                            nv.pos[k] = nv.pos[k] + nv.vel[k] * dt + 0.5 * ag * dt * dt;
-                            nv.vel[k] = nv.vel[k] + ag * dt;
-                        }
-                        mat3_mul(Rp, Rd, Rn);
-                        R_to_quat(Rn, nv.q);
-                        // Fx blocks (:216-223)
-                        double K[9], B[9];
-                        lds_diag3(sF, EKF_POS, EKF_VEL, dt);
-                        skew(a, K);
-                        mat3_mul(Rp, K, B);
-                        for (int k = 0; k < 9; ++k) B[k] = -dt * B[k];
-                        lds_blk3(sF, EKF_VEL, EKF_PHI, B);
-                        for (int k = 0; k < 9; ++k) B[k] = -dt * Rp[k];
-                        lds_blk3(sF, EKF_VEL, EKF_BA, B);
-                        for (int r = 0; r < 3; ++r)
-                            for (int cc = 0; cc < 3; ++cc) B[3 * r + cc] = Rd[3 * cc + r];
-                        lds_blk3(sF, EKF_PHI, EKF_PHI, B);
-                        lds_diag3(sF, EKF_PHI, EKF_BG, -dt);
-                        // W blocks (:226-233); the reference's names do not match their use, this copies the use
-                        lds_diag3(sW, EKF_VEL, EKF_VEL, dt * dt * (0.049 * 0.049));
-                        lds_diag3(sW, EKF_PHI, EKF_PHI, dt * dt * (0.38 * 0.38));
-                        lds_diag3(sW, EKF_BA, EKF_BA, dt * (0.0043 * 0.0043));
-                        lds_diag3(sW, EKF_BG, EKF_BG, dt * (0.000466 * 0.000466));
-                    }
+            // The gyro / accelerometer biases are constant between pose updates, so the per-sample rotation
+            // increments Exp((w - b_g) dt) - the only transcendental work of a predict - do not depend on the
+            // running state: they are computed for a chunk of samples in parallel, one thread per sample.
+            for (int c0 = i0; c0 < i1; c0 += EKF_CHUNK) {
+                const int nc = (i1 - c0) < EKF_CHUNK ? (i1 - c0) : EKF_CHUNK;
+                if (tid == 0) { for (int k = 0; k < 3; ++k) { sBias[k] = nv.bg[k]; sBias[3 + k] = nv.ba[k]; } sBias[6] = nv.cur_ts; }
+                __syncthreads();
+                if (tid < nc) {
+                    const double* row = imu + 7 * (size_t)(c0 + tid);
+                    const double tprev = (tid == 0) ? sBias[6] : imu[7 * (size_t)(c0 + tid - 1)];
+                    const double dt = row[0] - tprev;  // es_ekf.py:196
+                    double dth[3], Rd[9];
+                    for (int k = 0; k < 3; ++k) dth[k] = (row[4 + k] - sBias[k]) * dt;
+                    rotvec_to_R(dth, Rd);
+                    for (int k = 0; k < 9; ++k) sRd[tid][k] = Rd[k];
+                    sRd[tid][9] = dt;
                 }
                 __syncthreads();
-                if (active) {
-                    // ---- P = Fx P Fx^T + W (:235), dense like the reference
-                    // Only the structurally non-zero columns of each Fx row are visited, in ascending order:
-                    // skipping exact-zero products leaves every partial sum bit-identical to the dense loop.
-                    if (cell) {
-                        double acc = 0.0;
-                        for (unsigned m = ekf_row_mask(ti); m; m &= m - 1) {
-                            const int k = __ffs(m) - 1;
-                            acc += sF[ti * EKF_N + k] * sP[k * EKF_N + tj];
+                for (int j = 0; j < nc; ++j) {
+                    // ---- processImu: scalar part on thread 0 (mechanisation + Fx/W blocks)
+                    if (tid == 0) {
+                        const double* row = imu + 7 * (size_t)(c0 + j);
+                        nv.cur_dt = sRd[j][9];
+                        nv.cur_ts = row[0];
+                        for (int k = 0; k < 3; ++k) { nv.cur_lacc[k] = row[1 + k]; nv.cur_avel[k] = row[4 + k]; }
+                        if (!nv.initialized) {  // :201-203 the first sample only latches
+                            nv.initialized = 1;
+                            active = 0;
+                        } else {
+                            active = 1;
+                            const double dt = nv.cur_dt;
+                            double Rp[9], a[3], Rd[9], Rn[9];
+                            quat_to_R(nv.q, Rp);  // nav_prev.att_h
+                            for (int k = 0; k < 3; ++k) a[k] = row[1 + k] - nv.ba[k];
+                            for (int k = 0; k < 9; ++k) Rd[k] = sRd[j][k];
+                            // _insMech (:239-257)
+                            for (int k = 0; k < 3; ++k) {
+                                const double ag = (Rp[3 * k] * a[0] + Rp[3 * k + 1] * a[1] + Rp[3 * k + 2] * a[2]) + nv.grav[k];
+                                nv.pos[k] = nv.pos[k] + nv.vel[k] * dt + 0.5 * ag * dt * dt;
+                                nv.vel[k] = nv.vel[k] + ag * dt;
+                            }
+                            mat3_mul(Rp, Rd, Rn);
+                            R_to_quat(Rn, nv.q);
+                            // Fx blocks (:216-223)
+                            double K[9], B[9];
+                            lds_diag3(sF, EKF_POS, EKF_VEL, dt);
+                            skew(a, K);
+                            mat3_mul(Rp, K, B);
+                            for (int k = 0; k < 9; ++k) B[k] = -dt * B[k];
+                            lds_blk3(sF, EKF_VEL, EKF_PHI, B);
+                            for (int k = 0; k < 9; ++k) B[k] = -dt * Rp[k];
+                            lds_blk3(sF, EKF_VEL, EKF_BA, B);
+                            for (int r = 0; r < 3; ++r)
+                                for (int cc = 0; cc < 3; ++cc) B[3 * r + cc] = Rd[3 * cc + r];
+                            lds_blk3(sF, EKF_PHI, EKF_PHI, B);
+                            lds_diag3(sF, EKF_PHI, EKF_BG, -dt);
+                            // W blocks (:226-233); the reference's names do not match their use, this copies the use
+                            lds_diag3(sW, EKF_VEL, EKF_VEL, dt * dt * (0.049 * 0.049));
+                            lds_diag3(sW, EKF_PHI, EKF_PHI, dt * dt * (0.38 * 0.38));
+                            lds_diag3(sW, EKF_BA, EKF_BA, dt * (0.0043 * 0.0043));
+                            lds_diag3(sW, EKF_BG, EKF_BG, dt * (0.000466 * 0.000466));
                         }
-                        sT[tid] = acc;
                     }
                     __syncthreads();
-                    if (cell) {
-                        double acc = 0.0;
-                        for (unsigned m = ekf_row_mask(tj); m; m &= m - 1) {
-                            const int k = __ffs(m) - 1;
-                            acc += sT[ti * EKF_N + k] * sF[tj * EKF_N + k];
+                    if (active) {
+                        // ---- P = Fx P Fx^T + W (:235), dense like the reference.  Only the structurally non-zero
+                        // columns of each Fx row are visited, in ascending order: skipping exact-zero products
+                        // leaves every partial sum bit-identical to the dense loop.
+                        if (cell) {
+                            double acc = 0.0;
+                            for (unsigned m = ekf_row_mask(ti); m; m &= m - 1) {
+                                const int k = __ffs(m) - 1;
+                                acc += sF[ti * EKF_N + k] * sP[k * EKF_N + tj];
+                            }
+                            sT[tid] = acc;
                         }
-                        sP[tid] = acc + sW[tid];
+                        __syncthreads();
+                        if (cell) {
+                            double acc = 0.0;
+                            for (unsigned m = ekf_row_mask(tj); m; m &= m - 1) {
+                                const int k = __ffs(m) - 1;
+                                acc += sT[ti * EKF_N + k] * sF[tj * EKF_N + k];
+                            }
+                            sP[tid] = acc + sW[tid];
+                        }
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
             continue;
         }
         if (!do_update) continue;
         // ---- processPose (:259-329); the error state is zero on entry (reset at :327)
         if (tid == 0) {
-            double Rk[9], RkT[9], Rm[9], D[9], S[36];
+            double Rk[9], RkT[9], Rm[9], D[9];
             quat_to_R(nv.q, Rk);
             for (int r = 0; r < 3; ++r)
                 for (int cc = 0; cc < 3; ++cc) { RkT[3 * r + cc] = Rk[3 * cc + r]; Rm[3 * r + cc] = pose[4 * r + cc]; }
             for (int k = 0; k < 3; ++k) sr[k] = pose[4 * k + 3] - nv.pos[k];  // :294
             mat3_mul(RkT, Rm, D);
             R_to_rotvec(D, sr + 3);  // :297
-            for (int a = 0; a < 6; ++a)
-                for (int b = 0; b < 6; ++b) {
-                    double rm;
-                    if (meas_cov) rm = meas_cov[6 * a + b];
-                    else rm = (a == b) ? ((a < 3) ? 0.02 * 0.02 : 0.01 * 0.01) : 0.0;  // :289-292
-                    S[6 * a + b] = sP[sel[a] * EKF_N + sel[b]] + rm;                    // :299
-                }
-            // inverse by Gauss-Jordan with partial pivoting (np.linalg.inv, :300)
-            double M[6][12];
-            for (int a = 0; a < 6; ++a)
-                for (int b = 0; b < 6; ++b) { M[a][b] = S[6 * a + b]; M[a][6 + b] = (a == b) ? 1.0 : 0.0; }
-            for (int cI = 0; cI < 6; ++cI) {
+        }
+        // S = Jp P Jp^T + R (:299) and its inverse by Gauss-Jordan with partial pivoting (np.linalg.inv, :300), held
+        // in LDS as the 6 x 12 augmented matrix [S | I]; thread (a, b) owns one entry, every entry sees exactly
+        // the operations of the sequential algorithm.
+        if (tid < 72) {
+            const int a = tid / 12, bb = tid % 12;
+            double v;
+            if (bb < 6) {
+                double rm;
+                if (meas_cov) rm = meas_cov[6 * a + bb];
+                else rm = (a == bb) ? ((a < 3) ? 0.02 * 0.02 : 0.01 * 0.01) : 0.0;  // :289-292
+                v = sP[sel[a] * EKF_N + sel[bb]] + rm;
+            } else {
+                v = (a == bb - 6) ? 1.0 : 0.0;
+            }
+            sM[a][bb] = v;
+        }
+        __syncthreads();
+        for (int cI = 0; cI < 6; ++cI) {
+            if (tid == 0) {
                 int p = cI;
                 for (int r = cI + 1; r < 6; ++r)
-                    if (fabs(M[r][cI]) > fabs(M[p][cI])) p = r;
-                if (p != cI)
-                    for (int b = 0; b < 12; ++b) { const double t = M[cI][b]; M[cI][b] = M[p][b]; M[p][b] = t; }
-                const double d = M[cI][cI];
-                for (int b = 0; b < 12; ++b) M[cI][b] /= d;
-                for (int r = 0; r < 6; ++r) {
-                    if (r == cI) continue;
-                    const double f = M[r][cI];
-                    if (f == 0.0) continue;
-                    for (int b = 0; b < 12; ++b) M[r][b] -= f * M[cI][b];
-                }
+                    if (fabs(sM[r][cI]) > fabs(sM[p][cI])) p = r;
+                sPiv = p;
             }
-            for (int a = 0; a < 6; ++a)
-                for (int b = 0; b < 6; ++b) sSi[6 * a + b] = M[a][6 + b];
+            __syncthreads();
+            const int p = sPiv;
+            double mine = 0.0, other = 0.0;
+            if (tid < 12 && p != cI) { mine = sM[cI][tid]; other = sM[p][tid]; }
+            __syncthreads();
+            if (tid < 12 && p != cI) { sM[cI][tid] = other; sM[p][tid] = mine; }
+            __syncthreads();
+            const double d = sM[cI][cI];
+            double pv = 0.0;
+            if (tid < 12) pv = sM[cI][tid] / d;
+            __syncthreads();
+            if (tid < 12) sM[cI][tid] = pv;
+            __syncthreads();
+            double f = 0.0, prow = 0.0, cur = 0.0;
+            const int a = tid / 12, bb = tid % 12;
+            if (tid < 72 && a != cI) { f = sM[a][cI]; prow = sM[cI][bb]; cur = sM[a][bb]; }
+            __syncthreads();
+            if (tid < 72 && a != cI && f != 0.0) sM[a][bb] = cur - f * prow;
+            __syncthreads();
         }
+        if (tid < 36) sSi[tid] = sM[tid / 6][6 + tid % 6];
         __syncthreads();
         if (tid < EKF_N * 6) {  // K = P Jp^T S^-1 (:300)
             const int i = tid / 6, j = tid % 6;
