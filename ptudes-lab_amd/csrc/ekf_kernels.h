@@ -120,9 +120,9 @@ __device__ __forceinline__ void d_ekf_step(EkfState* e, const double* imu, int i
     const int ti = tid / EKF_N, tj = tid % EKF_N;
     const bool cell = tid < EKF_N * EKF_N;
     if (cell) { sP[tid] = e->P[tid]; sF[tid] = e->Fx[tid]; sW[tid] = e->W[tid]; }
-    // thread 0 keeps the nav state in registers for the whole launch (written back once at the end)
-    EkfNav nv;
-    if (tid == 0) nv = e->nav;
+    // the nav state lives in LDS for the whole launch (only thread 0 touches it; written back once at the end)
+    __shared__ EkfNav nv;
+    if (tid < (int)(sizeof(EkfNav) / 8)) ((double*)&nv)[tid] = ((const double*)&e->nav)[tid];
     __syncthreads();
     const int sel[6] = {EKF_POS, EKF_POS + 1, EKF_POS + 2, EKF_PHI, EKF_PHI + 1, EKF_PHI + 2};
     for (int phase = 0; phase < 3; ++phase) {

@@ -317,7 +317,8 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c) {
             else {
                 slot = vds_claim(c.vkey1, c.vmask, key);
                 if (slot < 0) atomicOr(&st->err_flags, ERR_VDS_TABLE);
-                else atomicMin(&c.vmin1[slot], (unsigned)i);
+                else if (__hip_atomic_load(&c.vmin1[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)i)
+                    atomicMin(&c.vmin1[slot], (unsigned)i);  // the slot's value only ever decreases: a smaller one seen = nothing to do
             }
         }
         c.slot1[i] = slot;
@@ -340,7 +341,8 @@ __device__ __forceinline__ void d_vds2(const Ctx& c) {
             vox_key(p, c.vds2, key, kx, ky, kz);
             slot = vds_claim(c.vkey2, c.vmask, key);
             if (slot < 0) atomicOr(&c.st->err_flags, ERR_VDS_TABLE);
-            else atomicMin(&c.vmin2[slot], (unsigned)i);
+            else if (__hip_atomic_load(&c.vmin2[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)i)
+                atomicMin(&c.vmin2[slot], (unsigned)i);
         }
         c.slot2[i] = slot;
     }
