@@ -450,9 +450,10 @@ __device__ __forceinline__ int map_find(const CT& c, unsigned long long key) {
 // this lane's probe result from the previous call: the map is constant during a Gauss-Newton loop, so when the
 // point has not left its voxel the probes are skipped.
 // Returns in every lane of the group: best squared distance, best target, found flag; adds candidates to ncand.
-template <class CT>
+template <int PC, class CT>
 __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
                                             long long& ncand, unsigned long long& ck, int& cblk, bool use_cache) {
+    const int P = (PC > 0) ? PC : c.P;  // compile-time for the default 20: y / z become immediate offsets of x
     const int kx = (int)(s.x / c.vs), ky = (int)(s.y / c.vs), kz = (int)(s.z / c.vs);
     const unsigned long long key = pack_key(kx, ky, kz);
     int pb = -1;
@@ -500,7 +501,7 @@ __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int g
             if (idx < C) {
                 const double* X = blk_x(c, bv);
                 const int slot = idx - ev;
-                qx[u] = X[slot]; qy[u] = X[c.P + slot]; qz[u] = X[2 * c.P + slot];
+                qx[u] = X[slot]; qy[u] = X[P + slot]; qz[u] = X[2 * P + slot];
             }
         }
 #pragma unroll
@@ -614,6 +615,7 @@ __device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_emp
 #define GN_MAX_THREADS 512
 #endif
 #define GN_MAX_GROUPS (GN_MAX_THREADS / 32)
+template <int PC>
 __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     __shared__ double red[GN_MAX_GROUPS][32];
     __shared__ double red2[4][32];
@@ -662,12 +664,13 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         const long long c0 = __builtin_readcyclecounter();
         double acc = 0.0;
         long long ncand = 0;
-        Rt E;
-        for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
-        for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
         const PointWalk pw = point_walk(n, G, wg, NG, grp);
         for (int i = pw.first; i < pw.last; i += pw.step) {
-            // lazily apply the previous iteration's increment (TransformPoints(estimation, source))
+            // lazily apply the previous iteration's increment (TransformPoints(estimation, source)); the increment is
+            // re-read from LDS per point so that it does not occupy 24 registers during the search
+            Rt E;
+            for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
+            for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
             V3 s;
             if (it == 0 && mode != 1) s = rt_apply(E, v3(c.src0[3 * (size_t)i], c.src0[3 * (size_t)i + 1], c.src0[3 * (size_t)i + 2]));
             else if (it == 0) s = v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]);
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             }
             V3 t;
             double d2;
-            const bool found = nn_search32(c, s, lane32, gbase, t, d2, ncand, ckey, cblk, single_pass && it > 0);
+            const bool found = nn_search32<PC>(c, s, lane32, gbase, t, d2, ncand, ckey, cblk, single_pass && it > 0);
             if (found && sqrt(d2) < max_dist) {  // uniform over the group
                 const V3 r = v3(s.x - t.x, s.y - t.y, s.z - t.z);
                 const double den = kern + (r.x * r.x + r.y * r.y + r.z * r.z);
@@ -1022,6 +1025,7 @@ struct GnBatch {
     GnSeq q[GN_MAX_SEQ];
     int S, max_iter;
 };
+template <int PC>
 __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const SeqCtx* a, double* partials) {
     __shared__ double red[GN_MAX_SEQ][GN_MAX_GROUPS / 2][32];
     __shared__ double red2[4][32];
@@ -1091,7 +1095,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
                 if (lane32 == 0) { c.src_cur[3 * (size_t)i] = sp.x; c.src_cur[3 * (size_t)i + 1] = sp.y; c.src_cur[3 * (size_t)i + 2] = sp.z; }
                 V3 t;
                 double d2;
-                const bool found = nn_search32(c, sp, lane32, gbase, t, d2, ncand, ckey, cblk, false);
+                const bool found = nn_search32<PC>(c, sp, lane32, gbase, t, d2, ncand, ckey, cblk, false);
                 if (found && sqrt(d2) < max_dist) {
                     const V3 r = v3(sp.x - t.x, sp.y - t.y, sp.z - t.z);
                     const double den = kern + (r.x * r.x + r.y * r.y + r.z * r.z);

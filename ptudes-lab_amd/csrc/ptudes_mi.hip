@@ -264,7 +264,7 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
         e0 = h->ev[h->ev_used++]; e1 = h->ev[h->ev_used++];
         HIPCHK(hipEventRecord(e0, s));
     }
-    k_gn_loop<<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0);  // ends with the post-ICP bookkeeping (kiss.py:116-128)
+    if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0);  // ends with the post-ICP bookkeeping (kiss.py:116-128)
     if (h->prof) HIPCHK(hipEventRecord(e1, s));
     // local_map.update(frame_downsample, new_pose)  (kiss.py:129)
     k_map_insert_a<<<nb, 256, 0, s>>>(c, c.fd, &c.st->n_down, 0, 1);
@@ -438,7 +438,7 @@ extern "C" int ptl_icp_linear_system(ptl_icp* h, const double* src_world, int64_
     Ctx& c = h->c;
     HIPCHK(hipMemcpyAsync(c.src_cur, src_world, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     k_set_gn<<<1, 64, 0, h->stream>>>(c.st, (int)n, max_dist, kernel, nullptr);
-    k_gn_loop<<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1);
+    if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1);
     double out[32];
     HIPCHK(hipMemcpyAsync(out, (char*)c.st + offsetof(DevState, dbg_sums), sizeof out, hipMemcpyDeviceToHost, h->stream));
     int rc = icp_check_flags(h);
@@ -457,7 +457,7 @@ extern "C" int ptl_icp_align(ptl_icp* h, const double* frame, int64_t n, const d
     HIPCHK(hipMemcpyAsync(c.src0, frame, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_ext, guess, 128, hipMemcpyHostToDevice, h->stream));
     k_set_gn<<<1, 64, 0, h->stream>>>(c.st, (int)n, max_dist, kernel, h->d_ext);
-    k_gn_loop<<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 2);  // new_pose = T_icp * guess, trajectory untouched
+    if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 2); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 2);  // new_pose = T_icp * guess, trajectory untouched
     DevState st;
     HIPCHK(hipMemcpyAsync(&st, c.st, sizeof st, hipMemcpyDeviceToHost, h->stream));
     int rc = icp_check_flags(h);
@@ -1135,7 +1135,8 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
                 gb.q[s].st = c.st; gb.q[s].tmask = c.tmask; gb.q[s].bstride = c.bstride; gb.q[s].P = c.P;
                 gb.q[s].vs = c.vs; gb.q[s].conv = c.conv;
             }
-            kb_gn_loop<<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(gb, b->d_ctx, b->d_partials);
+            if (ic.max_points_per_voxel == 20) kb_gn_loop<20><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(gb, b->d_ctx, b->d_partials);
+            else kb_gn_loop<0><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(gb, b->d_ctx, b->d_partials);
         }
         if (b->prof) HIPCHK(hipEventRecord(e1, st));
         kb_map_insert_a<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
