@@ -111,6 +111,10 @@ int ptl_icp_map_points(ptl_icp *h, double *xyz_out, int64_t max_points, int64_t 
 int ptl_icp_last_frame_down(ptl_icp *h, double *xyz_out, int64_t max_points, int64_t *n_written);
 int ptl_icp_last_source(ptl_icp *h, double *xyz_out, int64_t max_points, int64_t *n_written);
 
+/* KissICPWrapper.deskew (kiss.py:76-78): motion-compensate `xyz` (n x 3 f64) with the last two poses; fewer than two
+ * poses => returned unchanged */
+int ptl_icp_deskew(ptl_icp *h, const double *xyz, const double *t01, int64_t n, double *out);
+
 /* Stage-level entry points (teacher-forced parity checks of single kernels; kiss-icp 0.2.10 units):
  * VoxelHashMap::AddPoints + RemovePointsFarFromLocation on world-frame points */
 int ptl_icp_map_add(ptl_icp *h, const double *xyz_world, int64_t n, const double origin[3], int prune);

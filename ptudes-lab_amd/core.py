@@ -125,6 +125,12 @@ class Icp:
     def last_source(self):
         return self._cloud(L.lib().ptl_icp_last_source)
 
+    def deskew(self, xyz, t01):
+        x, t = L.as_f64(xyz), L.as_f64(t01)
+        out = np.empty_like(x)
+        L.check(L.lib().ptl_icp_deskew(self._h, L.dptr(x), L.dptr(t), len(x), L.dptr(out)))
+        return out
+
     # stage-level entry points (teacher-forced parity)
     def map_add(self, xyz_world, origin=None):
         x = L.as_f64(xyz_world)

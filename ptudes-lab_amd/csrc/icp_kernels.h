@@ -935,6 +935,23 @@ __global__ __launch_bounds__(256) void k_map_export(Ctx c, double* out, int* cou
     }
 }
 
+// MotionCompensator.deskew_scan as a stand-alone call (KissICPWrapper.deskew, reference kiss.py:76-78): the same
+// per-point transform K1 applies, without filtering; fewer than two poses => the frame is returned unchanged.
+__global__ __launch_bounds__(256) void k_deskew_only(Ctx c, const double* xyz, const double* t01, int n, double* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const DevState* st = c.st;
+    V3 p = v3(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
+    if (c.deskew && st->n_poses >= 2) {
+        double xi[6], x[6];
+        se3_log(rt_mul(rt_inv(rt_from16(st->pose_prev)), rt_from16(st->pose_last)), xi);
+        const double sft = t01[i] - 0.5;
+        for (int k = 0; k < 6; ++k) x[k] = sft * xi[k];
+        p = rt_apply(se3_exp(x), p);
+    }
+    out[3 * (size_t)i] = p.x; out[3 * (size_t)i + 1] = p.y; out[3 * (size_t)i + 2] = p.z;
+}
+
 // ================================================================================================ launch wrappers
 // Every stage exists as a device function d_*(ctx, ...); k_* runs it for one sequence (context by value), kb_* runs
 // it for S sequences in one launch (blockIdx.y = sequence, contexts in device memory): the batched driver

@@ -403,6 +403,19 @@ extern "C" int ptl_icp_last_source(ptl_icp* h, double* out, int64_t max_points, 
     return copy_cloud(h, h ? h->c.src0 : nullptr, h ? &h->c.st->n_src : nullptr, out, max_points, n_written);
 }
 
+extern "C" int ptl_icp_deskew(ptl_icp* h, const double* xyz, const double* t01, int64_t n, double* out) {
+    if (!h || (!xyz && n > 0) || (!t01 && n > 0) || !out || n < 0) return set_err(PTL_ERR_ARG, "bad argument");
+    if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "too many points");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    if (n == 0) return PTL_OK;
+    k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);
+    HIPCHK(hipMemcpyAsync(h->d_in, xyz, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_t01, t01, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    k_deskew_only<<<(int)((n + 255) / 256), 256, 0, h->stream>>>(h->c, (const double*)h->d_in, h->d_t01, (int)n, h->c.fdw);
+    HIPCHK(hipMemcpyAsync(out, h->c.fdw, (size_t)n * 24, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PTL_OK;
+}
 extern "C" int ptl_icp_map_add(ptl_icp* h, const double* xyz_world, int64_t n, const double origin[3], int prune) {
     if (!h || (!xyz_world && n > 0)) return set_err(PTL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device_id));

@@ -97,6 +97,10 @@ class KissICPWrapper:
         self._kiss.poses.append(pose)
         self._poses_ts.append(ts)
 
+    def deskew(self, frame, timestamps) -> np.ndarray:
+        """motion-compensate `frame` with the last two poses (reference kiss.py:76-78)"""
+        return self._icp.deskew(frame, timestamps)
+
     def _scan_arrays(self, scan):
         if self._xyz_lut is not None and hasattr(scan, "field"):
             import ouster.client as client  # noqa: WPS433

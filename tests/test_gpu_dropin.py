@@ -65,6 +65,10 @@ def test_kiss_wrapper_matches_oracle(seq):
         assert np.abs(T - Tr).max() < 2e-4
         assert abs(w._sigmas[-1] - ref.stats[-1]["sigma"]) < 1e-9
         assert abs(w._err_dt[-1] - ref.stats[-1]["err_dt"]) < 2e-4
+    # KissICPWrapper.deskew == Deskew.cpp on the last two poses
+    pts = seq.scan(5).astype(np.float64)[::50]
+    tt = t01[::50]
+    assert np.abs(w.deskew(pts, tt) - orc.deskew(pts, tt, ref.pose(-2), ref.pose(-1))).max() < 1e-9
     assert len(w.poses) == 6 and w.poses_ts[-1] == 100.5
     assert np.abs(w._kiss.get_prediction_model() - ref.prediction()).max() < 4e-4
     assert np.allclose(w.velocity, w._kiss.get_prediction_model()[:3, 3] / 0.1)

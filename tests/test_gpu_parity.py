@@ -229,3 +229,24 @@ def test_sequence_icp_only_matches_per_call(seq):
     # deterministic across runs
     r.run()
     assert np.array_equal(r.results()["kiss_poses"], out["kiss_poses"])
+
+
+def test_dense_map_config_vs_oracle():
+    """BASELINE config 5 shape (64 x 2048 sweeps, 0.1 m voxels, max range 100 m) on a few sweeps: the regime
+    where N_s (~45 k) exceeds the points in flight and every workgroup walks several points per iteration"""
+    sq = synth.make_sequence(seed=1005, n_scans=4, H=64, W=2048, max_range=100.0)
+    t01 = sq.column_times()
+    icp = core.Icp(100.0, 1.0, voxel_size=0.1, scan_cols=2048, map_block_capacity=1 << 20, map_table_capacity=1 << 22)
+    ref = orc.ICP(100.0, 1.0, voxel_size=0.1)
+    gt = sq.gt_poses(0.5)
+    for k in range(4):
+        x = sq.scan(k)
+        guess = np.linalg.inv(gt[0]) @ gt[k]
+        Tg = icp.register_frame(x, None, guess)
+        Tr = ref.register_frame(x.astype(np.float64), t01, guess)
+        sr, sg = ref.stats[-1], icp.stats[-1]
+        for key in ("n_valid", "n_down", "n_src", "map_voxels", "map_points", "sum_cand"):
+            assert sr[key] == sg[key], (k, key, sr[key], sg[key])
+        dt, dr = _pose_diff(Tr, Tg)
+        assert dt <= ICP_T_TOL and dr <= ICP_R_TOL, (k, dt, dr)
+    assert sg["n_src"] > 20000 and sg["map_voxels"] > 100000
