@@ -16,7 +16,9 @@ import os
 import sys
 import time
 
-import numpy as np
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # cpu_baseline's OpenMP pass: idle threads must not burn the cgroup quota
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -52,9 +54,25 @@ def scan_bytes(s, n_raw):
     return b_pre + b_ds + icp_bytes(s) + b_map
 
 
-def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0):
-    """The CPU oracle (kind "port": our C restatement of the reference path, single thread) timed on this
-    host on the first sweeps of the same sequence, until ~budget_s seconds of CPU work are spent."""
+def usable_cores():
+    """cores this process may actually use: the affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def _cpu_pass(seq, n_total, use_imu_prediction, budget_s):
     from oracle import cpu as orc
     icp = orc.ICP(max_range=seq.max_range, min_range=seq.min_range)
     ekf = orc.EKF()
@@ -76,10 +94,33 @@ def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0):
         done += 1
         if spent >= budget_s:
             break
-    return dict(value=done / spent, unit="scans/s", cores=1, kind="port",
-                sample=f"first {done} sweeps of sequence seed {seq.seed} (cold start), {spent:.1f} s of CPU work, "
-                       f"oracle/liboracle.so single thread, host has {os.cpu_count()} logical cores"), \
-        np.array(kiss), np.array(res)
+    return done, spent, np.array(kiss), np.array(res)
+
+
+def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0):
+    """The CPU oracle (kind "port": our C restatement of the reference path) timed on this host on the first
+    sweeps of the same sequence: one sequential pass (~1/3 of the budget; also the parity check of the GPU
+    trajectory) and one pass with the loops kiss-icp runs under TBB spread over every usable core (oracle.h
+    orc_set_threads).  `value` is the faster of the two."""
+    from oracle import cpu as orc
+    cores = usable_cores()
+    orc.set_threads(1)
+    d1, s1, kiss, res = _cpu_pass(seq, n_total, use_imu_prediction, budget_s / 3.0)
+    v1, vm, dm, sm = d1 / s1, 0.0, 0, 0.0
+    if cores > 1:
+        orc.set_threads(cores)
+        dm, sm, kiss_m, res_m = _cpu_pass(seq, n_total, use_imu_prediction, budget_s * 2.0 / 3.0)
+        orc.set_threads(1)
+        vm = dm / sm
+        if dm > d1:
+            kiss, res = kiss_m, res_m
+    multi = vm > v1
+    return dict(value=max(v1, vm), unit="scans/s", cores=cores if multi else 1, kind="port",
+                single_thread_value=v1, multi_thread_value=vm if cores > 1 else None,
+                sample=f"first {dm if multi else d1} sweeps of sequence seed {seq.seed} (cold start), "
+                       f"{sm if multi else s1:.1f} s wall on {cores if multi else 1} threads "
+                       f"(plus {d1} sweeps / {s1:.1f} s single-thread), oracle/liboracle.so; host has "
+                       f"{os.cpu_count()} logical cores, {cores} usable under the cgroup quota"), kiss, res
 
 
 def main():

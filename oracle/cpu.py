@@ -86,6 +86,7 @@ def lib():
             "orc_ekf_get_nav": (None, [vp, c_d_p]), "orc_ekf_get_cov": (None, [vp, c_d_p]),
             "orc_ekf_pose_mat": (None, [vp, c_d_p]), "orc_ekf_ts": (C.c_double, [vp]),
             "orc_calc_ate": (C.c_int, [c_d_p, c_d_p, C.c_int64, c_d_p]),
+            "orc_set_threads": (None, [C.c_int]), "orc_get_threads": (C.c_int, []),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -93,6 +94,15 @@ def lib():
             f.argtypes = args
         _lib = L
     return _lib
+
+
+def set_threads(n: int):
+    """multi-core timing mode of the ICP loops (see oracle.h); 1 = the sequential pass every parity test uses"""
+    lib().orc_set_threads(int(n))
+
+
+def get_threads() -> int:
+    return lib().orc_get_threads()
 
 
 def _d(a):

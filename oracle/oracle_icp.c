@@ -167,6 +167,16 @@ static void vtab_put(vtab *t, vox_t k, int32_t v) {
     vtab_put_nogrow(t, k, v);
 }
 
+/* Thread count of the multi-core timing mode (bench.py's cpu_baseline leg).  1 (the default, what every parity
+ * test uses) = one sequential pass in point order.  > 1 = the two loops kiss-icp itself runs under TBB
+ * (Registration.cpp: correspondences + linear system; Deskew.cpp / the per-point transforms) are split over
+ * OpenMP threads in fixed chunks of ORC_CHUNK points whose partial sums are added in chunk order, so the result
+ * does not depend on the thread count (it differs from the sequential pass by summation order only). */
+#define ORC_CHUNK 128
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
+
 /* ================================================================= Deskew / Preprocess / VoxelDownsample */
 
 /* Deskew.cpp DeSkewScan (reference call site kiss.py:90): mid-pose timestamp 0.5 */
@@ -176,6 +186,7 @@ void orc_deskew(const double *xyz, const double *t01, int64_t n, const double st
     orc_se3_inv(start, si);
     orc_se3_mul(si, finish, d);
     orc_se3_log(d, xi);
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads)
     for (int64_t i = 0; i < n; ++i) {
         double s = t01[i] - 0.5, x[6], M[16];
         for (int k = 0; k < 6; ++k) x[k] = s * xi[k];
@@ -317,6 +328,7 @@ void orc_map_prune(orc_map *m, const double origin[3]) {
 /* VoxelHashMap::Update(points, pose): transform, AddPoints, prune around the pose's translation */
 void orc_map_update(orc_map *m, const double *xyz, int64_t n, const double pose[16]) {
     double *w = (double *)malloc((size_t)(n > 0 ? n : 1) * 3 * sizeof(double));
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads)
     for (int64_t i = 0; i < n; ++i) T_apply(pose, xyz + 3 * i, w + 3 * i);
     orc_map_add_points(m, w, n);
     double o[3] = {pose[3], pose[7], pose[11]};
@@ -353,47 +365,81 @@ static inline int nearest_in_map(const orc_map *m, const double p[3], double bes
     return found;
 }
 
-/* GetCorrespondences + Registration.cpp BuildLinearSystem on transformed source points:
- * residual r = s - t, J = [I | -hat(s)], w = k^2 / (k + |r|^2)^2 */
-void orc_map_linear_system(const orc_map *m, const double *src, int64_t n, double max_dist, double kernel,
-                           double sums[27], int64_t *n_corr, int64_t *n_cand, double *tgt) {
-    double JTJ[36], JTr[6];
-    memset(JTJ, 0, sizeof JTJ);
-    memset(JTr, 0, sizeof JTr);
-    int64_t nc = 0, cand = 0;
+/* Registration.cpp BuildLinearSystem, one pair: residual r = s - t, J = [I | -hat(s)], w = k^2 / (k + |r|^2)^2 */
+static inline void accumulate_pair(const double s[3], const double t[3], double kernel, double k2, double JTJ[36],
+                                   double JTr[6]) {
+    double r[3] = {s[0] - t[0], s[1] - t[1], s[2] - t[2]};
+    double r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    double den = kernel + r2;
+    double w = k2 / (den * den);
+    double J[18], H[9]; /* J row-major 3x6 */
+    hat3(s, H);
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            J[6 * a + b] = (a == b) ? 1.0 : 0.0;
+            J[6 * a + 3 + b] = -H[3 * a + b];
+        }
+    for (int a = 0; a < 6; ++a) {
+        for (int b = a; b < 6; ++b) {
+            double acc = 0.0;
+            for (int q = 0; q < 3; ++q) acc += (J[6 * q + a] * w) * J[6 * q + b];
+            JTJ[6 * a + b] += acc;
+        }
+        double acc = 0.0;
+        for (int q = 0; q < 3; ++q) acc += (J[6 * q + a] * w) * r[q];
+        JTr[a] += acc;
+    }
+}
+
+/* points [i0, i1) of the correspondence search + linear system, accumulated in index order */
+static void linear_system_range(const orc_map *m, const double *src, int64_t i0, int64_t i1, double max_dist,
+                                double kernel, double JTJ[36], double JTr[6], int64_t *nc, int64_t *cand,
+                                double *tgt) {
     double k2 = kernel * kernel;
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = i0; i < i1; ++i) {
         const double *s = src + 3 * i;
         double t[3], d2;
-        int ok = nearest_in_map(m, s, t, &d2, &cand);
+        int ok = nearest_in_map(m, s, t, &d2, cand);
         /* upstream keeps the pair when (closest - point).norm() < max_correspondance_distance */
         if (!ok || !(sqrt(d2) < max_dist)) {
             if (tgt) tgt[3 * i] = tgt[3 * i + 1] = tgt[3 * i + 2] = NAN;
             continue;
         }
         if (tgt) { tgt[3 * i] = t[0]; tgt[3 * i + 1] = t[1]; tgt[3 * i + 2] = t[2]; }
-        ++nc;
-        double r[3] = {s[0] - t[0], s[1] - t[1], s[2] - t[2]};
-        double r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-        double den = kernel + r2;
-        double w = k2 / (den * den);
-        double J[18], H[9]; /* J row-major 3x6 */
-        hat3(s, H);
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) {
-                J[6 * a + b] = (a == b) ? 1.0 : 0.0;
-                J[6 * a + 3 + b] = -H[3 * a + b];
-            }
-        for (int a = 0; a < 6; ++a) {
-            for (int b = a; b < 6; ++b) {
-                double acc = 0.0;
-                for (int q = 0; q < 3; ++q) acc += (J[6 * q + a] * w) * J[6 * q + b];
-                JTJ[6 * a + b] += acc;
-            }
-            double acc = 0.0;
-            for (int q = 0; q < 3; ++q) acc += (J[6 * q + a] * w) * r[q];
-            JTr[a] += acc;
+        ++*nc;
+        accumulate_pair(s, t, kernel, k2, JTJ, JTr);
+    }
+}
+
+/* GetCorrespondences + BuildLinearSystem on transformed source points */
+void orc_map_linear_system(const orc_map *m, const double *src, int64_t n, double max_dist, double kernel,
+                           double sums[27], int64_t *n_corr, int64_t *n_cand, double *tgt) {
+    double JTJ[36], JTr[6];
+    memset(JTJ, 0, sizeof JTJ);
+    memset(JTr, 0, sizeof JTr);
+    int64_t nc = 0, cand = 0;
+    if (g_threads <= 1 || n < 2 * ORC_CHUNK) {
+        linear_system_range(m, src, 0, n, max_dist, kernel, JTJ, JTr, &nc, &cand, tgt);
+    } else {
+        const int64_t nchunk = (n + ORC_CHUNK - 1) / ORC_CHUNK;
+        double *part = (double *)calloc((size_t)nchunk * 44, sizeof(double)); /* 36 JTJ + 6 JTr + nc + cand */
+#pragma omp parallel for schedule(dynamic, 4) num_threads(g_threads)
+        for (int64_t ch = 0; ch < nchunk; ++ch) {
+            double *q = part + ch * 44;
+            int64_t c_nc = 0, c_cand = 0;
+            int64_t i1 = (ch + 1) * ORC_CHUNK < n ? (ch + 1) * ORC_CHUNK : n;
+            linear_system_range(m, src, ch * ORC_CHUNK, i1, max_dist, kernel, q, q + 36, &c_nc, &c_cand, tgt);
+            q[42] = (double)c_nc;
+            q[43] = (double)c_cand;
         }
+        for (int64_t ch = 0; ch < nchunk; ++ch) {
+            const double *q = part + ch * 44;
+            for (int a = 0; a < 36; ++a) JTJ[a] += q[a];
+            for (int a = 0; a < 6; ++a) JTr[a] += q[36 + a];
+            nc += (int64_t)q[42];
+            cand += (int64_t)q[43];
+        }
+        free(part);
     }
     int o = 0;
     for (int a = 0; a < 6; ++a)
@@ -451,6 +497,7 @@ void orc_register(const orc_map *m, const double *frame, int64_t n, const double
         return;
     }
     double *src = (double *)malloc((size_t)(n > 0 ? n : 1) * 3 * sizeof(double));
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads)
     for (int64_t i = 0; i < n; ++i) T_apply(guess, frame + 3 * i, src + 3 * i);
     double Ticp[16];
     T_identity(Ticp);
@@ -460,6 +507,7 @@ void orc_register(const orc_map *m, const double *frame, int64_t n, const double
         orc_map_linear_system(m, src, n, max_dist, kernel, sums, &nc, &cand, NULL);
         orc_solve6(sums, dx);
         orc_se3_exp(dx, E);
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads)
         for (int64_t i = 0; i < n; ++i) T_apply(E, src + 3 * i, src + 3 * i);
         orc_se3_mul(E, Ticp, Ticp);
         if (iters) *iters = j + 1;
