@@ -216,16 +216,13 @@ __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
     st->sigma = sigma;
     st->gn_max_dist = 3.0 * sigma;
     st->gn_kernel = sigma / 3.0;
-    // initial guess
-    Rt g;
-    if (c.ext_guess) {
-        g = rt_from16(c.ext_guess);
-    } else {
+    // initial guess: the constant-velocity model here; a caller-supplied one (c.ext_guess) is read by the GN kernel
+    // itself, so that whatever produces it (the EKF predict on its own stream) may still be running during K0-K4
+    if (!c.ext_guess) {
         Rt pred = (st->n_poses >= 2) ? rel : rt_identity();
         Rt lp = (st->n_poses >= 1) ? last : rt_identity();
-        g = rt_mul(lp, pred);
+        rt_to16(rt_mul(lp, pred), st->guess);
     }
-    rt_to16(g, st->guess);
     __threadfence_block();
     }
     __syncthreads();
@@ -439,14 +436,11 @@ __device__ __forceinline__ int map_find(const CT& c, unsigned long long key) {
     return -1;
 }
 
-// 32 lanes cooperate on one source point: lanes 0..26 probe the 27 neighbour voxels in (i,j,k) ascending
-// order, then all lanes scan each found block (lane j <-> j-th stored point, coalesced x/y/z reads).
-// Returns in every lane of the group: best squared distance, best target, found flag; adds candidates to ncand.
 // 32 lanes cooperate on one source point.  Lanes 0..26 probe the 27 neighbour voxels in (i,j,k) ascending
-// order; a probe returns block id and point count together.  The candidates of all found voxels then form ONE
-// flat list in (voxel order, insertion order) - upstream's visiting order - and lane l takes candidates
-// l, l+32, l+64, ...; four of them are loaded per round before any is consumed, so a point costs
-// ceil(C / 128) memory round trips instead of one or two per voxel.  `ck` / `cblk` carry the centre voxel and
+// order; a probe returns block id and point count together.  The point's own voxel is scanned first; neighbour
+// voxels whose box lies farther than the best distance found there are dropped (exact: see stage A below).  The
+// candidates of the remaining voxels form ONE flat list in (voxel order, insertion order) - upstream's visiting
+// order - and lane l takes candidates l, l+32, l+64, ...; four are loaded per round before any is consumed.  `ck` / `cblk` carry the centre voxel and
 // this lane's probe result from the previous call: the map is constant during a Gauss-Newton loop, so when the
 // point has not left its voxel the probes are skipped.
 // Returns in every lane of the group: best squared distance, best target, found flag; adds candidates to ncand.
@@ -465,9 +459,47 @@ __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int g
     }
     ck = key;
     cblk = pb;
-    const int cnt = (pb < 0) ? 0 : (int)((unsigned)pb >> 24);
+    const int cnt0 = (pb < 0) ? 0 : (int)((unsigned)pb >> 24);
     const int blk = pb & BLK_ID_MASK;
-    // exclusive prefix of the counts over the 32 lanes of the group (lanes >= 27 hold 0)
+    ncand += cnt0;  // per lane; the caller sums the 32 lanes once per iteration
+    double bd = 1.7976931348623157e308;
+    unsigned border = 0xFFFFFFFFu;  // visiting order of a candidate: voxel lane * 32 + slot
+    V3 bp = v3(0, 0, 0);
+    // Stage A: the point's own voxel (lane 13).  Its best distance bounds the search: a neighbour voxel whose box is
+    // farther than that cannot hold a strictly closer point, and equal distances lose to nothing they could beat
+    // only when strictly farther, so the (distance, visiting order) minimum is unchanged by skipping it.
+    int cnt = cnt0;
+    const int cntc = __shfl(cnt0, gbase + 13);
+    if (cntc > 0) {  // uniform over the group
+        const int blkc = __shfl(blk, gbase + 13);
+        if (lane32 < cntc) {
+            const double* X = blk_x(c, blkc);
+            const double qx = X[lane32], qy = X[P + lane32], qz = X[2 * P + lane32];
+            const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+            bd = dx * dx + dy * dy + dz * dz;
+            border = 13u * 32u + (unsigned)lane32;
+            bp = v3(qx, qy, qz);
+        }
+        // box of this lane's voxel under truncation toward zero: index 0 spans (-vs, vs), k > 0 [k vs, (k+1) vs),
+        // k < 0 ((k-1) vs, k vs]; 1 nm of slack covers the rounding of x / vs at any coordinate the key range allows
+        double gap2 = 0.0;
+        if (lane32 < 27) {
+            const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
+            const int v[3] = {kx + di, ky + dj, kz + dk};
+            const double x[3] = {s.x, s.y, s.z};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double lo = (double)(v[a] > 0 ? v[a] : v[a] - 1) * c.vs, hi = (double)(v[a] < 0 ? v[a] : v[a] + 1) * c.vs;
+                double g = fmax(fmax(lo - x[a], x[a] - hi), 0.0) - 1e-9;
+                g = fmax(g, 0.0);
+                gap2 += g * g;
+            }
+        }
+        double m = bd;
+        for (int o = 16; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));
+        if (lane32 == 13 || gap2 > m) cnt = 0;
+    }
+    // exclusive prefix of the remaining counts over the 32 lanes of the group (lanes >= 27 hold 0)
     int incl = cnt;
     for (int o = 1; o < 32; o <<= 1) {
         const int up = __shfl_up(incl, o, 32);
@@ -475,18 +507,14 @@ __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int g
     }
     const int excl = incl - cnt;
     const int C = __shfl(incl, gbase + 31);
-    if (lane32 == 0) ncand += C;
-    double bd = 1.7976931348623157e308;
-    unsigned border = 0xFFFFFFFFu;
-    V3 bp = v3(0, 0, 0);
     for (int base = 0; base < C; base += 128) {
         double qx[4], qy[4], qz[4];
-        int id[4];
+        unsigned id[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int idx = base + 32 * u + lane32;
-            id[u] = idx;
-            // owner voxel of candidate idx: largest lane v with excl(v) <= idx (binary search over the group)
+            // owner voxel of candidate idx: largest lane v with excl(v) <= idx (binary search over the group); among
+            // lanes sharing a prefix that is the one holding points
             int v = 0;
 #pragma unroll
             for (int st = 16; st > 0; st >>= 1) {
@@ -494,22 +522,23 @@ __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int g
                 const int e = __shfl(excl, gbase + (mid & 31));
                 if (mid < 27 && e <= idx) v = mid;
             }
-            // empty voxels share their excl with the next one: step to the last lane with that prefix and a count
             const int bv = __shfl(blk, gbase + v);
             const int ev = __shfl(excl, gbase + v);
             qx[u] = 0.0; qy[u] = 0.0; qz[u] = 0.0;
+            id[u] = 0xFFFFFFFFu;
             if (idx < C) {
                 const double* X = blk_x(c, bv);
                 const int slot = idx - ev;
+                id[u] = (unsigned)(v * 32 + slot);
                 qx[u] = X[slot]; qy[u] = X[P + slot]; qz[u] = X[2 * P + slot];
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (id[u] < C) {
+            if (id[u] != 0xFFFFFFFFu) {
                 const double dx = qx[u] - s.x, dy = qy[u] - s.y, dz = qz[u] - s.z;
                 const double d2 = dx * dx + dy * dy + dz * dz;
-                if (d2 < bd) { bd = d2; border = (unsigned)id[u]; bp = v3(qx[u], qy[u], qz[u]); }
+                if (d2 < bd || (d2 == bd && id[u] < border)) { bd = d2; border = id[u]; bp = v3(qx[u], qy[u], qz[u]); }
             }
         }
     }
@@ -582,8 +611,10 @@ __device__ __forceinline__ void grid_barrier(DevState* st, int G, int wg, int it
 
 // kiss.py:116-130 after the ICP: new pose, innovation (err_dt / err_drot), threshold model deviation, stats
 // row.  full != 0 => a real scan (trajectory + stats row, closes with finish_pending); 0 => ptl_icp_align.
+__device__ __forceinline__ const double* guess_src(const Ctx& c) { return c.ext_guess ? c.ext_guess : c.st->guess; }
 __device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_empty, int full) {
-    Rt guess = rt_from16(st->guess);
+    Rt guess = rt_from16(guess_src(c));
+    if (c.ext_guess) rt_to16(guess, st->guess);
     Rt np = map_empty ? guess : rt_mul(rt_from16(st->T_icp), guess);
     rt_to16(np, st->new_pose);
     if (!full) return;
@@ -648,7 +679,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         if (lane32 >= 21) { ia = lane32 - 21; ib = 6; }
     }
     if (tid < 12) {
-        Rt g = (mode != 1) ? rt_from16(st->guess) : rt_identity();
+        Rt g = (mode != 1) ? rt_from16(guess_src(c)) : rt_identity();
         Esh[tid] = (tid < 9) ? g.R[tid] : g.t[tid - 9];
         Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
     }
@@ -691,7 +722,8 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         }
         const long long c1 = __builtin_readcyclecounter();
         // workgroup reduction in fixed order (column 28 carries the candidate count)
-        const long long ncand0 = __shfl(ncand, gbase);  // all lanes execute the shuffle
+        long long ncand0 = ncand;  // sum of the per-lane probe counts over the 32 lanes of the group
+        for (int o = 16; o > 0; o >>= 1) ncand0 += __shfl_xor(ncand0, o);
         {
             // workgroup reduction, fixed tree: the two groups of a wavefront, then 4 segments of wavefronts, then 4 -> 1
             const double mine = (lane32 == 28) ? (double)ncand0 : acc;
@@ -1067,7 +1099,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
     }
     if (tid < S * 12) {
         const int s = tid / 12, k = tid % 12;
-        const double* g = b.q[s].st->guess;
+        const double* g = guess_src(a[s].c);
         Esh[s][k] = (k < 9) ? g[4 * (k / 3) + (k % 3)] : g[4 * (k - 9) + 3];
         Tsh[s][k] = (k < 9) ? ((k % 4 == 0) ? 1.0 : 0.0) : 0.0;
     }
@@ -1121,7 +1153,8 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
                     else if (lane32 == 27) acc += 1.0;
                 }
             }
-            const long long ncand0 = __shfl(ncand, gbase);
+            long long ncand0 = ncand;
+            for (int o = 16; o > 0; o >>= 1) ncand0 += __shfl_xor(ncand0, o);
             const double mine = (lane32 == 28) ? (double)ncand0 : acc;
             const double pair = mine + __shfl_xor(mine, 32);
             if ((tid & 63) < 32) red[s][tid >> 6][lane32] = pair;

@@ -55,6 +55,9 @@ struct ptl_icp {
     bool prof;
     std::vector<hipEvent_t> ev;
     size_t ev_used;
+    // set by the sequence runner: the GN kernel waits for `gn_wait` (the EKF stream produced the guess) and
+    // `gn_done` is recorded right after it (the EKF update may start while the map update still runs)
+    hipEvent_t gn_wait, gn_done;
     double gn_ms;
     int64_t gn_launches;
 };
@@ -144,6 +147,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     h->own_stream = shared_stream == nullptr;
     h->stream = shared_stream;
     h->prof = false; h->ev_used = 0; h->gn_ms = 0; h->gn_launches = 0;
+    h->gn_wait = nullptr; h->gn_done = nullptr;
     h->d_in = nullptr; h->d_t01 = nullptr; h->d_ext = nullptr; h->d_counter = nullptr; h->d_row_mask = nullptr;
     memset(&h->c, 0, sizeof(Ctx));
     if (h->own_stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -256,6 +260,7 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     k_vds2<<<nb, 256, 0, s>>>(c);
     k_compact_fd<<<nb, 256, 0, s>>>(c);
     k_compact_src<<<nb, 256, 0, s>>>(c);
+    if (h->gn_wait) HIPCHK(hipStreamWaitEvent(s, h->gn_wait, 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         if (h->ev_used + 2 > h->ev.size()) {
@@ -266,6 +271,7 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     }
     if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0);  // ends with the post-ICP bookkeeping (kiss.py:116-128)
     if (h->prof) HIPCHK(hipEventRecord(e1, s));
+    if (h->gn_done) HIPCHK(hipEventRecord(h->gn_done, s));
     // local_map.update(frame_downsample, new_pose)  (kiss.py:129)
     k_map_insert_a<<<nb, 256, 0, s>>>(c, c.fd, &c.st->n_down, 0, 1);
     k_map_insert_b<<<nb, 256, 0, s>>>(c, &c.st->n_down, 0);
@@ -728,6 +734,11 @@ extern "C" int ptl_ekf_ts(ptl_ekf* h, double* ts) {
 struct ptl_seq {
     ptl_seq_cfg cfg;
     hipStream_t stream;
+    // The EKF launches run on their own stream: the update with scan k's pose and the IMU predicts up to scan k+1
+    // overlap scan k's map update and scan k+1's deskew / downsampling; only the GN kernel waits for the EKF
+    // (its guess), and the EKF waits for the GN kernel (the pose measurement).
+    hipStream_t ekf_stream;
+    hipEvent_t ev_guess, ev_gn;
     ptl_icp* icp;
     ptl_ekf* ekf;
     float* d_scans;      // [n_scans][pps][3] f32
@@ -753,6 +764,9 @@ extern "C" int ptl_seq_destroy(ptl_seq* s) {
     if (s->d_res_poses) hipFree(s->d_res_poses);
     if (s->d_res_t) hipFree(s->d_res_t);
     if (s->d_rows) hipFree(s->d_rows);
+    if (s->ev_guess) hipEventDestroy(s->ev_guess);
+    if (s->ev_gn) hipEventDestroy(s->ev_gn);
+    if (s->ekf_stream) hipStreamDestroy(s->ekf_stream);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
     return PTL_OK;
@@ -766,14 +780,21 @@ extern "C" int ptl_seq_create(const ptl_seq_cfg* cfg, ptl_seq** out) {
     s->cfg = *cfg;
     s->icp = nullptr; s->ekf = nullptr; s->d_scans = nullptr; s->d_imu = nullptr;
     s->d_res_poses = nullptr; s->d_res_t = nullptr; s->d_rows = nullptr; s->n_out = 0; s->stream = nullptr;
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return set_err(PTL_ERR_HIP, "stream"); }
+    s->ekf_stream = nullptr; s->ev_guess = nullptr; s->ev_gn = nullptr;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->ekf_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_guess, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_gn, hipEventDisableTiming) != hipSuccess) {
+        ptl_seq_destroy(s);
+        return set_err(PTL_ERR_HIP, "stream / event creation failed");
+    }
     ptl_icp_cfg ic = cfg->icp;
     if (ic.max_points_per_scan < cfg->points_per_scan) ic.max_points_per_scan = cfg->points_per_scan;
     s->cfg.icp = ic;
     ptl_ekf_cfg ec = cfg->ekf;
     ec.device_id = ic.device_id;
     int rc = icp_create_impl(&ic, s->stream, &s->icp);
-    if (rc == PTL_OK) rc = ekf_create_impl(&ec, s->stream, &s->ekf);
+    if (rc == PTL_OK) rc = ekf_create_impl(&ec, s->ekf_stream, &s->ekf);
     const size_t nim = cfg->n_imu > 0 ? (size_t)cfg->n_imu : 1;
     if (rc == PTL_OK &&
         (hipMalloc((void**)&s->d_scans, (size_t)cfg->n_scans * cfg->points_per_scan * 12) != hipSuccess ||
@@ -841,34 +862,42 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
     const double* guess_ptr = (with_ekf && s->cfg.use_imu_prediction) ? (const double*)((char*)s->ekf->st + offsetof(EkfState, pose)) : nullptr;
     const size_t pps = (size_t)s->cfg.points_per_scan;
     const int64_t end = s->next_scan + n;
+    hipStream_t es = s->ekf_stream;
     for (int64_t k = s->next_scan; k < end; ++k) {
         // IMU samples that precede scan k and were not consumed yet (only before the very first scan of a run,
         // or when the previous scan was skipped: otherwise the previous scan's EKF launch already ran them)
         const int64_t e = with_ekf ? s->imu_end[(size_t)k] : s->imu_pos;
         if (e > s->imu_pos) {
-            k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+            k_ekf_step<<<1, 384, 0, es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
             s->imus_per_scan += e - s->imu_pos;
             s->imu_pos = e;
         }
         s->next_scan = k + 1;
         if (with_ekf && !s->imus_per_scan) continue;  // ekf_bench.py:512-518
         s->imus_per_scan = 0;
+        if (with_ekf) {
+            if (guess_ptr) HIPCHK(hipEventRecord(s->ev_guess, es));  // the EKF nav pose scan k starts from
+            s->icp->gn_wait = guess_ptr ? s->ev_guess : nullptr;
+            s->icp->gn_done = s->ev_gn;
+        }
         int rc;
         if (s->is_range[(size_t)k]) {
-            if (!s->lut) return set_err(PTL_ERR_STATE, "scan %lld is a range image but no LUT was set", (long long)k);
-            rc = icp_enqueue_scan(s->icp, nullptr, nullptr, nullptr, (int64_t)pps, guess_ptr,
-                                  (const unsigned*)(s->d_scans + (size_t)k * pps * 3), s->lut);
+            if (!s->lut) rc = set_err(PTL_ERR_STATE, "scan %lld is a range image but no LUT was set", (long long)k);
+            else rc = icp_enqueue_scan(s->icp, nullptr, nullptr, nullptr, (int64_t)pps, guess_ptr,
+                                       (const unsigned*)(s->d_scans + (size_t)k * pps * 3), s->lut);
         } else {
             rc = icp_enqueue_scan(s->icp, s->d_scans + (size_t)k * pps * 3, nullptr, nullptr, (int64_t)pps, guess_ptr);
         }
+        s->icp->gn_wait = nullptr; s->icp->gn_done = nullptr;
         if (rc) return rc;
         const int64_t o = s->n_out;
         const double* kiss_pose = s->icp->c.traj + 16 * (s->icp->scans_done - 1);
         if (with_ekf) {
             // one launch: update with scan k's pose, then predict through the IMU samples up to scan k+1
+            HIPCHK(hipStreamWaitEvent(es, s->ev_gn, 0));
             const int64_t e2 = (k + 1 < s->cfg.n_scans) ? s->imu_end[(size_t)k + 1] : s->imu_pos;
-            k_ekf_step<<<1, 384, 0, s->stream>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e2, kiss_pose, nullptr,
-                                                s->d_res_poses + 16 * o, s->d_res_t + o, s->d_rows + 8 * o, 1);
+            k_ekf_step<<<1, 384, 0, es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e2, kiss_pose, nullptr,
+                                         s->d_res_poses + 16 * o, s->d_res_t + o, s->d_rows + 8 * o, 1);
             s->imus_per_scan += e2 - s->imu_pos;
             s->imu_pos = e2;
         }
@@ -881,7 +910,9 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
 extern "C" int ptl_seq_wait(ptl_seq* s) {
     if (!s) return set_err(PTL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(s->cfg.icp.device_id));
-    return icp_check_flags(s->icp);
+    int rc = icp_check_flags(s->icp);
+    HIPCHK(hipStreamSynchronize(s->ekf_stream));
+    return rc;
 }
 extern "C" int ptl_seq_run(ptl_seq* s, int64_t n) {
     if (!s || n < 0 || n > s->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
@@ -902,6 +933,7 @@ extern "C" int ptl_seq_copy_traj(ptl_seq* s, void* dst_device, int64_t max_rows,
     if (!s->cfg.with_ekf) return set_err(PTL_ERR_STATE, "trajectory rows need with_ekf");
     HIPCHK(hipSetDevice(s->cfg.icp.device_id));
     const int64_t n = s->n_out < max_rows ? s->n_out : max_rows;
+    HIPCHK(hipStreamSynchronize(s->ekf_stream));
     if (n > 0) HIPCHK(hipMemcpyAsync(dst_device, s->d_rows, (size_t)n * 64, hipMemcpyDeviceToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (rows) *rows = n;
@@ -918,6 +950,7 @@ extern "C" int ptl_seq_results(ptl_seq* s, double* res_poses, double* res_t, dou
     HIPCHK(hipSetDevice(s->cfg.icp.device_id));
     const int64_t n = s->n_out < max_n ? s->n_out : max_n;
     HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipStreamSynchronize(s->ekf_stream));
     if (n > 0) {
         if (res_poses && s->cfg.with_ekf) HIPCHK(hipMemcpy(res_poses, s->d_res_poses, (size_t)n * 128, hipMemcpyDeviceToHost));
         if (res_t && s->cfg.with_ekf) HIPCHK(hipMemcpy(res_t, s->d_res_t, (size_t)n * 8, hipMemcpyDeviceToHost));
