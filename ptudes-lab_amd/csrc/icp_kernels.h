@@ -436,122 +436,112 @@ __device__ __forceinline__ int map_find(const CT& c, unsigned long long key) {
     return -1;
 }
 
-// 32 lanes cooperate on one source point.  Lanes 0..26 probe the 27 neighbour voxels in (i,j,k) ascending
-// order; a probe returns block id and point count together.  The point's own voxel is scanned first; neighbour
-// voxels whose box lies farther than the best distance found there are dropped (exact: see stage A below).  The
-// candidates of the remaining voxels form ONE flat list in (voxel order, insertion order) - upstream's visiting
-// order - and lane l takes candidates l, l+32, l+64, ...; four are loaded per round before any is consumed.  `ck` / `cblk` carry the centre voxel and
-// this lane's probe result from the previous call: the map is constant during a Gauss-Newton loop, so when the
-// point has not left its voxel the probes are skipped.
-// Returns in every lane of the group: best squared distance, best target, found flag; adds candidates to ncand.
+// (int)(x / vs) - the voxel index of VoxelHashMap / VoxelDownsample (C truncation) - without the fp64 division in the
+// common case: q = x * (1 / vs) differs from the correctly rounded quotient by a few ulp, so both truncate alike
+// unless an integer lies within 1e-9 (|q| + 1) of q; only then is the real division evaluated.
+__device__ __forceinline__ int voxel_index(double x, double vs, double inv_vs) {
+    const double q = x * inv_vs;
+    int k = (int)q;
+    if (fabs(q - rint(q)) <= 1e-9 * (fabs(q) + 1.0)) k = (int)(x / vs);
+    return k;
+}
+
+// 32 lanes cooperate on one source point.  Lanes 0..26 probe the 27 neighbour voxels in (i,j,k) ascending order
+// (upstream's visiting order); a probe returns block id and point count together.  `ck` / `cblk` carry the centre
+// voxel and this lane's probe result from the previous call: the map is constant during a Gauss-Newton loop, so
+// when the point has not left its voxel the probes are skipped.  The point's own voxel is scanned first (lane l <->
+// its l-th stored point, one coalesced read per coordinate); a neighbour voxel whose box lies farther than the
+// best distance found there cannot hold a strictly closer point and is dropped - exact, because a candidate
+// replaces the incumbent only when strictly closer or equally close and earlier in visiting order, and a dropped
+// voxel can offer neither.  The surviving voxels are scanned two at a time.
+// Returns in every lane of the group: best squared distance, best target, found flag; adds this lane's probe
+// count to ncand (the caller sums the lanes).
 template <int PC, class CT>
 __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
                                             long long& ncand, unsigned long long& ck, int& cblk, bool use_cache) {
     const int P = (PC > 0) ? PC : c.P;  // compile-time for the default 20: y / z become immediate offsets of x
-    const int kx = (int)(s.x / c.vs), ky = (int)(s.y / c.vs), kz = (int)(s.z / c.vs);
+    const double inv_vs = 1.0 / c.vs;   // loop-invariant
+    const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
     const unsigned long long key = pack_key(kx, ky, kz);
+    const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
     int pb = -1;
     if (use_cache && key == ck) {
         pb = cblk;
     } else if (lane32 < 27) {
-        const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
         pb = map_find(c, pack_key(kx + di, ky + dj, kz + dk));
     }
     ck = key;
     cblk = pb;
     const int cnt0 = (pb < 0) ? 0 : (int)((unsigned)pb >> 24);
-    const int blk = pb & BLK_ID_MASK;
-    ncand += cnt0;  // per lane; the caller sums the 32 lanes once per iteration
+    ncand += cnt0;
     double bd = 1.7976931348623157e308;
     unsigned border = 0xFFFFFFFFu;  // visiting order of a candidate: voxel lane * 32 + slot
     V3 bp = v3(0, 0, 0);
-    // Stage A: the point's own voxel (lane 13).  Its best distance bounds the search: a neighbour voxel whose box is
-    // farther than that cannot hold a strictly closer point, and equal distances lose to nothing they could beat
-    // only when strictly farther, so the (distance, visiting order) minimum is unchanged by skipping it.
-    int cnt = cnt0;
-    const int cntc = __shfl(cnt0, gbase + 13);
-    if (cntc > 0) {  // uniform over the group
-        const int blkc = __shfl(blk, gbase + 13);
-        if (lane32 < cntc) {
-            const double* X = blk_x(c, blkc);
+    bool keep = lane32 != 13 && cnt0 > 0;
+    const int pbc = __shfl(pb, gbase + 13);
+    if (pbc >= 0) {  // uniform over the group (a stored voxel holds at least one point)
+        if (lane32 < (int)((unsigned)pbc >> 24)) {
+            const double* X = blk_x(c, pbc & BLK_ID_MASK);
             const double qx = X[lane32], qy = X[P + lane32], qz = X[2 * P + lane32];
             const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
             bd = dx * dx + dy * dy + dz * dz;
             border = 13u * 32u + (unsigned)lane32;
             bp = v3(qx, qy, qz);
         }
-        // box of this lane's voxel under truncation toward zero: index 0 spans (-vs, vs), k > 0 [k vs, (k+1) vs),
-        // k < 0 ((k-1) vs, k vs]; 1 nm of slack covers the rounding of x / vs at any coordinate the key range allows
+        // distance from the point to this lane's voxel box.  Under truncation toward zero index 0 spans (-vs, vs),
+        // v > 0 spans [v vs, (v+1) vs), v < 0 spans ((v-1) vs, v vs]; 1 nm of slack covers the rounding of x / vs
+        const int d[3] = {di, dj, dk}, k[3] = {kx, ky, kz};
+        const double x[3] = {s.x, s.y, s.z};
         double gap2 = 0.0;
-        if (lane32 < 27) {
-            const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
-            const int v[3] = {kx + di, ky + dj, kz + dk};
-            const double x[3] = {s.x, s.y, s.z};
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double lo = (double)(v[a] > 0 ? v[a] : v[a] - 1) * c.vs, hi = (double)(v[a] < 0 ? v[a] : v[a] + 1) * c.vs;
-                double g = fmax(fmax(lo - x[a], x[a] - hi), 0.0) - 1e-9;
-                g = fmax(g, 0.0);
-                gap2 += g * g;
-            }
+        for (int a = 0; a < 3; ++a) {
+            const int v = k[a] + d[a];
+            const int bi = (d[a] > 0) ? (v > 0 ? v : v - 1) : (v < 0 ? v : v + 1);  // near face of the box
+            double g = ((double)bi * c.vs - x[a]) * (double)d[a] - 1e-9;
+            g = (d[a] == 0) ? 0.0 : fmax(g, 0.0);
+            gap2 += g * g;
         }
         double m = bd;
         for (int o = 16; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));
-        if (lane32 == 13 || gap2 > m) cnt = 0;
+        keep = keep && !(gap2 > m);
     }
-    // exclusive prefix of the remaining counts over the 32 lanes of the group (lanes >= 27 hold 0)
-    int incl = cnt;
-    for (int o = 1; o < 32; o <<= 1) {
-        const int up = __shfl_up(incl, o, 32);
-        if (lane32 >= o) incl += up;
-    }
-    const int excl = incl - cnt;
-    const int C = __shfl(incl, gbase + 31);
-    for (int base = 0; base < C; base += 128) {
-        double qx[4], qy[4], qz[4];
-        unsigned id[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = base + 32 * u + lane32;
-            // owner voxel of candidate idx: largest lane v with excl(v) <= idx (binary search over the group); among
-            // lanes sharing a prefix that is the one holding points
-            int v = 0;
-#pragma unroll
-            for (int st = 16; st > 0; st >>= 1) {
-                const int mid = v + st;
-                const int e = __shfl(excl, gbase + (mid & 31));
-                if (mid < 27 && e <= idx) v = mid;
-            }
-            const int bv = __shfl(blk, gbase + v);
-            const int ev = __shfl(excl, gbase + v);
-            qx[u] = 0.0; qy[u] = 0.0; qz[u] = 0.0;
-            id[u] = 0xFFFFFFFFu;
-            if (idx < C) {
-                const double* X = blk_x(c, bv);
-                const int slot = idx - ev;
-                id[u] = (unsigned)(v * 32 + slot);
-                qx[u] = X[slot]; qy[u] = X[P + slot]; qz[u] = X[2 * P + slot];
-            }
+    unsigned todo = (unsigned)(__ballot(keep) >> gbase);  // this group's surviving voxels, visited in ascending order
+    while (todo) {
+        const int v0 = __ffs(todo) - 1;
+        todo &= todo - 1;
+        const int v1 = todo ? __ffs(todo) - 1 : v0;
+        const bool two = todo != 0;
+        todo &= todo - 1;
+        const int pb0 = __shfl(pb, gbase + v0), pb1 = __shfl(pb, gbase + v1);
+        const bool a0 = lane32 < (int)((unsigned)pb0 >> 24), a1 = two && lane32 < (int)((unsigned)pb1 >> 24);
+        double q0x = 0.0, q0y = 0.0, q0z = 0.0, q1x = 0.0, q1y = 0.0, q1z = 0.0;
+        if (a0) { const double* X = blk_x(c, pb0 & BLK_ID_MASK); q0x = X[lane32]; q0y = X[P + lane32]; q0z = X[2 * P + lane32]; }
+        if (a1) { const double* X = blk_x(c, pb1 & BLK_ID_MASK); q1x = X[lane32]; q1y = X[P + lane32]; q1z = X[2 * P + lane32]; }
+        if (a0) {
+            const double dx = q0x - s.x, dy = q0y - s.y, dz = q0z - s.z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            const unsigned id = (unsigned)(v0 * 32 + lane32);
+            if (d2 < bd || (d2 == bd && id < border)) { bd = d2; border = id; bp = v3(q0x, q0y, q0z); }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (id[u] != 0xFFFFFFFFu) {
-                const double dx = qx[u] - s.x, dy = qy[u] - s.y, dz = qz[u] - s.z;
-                const double d2 = dx * dx + dy * dy + dz * dz;
-                if (d2 < bd || (d2 == bd && id[u] < border)) { bd = d2; border = id[u]; bp = v3(qx[u], qy[u], qz[u]); }
-            }
+        if (a1) {
+            const double dx = q1x - s.x, dy = q1y - s.y, dz = q1z - s.z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            const unsigned id = (unsigned)(v1 * 32 + lane32);
+            if (d2 < bd || (d2 == bd && id < border)) { bd = d2; border = id; bp = v3(q1x, q1y, q1z); }
         }
     }
-    // lexicographic (d2, candidate order) minimum over the 32 lanes of the group
-    for (int o = 16; o > 0; o >>= 1) {
-        const double od = __shfl_xor(bd, o);
-        const unsigned oo = __shfl_xor(border, o);
-        const double ox = __shfl_xor(bp.x, o), oy = __shfl_xor(bp.y, o), oz = __shfl_xor(bp.z, o);
-        if (od < bd || (od == bd && oo < border)) { bd = od; border = oo; bp = v3(ox, oy, oz); }
-    }
-    best = bp;
-    best_d2 = bd;
-    return border != 0xFFFFFFFFu;
+    // lexicographic (d2, visiting order) minimum over the 32 lanes: the distance, then the order among the lanes
+    // that hold it, then the winner lane hands out its point
+    double m = bd;
+    for (int o = 16; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));
+    unsigned bo = (bd == m) ? border : 0xFFFFFFFFu;
+    for (int o = 16; o > 0; o >>= 1) bo = min(bo, (unsigned)__shfl_xor((int)bo, o));
+    const bool found = bo != 0xFFFFFFFFu;
+    const unsigned win = (unsigned)(__ballot(found && bd == m && border == bo) >> gbase);
+    const int wl = gbase + (win ? __ffs(win) - 1 : 0);
+    best = v3(__shfl(bp.x, wl), __shfl(bp.y, wl), __shfl(bp.z, wl));
+    best_d2 = m;
+    return found;
 }
 
 // column `idx` of the 3x7 matrix [ I | -hat(s) | r ]: the Jacobian J = [I | -hat(s)] of Registration.cpp
@@ -686,7 +676,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     __syncthreads();
     long long cand_total = 0;
     int iters = 0, ncorr_last = 0;
-    long long ph[5] = {0, 0, 0, 0, 0};
+    long long ph[5] = {0, 0, 0, 0, 0}, ph_wait = 0;
     // one point per 32-lane group for the whole loop => its probe results can be cached across iterations
     const bool single_pass = ((G & 7) == 0) ? (((n + 7) >> 3) <= (G >> 3) * NG) : (n <= G * NG);
     unsigned long long ckey = EMPTY_KEY;
@@ -731,6 +721,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             if ((tid & 63) < 32) red[tid >> 6][lane32] = pair;
         }
         __syncthreads();
+        const long long c1b = __builtin_readcyclecounter();
         double* part = c.partials + ((size_t)(it & 1) * G + wg) * 32;
         if (tid < 128) {
             const int col = tid & 31, seg = tid >> 5, NW = NG >> 1, per = (NW + 3) >> 2;
@@ -795,6 +786,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         __syncthreads();
         const long long c5 = __builtin_readcyclecounter();
         ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
+        ph_wait += c1b - c1;
         cand_total += (long long)tot[28];
         ncorr_last = (int)tot[27];
         iters = it + 1;
@@ -813,6 +805,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         st->gn_cand = cand_total;
         for (int k = 0; k < 5; ++k) st->gn_phase_clk[k] += ph[k];
         st->gn_phase_clk[5] += iters;
+        st->gn_phase_clk[6] += ph_wait;  // part of phase 1 spent waiting for the workgroup's other wavefronts
         if (mode != 1) gn_post(c, st, false, mode == 0);
     }
 }

@@ -1,5 +1,6 @@
 import sys, ctypes as C, numpy as np
-sys.path.insert(0,'/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ptudes_lab_amd
 from ptudes_lab_amd import core, synth, _lib as L
 n=60
@@ -12,4 +13,4 @@ r.run()
 icp = C.c_void_p(); L.check(L.lib().ptl_seq_icp(r._h, C.byref(icp)))
 out = (C.c_int64*8)(); L.check(L.lib().ptl_icp_gn_phases(icp, out))
 o = np.array(list(out), dtype=float); it=o[5]
-print("iters", it, "ticks/iter: nn %.0f wgred %.0f barrier %.0f gridred %.0f solve %.0f" % tuple(o[:5]/it), "total/iter", o[:5].sum()/it)
+print("iters", it, "ticks/iter: nn %.0f wgred %.0f barrier %.0f gridred %.0f solve %.0f" % tuple(o[:5]/it), "total/iter", o[:5].sum()/it, "| of wgred, waiting for own WG: %.0f" % (o[6]/it))
