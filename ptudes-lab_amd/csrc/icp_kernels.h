@@ -558,6 +558,65 @@ __device__ __forceinline__ V3 jcol(int idx, V3 s, V3 r) {
     }
 }
 
+// solve6_ldlt() spread over a wavefront: lane i < 6 owns row i of the factorisation; pivots, the pivot row and the
+// finished unknowns travel by v_readlane.  Every product and difference is the one solve6_ldlt() forms, in the same
+// order, so dx is bit-identical to the single-lane version - with about half the instructions on the critical
+// path of each Gauss-Newton iteration.  All 64 lanes must call it; all return dx.
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ void solve6_ldlt_wave(const double* s, int lane, double dx[6]) {
+    const int i = lane < 6 ? lane : 5;  // lanes >= 6 shadow row 5 (their results are never read)
+    double A[6], L[6], D[6];
+    // row i of the symmetric matrix from the packed upper triangle: entry (r, c), r <= c, sits at r (11 - r) / 2 + c
+#pragma unroll
+    for (int cidx = 0; cidx < 6; ++cidx) {
+        const int r = i < cidx ? i : cidx, cc = i < cidx ? cidx : i;
+        A[cidx] = s[r * (11 - r) / 2 + cc];
+        L[cidx] = 0.0;
+    }
+    double Dmine = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double v = A[j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < j) v -= L[k] * lane_bcast(L[k], j) * D[k];
+        const double d = lane_bcast(v, j);
+        D[j] = d;
+        if (i == j) Dmine = d;
+        L[j] = (i > j) ? ((d != 0.0) ? v / d : 0.0) : ((i == j) ? 1.0 : 0.0);
+    }
+    double y = -s[21 + i];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double yk = lane_bcast(y, k);
+        if (i > k) y -= L[k] * yk;
+    }
+    y = (Dmine != 0.0) ? y / Dmine : 0.0;
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+        double v = lane_bcast(y, r);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k > r) v -= lane_bcast(L[r], k) * dx[k];
+        dx[r] = v;
+    }
+}
+
+// Tsh <- Esh * Tsh (both 3x3 row-major + translation in LDS)
+__device__ __forceinline__ void gn_compose(const double* Esh, double* Tsh) {
+    Rt e, T;
+    for (int k = 0; k < 9; ++k) { e.R[k] = Esh[k]; T.R[k] = Tsh[k]; }
+    for (int k = 0; k < 3; ++k) { e.t[k] = Esh[9 + k]; T.t[k] = Tsh[9 + k]; }
+    T = rt_mul(e, T);
+    for (int k = 0; k < 9; ++k) Tsh[k] = T.R[k];
+    for (int k = 0; k < 3; ++k) Tsh[9 + k] = T.t[k];
+}
+
 // Source point -> workgroup assignment.  Workgroups with the same (wg & 7) run on one XCD (observed dispatch,
 // used for speed only) and share its 4 MB L2, so each such set gets one CONTIGUOUS eighth of the scan-ordered
 // source points (a band of beams): the map voxels it probes then stay resident in that XCD's L2.
@@ -683,6 +742,9 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     int cblk = -1;
     for (int it = 0; it < max_iter; ++it) {
         const long long c0 = __builtin_readcyclecounter();
+        // T_icp <- e T_icp for the previous iteration's increment, off the serial tail: one lane of the second
+        // wavefront does it while everybody searches (Esh is not rewritten before the next solve)
+        if (tid == 64 && it > 0) gn_compose(Esh, Tsh);
         double acc = 0.0;
         long long ncand = 0;
         const PointWalk pw = point_walk(n, G, wg, NG, grp);
@@ -769,19 +831,17 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         }
         __syncthreads();
         const long long c4 = __builtin_readcyclecounter();
-        if (tid == 0) {
+        if (tid < 64) {  // one wavefront; every lane ends up with the same dx, lane 0 publishes
             double dx[6];
-            solve6_ldlt(tot, dx);
-            Rt e = se3_exp(dx);
-            Rt T;
-            for (int k = 0; k < 9; ++k) T.R[k] = Tsh[k];
-            for (int k = 0; k < 3; ++k) T.t[k] = Tsh[9 + k];
-            T = rt_mul(e, T);
-            for (int k = 0; k < 9; ++k) { Esh[k] = e.R[k]; Tsh[k] = T.R[k]; }
-            for (int k = 0; k < 3; ++k) { Esh[9 + k] = e.t[k]; Tsh[9 + k] = T.t[k]; }
+            solve6_ldlt_wave(tot, tid, dx);
+          if (tid == 0) {
+            const Rt e = se3_exp_gn(dx);
+            for (int k = 0; k < 9; ++k) Esh[k] = e.R[k];
+            for (int k = 0; k < 3; ++k) Esh[9 + k] = e.t[k];
             double nn = 0.0;
             for (int k = 0; k < 6; ++k) nn += dx[k] * dx[k];
             flag_done = (sqrt(nn) < c.conv) ? 1 : 0;
+          }
         }
         __syncthreads();
         const long long c5 = __builtin_readcyclecounter();
@@ -795,6 +855,8 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         __syncthreads();
         if (done) break;
     }
+    if (tid == 64 && iters > 0) gn_compose(Esh, Tsh);  // the last increment
+    __syncthreads();
     if (wg == 0 && tid == 0) {
         Rt T;
         for (int k = 0; k < 9; ++k) T.R[k] = Tsh[k];
@@ -1217,7 +1279,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
             const int s = tid >> 6;
             double dx[6];
             solve6_ldlt(tot[s], dx);
-            Rt e = se3_exp(dx);
+            Rt e = se3_exp_gn(dx);
             Rt T;
             for (int k = 0; k < 9; ++k) T.R[k] = Tsh[s][k];
             for (int k = 0; k < 3; ++k) T.t[k] = Tsh[s][9 + k];
