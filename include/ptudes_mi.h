@@ -150,6 +150,9 @@ int ptl_icp_profile(ptl_icp *h, int enable, double *gn_ms_total, int64_t *gn_lau
 /* diagnostic: accumulated clock ticks of workgroup 0 per phase of that kernel (nn, wg-reduce+publish, barrier,
  * grid-reduce, solve) and out[5] = iterations, since the handle was created / reset */
 int ptl_icp_gn_phases(ptl_icp *h, int64_t out[8]);
+/* diagnostic: ticks each Gauss-Newton workgroup spent in the search phase since creation; out holds 2 * gn_workgroups
+ * values (until the last / the first wavefront finished) */
+int ptl_icp_gn_wg_clocks(ptl_icp *h, int64_t *out, int32_t max_wgs);
 
 /* ------------------------------------------------------------------------------------------------
  * EKF handle == reference ESEKF (src/ptudes/ins/es_ekf.py:57-365)

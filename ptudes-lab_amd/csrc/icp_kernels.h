@@ -118,6 +118,7 @@ struct Ctx {
     double* traj;        // [T][16] kiss poses
     ScanStats* sstats;   // [T]
     const double* ext_guess;  // device 4x4 or null
+    long long* wg_clk;        // [2 G] diagnostic: ticks each GN workgroup spent in the search phase (all waves / first wave)
     int traj_cap;
 };
 
@@ -857,6 +858,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     }
     if (tid == 64 && iters > 0) gn_compose(Esh, Tsh);  // the last increment
     __syncthreads();
+    if (tid == 0 && c.wg_clk) { c.wg_clk[wg] += ph[0] + ph_wait; c.wg_clk[G + wg] += ph[0]; }  // diagnostic: search phase per workgroup
     if (wg == 0 && tid == 0) {
         Rt T;
         for (int k = 0; k < 9; ++k) T.R[k] = Tsh[k];

@@ -93,7 +93,7 @@ static int icp_free(ptl_icp* h) {
     (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
     void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, c.fd, c.src0,
-                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.partials,
+                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.partials, c.wg_clk,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter, h->d_row_mask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -189,6 +189,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= hipMalloc((void**)&c.blocks, (size_t)c.pool_cap * c.bstride) == hipSuccess;
     ok &= dalloc(&c.free_stack, c.pool_cap) == hipSuccess;
     ok &= dalloc(&c.partials, (size_t)2 * c.G * 32) == hipSuccess;
+    ok &= hipMalloc((void**)&c.wg_clk, (size_t)c.G * 16) == hipSuccess && hipMemset(c.wg_clk, 0, (size_t)c.G * 16) == hipSuccess;
     ok &= dalloc(&c.st, 1) == hipSuccess;
     ok &= dalloc(&c.traj, (size_t)h->traj_cap * 16) == hipSuccess;
     ok &= dalloc(&c.sstats, (size_t)h->traj_cap) == hipSuccess;
@@ -483,6 +484,16 @@ extern "C" int ptl_icp_align(ptl_icp* h, const double* frame, int64_t n, const d
     if (rc) return rc;
     memcpy(out_pose, st.new_pose, 128);
     if (iterations) *iterations = st.gn_iters;
+    return PTL_OK;
+}
+
+// diagnostic: ticks every GN workgroup spent in the search phase since creation: out[0..G) until its last wavefront
+// finished, out[G..2G) its first wavefront
+extern "C" int ptl_icp_gn_wg_clocks(ptl_icp* h, int64_t* out, int32_t max_wgs) {
+    if (!h || !out || max_wgs < h->c.G) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(out, h->c.wg_clk, (size_t)h->c.G * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return PTL_OK;
 }
 

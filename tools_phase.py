@@ -14,3 +14,10 @@ icp = C.c_void_p(); L.check(L.lib().ptl_seq_icp(r._h, C.byref(icp)))
 out = (C.c_int64*8)(); L.check(L.lib().ptl_icp_gn_phases(icp, out))
 o = np.array(list(out), dtype=float); it=o[5]
 print("iters", it, "ticks/iter: nn %.0f wgred %.0f barrier %.0f gridred %.0f solve %.0f" % tuple(o[:5]/it), "total/iter", o[:5].sum()/it, "| of wgred, waiting for own WG: %.0f" % (o[6]/it))
+
+G = kw.get("gn_workgroups", 256)
+wc = (C.c_int64 * (2 * G))(); L.check(L.lib().ptl_icp_gn_wg_clocks(icp, wc, G))
+w = np.array(list(wc), dtype=float).reshape(2, G) / it
+print("search phase per workgroup, ticks/iter (all waves): min %.0f median %.0f max %.0f; first wave: min %.0f median %.0f max %.0f" % (w[0].min(), np.median(w[0]), w[0].max(), w[1].min(), np.median(w[1]), w[1].max()))
+print("by XCD slot (wg & 7), all-waves mean:", np.round([w[0][x::8].mean() for x in range(8)]))
+print("slowest 8 workgroups:", np.argsort(w[0])[-8:], np.round(np.sort(w[0])[-8:]))
