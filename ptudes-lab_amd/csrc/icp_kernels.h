@@ -150,7 +150,9 @@ __device__ __forceinline__ unsigned long long pack_key(int kx, int ky, int kz) {
 __device__ __forceinline__ int vds_claim(unsigned long long* keys, unsigned mask, unsigned long long key) {
     unsigned s = (unsigned)mix64(key) & mask;
     for (unsigned probe = 0; probe <= mask; ++probe) {
-        unsigned long long cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // A plain (L2-cached) read: within a kernel a slot only ever goes EMPTY -> key, so the worst a stale line can
+        // show is EMPTY, and then the CAS below - performed at device scope - decides.
+        unsigned long long cur = keys[s];
         if (cur == key) return (int)s;
         if (cur == EMPTY_KEY) {
             unsigned long long old = atomicCAS(&keys[s], EMPTY_KEY, key);
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(256) void k_build_lut(int H, int W, const double* a
 __device__ __forceinline__ void d_deskew_vds1(const Ctx& c) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     DevState* st = c.st;
-    bool valid = false;
+    bool valid = false, keyed = false;
+    unsigned long long key = EMPTY_KEY;
     if (i < st->prev_n_in) {  // release the previous scan's pass-2 slot this point won (K4 still read them)
         const int s2 = c.slot2[i];
         if (s2 >= 0 && c.vmin2[s2] == (unsigned)i) { c.vkey2[s2] = EMPTY_KEY; c.vmin2[s2] = 0xFFFFFFFFu; }
@@ -307,19 +310,34 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c) {
         }
         const double r = sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
         valid = (r < c.max_range) && (r > c.min_range);
-        int slot = -1;
         if (valid) {
             c.pts[3 * (size_t)i] = p.x; c.pts[3 * (size_t)i + 1] = p.y; c.pts[3 * (size_t)i + 2] = p.z;
-            unsigned long long key; int kx, ky, kz;
-            if (!vox_key(p, c.vds1, key, kx, ky, kz)) { atomicOr(&st->err_flags, ERR_KEY_RANGE); }
-            else {
-                slot = vds_claim(c.vkey1, c.vmask, key);
-                if (slot < 0) atomicOr(&st->err_flags, ERR_VDS_TABLE);
-                else if (__hip_atomic_load(&c.vmin1[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)i)
-                    atomicMin(&c.vmin1[slot], (unsigned)i);  // the slot's value only ever decreases: a smaller one seen = nothing to do
-            }
+            int kx, ky, kz;
+            keyed = vox_key(p, c.vds1, key, kx, ky, kz);
+            if (!keyed) atomicOr(&st->err_flags, ERR_KEY_RANGE);
         }
-        c.slot1[i] = slot;
+    }
+    // Neighbours along a beam fall into the same voxel in long runs (hundreds of returns close to the sensor), and
+    // same-address atomics serialise at the memory side.  Only the first lane of each run of equal keys within the
+    // wavefront - the lowest index of the run, the only one that can win - claims the slot and bids for it; the others
+    // take the slot from it.
+    {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long prev = __shfl_up(key, 1);
+        const bool prev_keyed = __shfl_up(keyed ? 1 : 0, 1) != 0;
+        const bool head = keyed && (lane == 0 || !prev_keyed || prev != key);
+        int slot = -1;
+        if (head) {
+            slot = vds_claim(c.vkey1, c.vmask, key);
+            if (slot < 0) atomicOr(&st->err_flags, ERR_VDS_TABLE);
+            else if (c.vmin1[slot] > (unsigned)i)  // plain read: a stale (larger) value only costs a redundant atomicMin
+                atomicMin(&c.vmin1[slot], (unsigned)i);  // the slot's value only ever decreases: a smaller one seen = nothing to do
+        }
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long below = heads & (~0ull >> (63 - lane));
+        const int my_head = below ? 63 - __clzll((long long)below) : lane;
+        const int hs = __shfl(slot, my_head);
+        if (i < c.n_in) c.slot1[i] = keyed ? hs : -1;
     }
     const int nv = __syncthreads_count(valid ? 1 : 0);
     if (threadIdx.x == 0 && nv) atomicAdd(&st->n_valid, nv);
@@ -339,7 +357,7 @@ __device__ __forceinline__ void d_vds2(const Ctx& c) {
             vox_key(p, c.vds2, key, kx, ky, kz);
             slot = vds_claim(c.vkey2, c.vmask, key);
             if (slot < 0) atomicOr(&c.st->err_flags, ERR_VDS_TABLE);
-            else if (__hip_atomic_load(&c.vmin2[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)i)
+            else if (c.vmin2[slot] > (unsigned)i)
                 atomicMin(&c.vmin2[slot], (unsigned)i);
         }
         c.slot2[i] = slot;
@@ -893,7 +911,7 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
     } else {
         unsigned s = (unsigned)mix64(key) & c.tmask;
         for (unsigned probe = 0; probe <= c.tmask; ++probe) {
-            unsigned long long cur = __hip_atomic_load(&c.tab[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long cur = c.tab[s].key;  // plain read, as in vds_claim: EMPTY -> key is the only change in this kernel
             if (cur == key) { slot = (int)s; break; }
             if (cur == EMPTY_KEY) {
                 const unsigned long long old = atomicCAS(&c.tab[s].key, EMPTY_KEY, key);
