@@ -72,6 +72,8 @@ struct DevState {
     long long n_samples;
     double model_dev[16];
     int prev_n_in, pending_finish;
+    int n_down_ins;     // frame_down points of the scan whose map update is in flight (n_down belongs to the next scan's K3 already)
+    int stats_pending;  // scan whose map_voxels / map_points are still to be recorded once its map update is complete, or -1
     // map
     int pool_hw, pad2;
     int free_top, n_live;
@@ -118,6 +120,7 @@ struct Ctx {
     double* traj;        // [T][16] kiss poses
     ScanStats* sstats;   // [T]
     const double* ext_guess;  // device 4x4 or null
+    int overlap_pre;          // the next scan's K0-K4 run beside this scan's map update (own stream): see flush_map_stats
     long long* wg_clk;        // [2 G] diagnostic: ticks each GN workgroup spent in the search phase (all waves / first wave)
     int traj_cap;
 };
@@ -168,11 +171,19 @@ __device__ __forceinline__ int vds_claim(unsigned long long* keys, unsigned mask
 // (Threshold.cpp ComputeThreshold, stateful), initial guess (reference kiss.py:102-105 or the caller's).
 // bookkeeping that closes a scan (KissICP.poses.append, kiss.py:130); runs at the start of the next
 // scan's prologue or from k_finish_scan when the host wants to read state
+// map size after a scan's map update: recorded by the first single-threaded step that is ordered after that update -
+// the next prologue (one stream), or the next GN launch / k_finish_scan when the prologue overlaps the update
+__device__ __forceinline__ void flush_map_stats(const Ctx& c, DevState* st) {
+    const int k = st->stats_pending;
+    if (k < 0) return;
+    st->stats_pending = -1;
+    if (k < c.traj_cap) { c.sstats[k].map_voxels = st->n_live; c.sstats[k].map_points = st->map_points; }
+}
 __device__ __forceinline__ void finish_pending(const Ctx& c, DevState* st) {
     if (!st->pending_finish) return;
     st->pending_finish = 0;
     const int k = st->n_poses;
-    if (k < c.traj_cap) { c.sstats[k].map_voxels = st->n_live; c.sstats[k].map_points = st->map_points; }
+    if (!c.overlap_pre) flush_map_stats(c, st);  // single stream: the map update of scan k is complete here
     if (k == 0) for (int i = 0; i < 16; ++i) st->pose_first[i] = st->new_pose[i];
     for (int i = 0; i < 16; ++i) { st->pose_prev[i] = st->pose_last[i]; st->pose_last[i] = st->new_pose[i]; }
     st->n_poses = k + 1;
@@ -180,6 +191,7 @@ __device__ __forceinline__ void finish_pending(const Ctx& c, DevState* st) {
 __global__ void k_finish_scan(Ctx c) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     finish_pending(c, c.st);
+    flush_map_stats(c, c.st);
 }
 
 __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
@@ -701,6 +713,8 @@ __device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_emp
         c.sstats[k] = s;
     }
     st->pending_finish = 1;
+    st->n_down_ins = st->n_down;
+    st->stats_pending = k;
 }
 
 // Persistent Gauss-Newton loop (Registration.cpp RegisterFrame).  G workgroups, all resident; one grid
@@ -727,6 +741,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     const int NG = blockDim.x >> 5;
     const int G = gridDim.x, wg = blockIdx.x;
     const int n = st->n_src;
+    if (wg == 0 && tid == 0 && mode == 0) flush_map_stats(c, st);  // the previous scan's map update precedes this launch
     if (st->n_live == 0 && mode != 1) {  // voxel_map.Empty() => return initial_guess
         if (wg == 0 && tid == 0) {
             Rt I = rt_identity();
@@ -1104,17 +1119,17 @@ __global__ __launch_bounds__(256) void kb_compact_src(const SeqCtx* a, int scan_
 __global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_in, const int* n_ptr, int n_fixed, int use_pose) { d_map_insert_a(c, pts_in, n_ptr, n_fixed, use_pose); }
 __global__ __launch_bounds__(256) void kb_map_insert_a(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_insert_a(c, c.fd, &c.st->n_down, 0, 1);
+    d_map_insert_a(c, c.fd, &c.st->n_down_ins, 0, 1);
 }
 __global__ __launch_bounds__(256) void k_map_insert_b(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_b(c, n_ptr, n_fixed); }
 __global__ __launch_bounds__(256) void kb_map_insert_b(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_insert_b(c, &c.st->n_down, 0);
+    d_map_insert_b(c, &c.st->n_down_ins, 0);
 }
 __global__ __launch_bounds__(256) void k_map_insert_c(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_c(c, n_ptr, n_fixed); }
 __global__ __launch_bounds__(256) void kb_map_insert_c(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_insert_c(c, &c.st->n_down, 0);
+    d_map_insert_c(c, &c.st->n_down_ins, 0);
 }
 __global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_xyz, int use_new_pose) { d_map_prune(c, origin_xyz, use_new_pose); }
 __global__ __launch_bounds__(256) void kb_map_prune(const SeqCtx* a, int scan_k) {

@@ -58,6 +58,22 @@ struct ptl_icp {
     // set by the sequence runner: the GN kernel waits for `gn_wait` (the EKF stream produced the guess) and
     // `gn_done` is recorded right after it (the EKF update may start while the map update still runs)
     hipEvent_t gn_wait, gn_done;
+    // K0-K4 of a scan run on `pre_stream`, beside the previous scan's map update (K7-K10 on `stream`): they need the
+    // previous pose (ev_gn: recorded right after each GN launch) and the uploaded input (ev_in), not the map.
+    // frame_down is double-buffered so that K3 of scan k+1 does not overwrite what K7 of scan k still reads.
+    // set by the sequence runner when the next guess comes from the EKF: its step (update with this scan's pose, then
+    // the IMU predicts up to the next scan) is launched on `stream` right after the GN kernel - a cross-stream event
+    // costs ~20 us of wake-up latency on either side, more than the step's overlap with the map update would save
+    struct { EkfState* st; const double* imu; int i0, i1; double *res_pose, *res_t, *rows; bool on; } post_ekf;
+    // the map update (K7-K10, rebuild) runs on `map_stream`: it needs the GN result (ev_gn) and must be complete before
+    // the next GN launch (ev_map); beside it, on `stream`, runs whatever else follows the GN kernel (the inline EKF step)
+    hipStream_t map_stream;
+    hipEvent_t ev_map;
+    bool ev_map_valid;
+    hipStream_t pre_stream;
+    hipEvent_t ev_pre, ev_gn, ev_in;
+    bool ev_gn_valid, ev_in_pending;
+    double* fd_buf[2];
     double gn_ms;
     int64_t gn_launches;
 };
@@ -92,12 +108,16 @@ static int icp_free(ptl_icp* h) {
     if (!h) return PTL_OK;
     (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
-    void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, c.fd, c.src0,
+    void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, h->fd_buf[0], h->fd_buf[1], c.src0,
                     c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.partials, c.wg_clk,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter, h->d_row_mask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_pre, h->ev_gn, h->ev_in, h->ev_map})
+        if (e) (void)hipEventDestroy(e);
+    if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
+    if (h->map_stream) (void)hipStreamDestroy(h->map_stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PTL_OK;
@@ -114,6 +134,7 @@ __global__ void k_state_init(DevState* st, int pool_cap) {
     rt_to16(I, st->pose_first); rt_to16(I, st->pose_prev); rt_to16(I, st->pose_last);
     rt_to16(I, st->model_dev); rt_to16(I, st->guess); rt_to16(I, st->new_pose); rt_to16(I, st->T_icp);
     st->free_top = pool_cap;
+    st->stats_pending = -1;
 }
 
 static int icp_reset_device(ptl_icp* h) {
@@ -128,6 +149,10 @@ static int icp_reset_device(ptl_icp* h) {
     k_fill_free_stack<<<(c.pool_cap + 255) / 256, 256, 0, h->stream>>>(c.free_stack, c.pool_cap);
     k_state_init<<<1, 64, 0, h->stream>>>(c.st, c.pool_cap);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->pre_stream));
+    HIPCHK(hipStreamSynchronize(h->map_stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // the other streams must not start on half-reset tables
+    h->ev_gn_valid = false; h->ev_in_pending = false; h->ev_map_valid = false;
     h->scans_done = 0;
     h->last_n = 0;
     return PTL_OK;
@@ -148,6 +173,10 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     h->stream = shared_stream;
     h->prof = false; h->ev_used = 0; h->gn_ms = 0; h->gn_launches = 0;
     h->gn_wait = nullptr; h->gn_done = nullptr;
+    h->post_ekf.on = false;
+    h->map_stream = nullptr; h->ev_map = nullptr; h->ev_map_valid = false;
+    h->pre_stream = nullptr; h->ev_pre = nullptr; h->ev_gn = nullptr; h->ev_in = nullptr;
+    h->ev_gn_valid = false; h->ev_in_pending = false; h->fd_buf[0] = h->fd_buf[1] = nullptr;
     h->d_in = nullptr; h->d_t01 = nullptr; h->d_ext = nullptr; h->d_counter = nullptr; h->d_row_mask = nullptr;
     memset(&h->c, 0, sizeof(Ctx));
     if (h->own_stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -181,6 +210,15 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= dalloc(&c.vmin1, vcap) == hipSuccess && dalloc(&c.vmin2, vcap) == hipSuccess;
     ok &= dalloc(&c.bcnt1, h->nblk_scan) == hipSuccess && dalloc(&c.bcnt2, h->nblk_scan) == hipSuccess;
     ok &= dalloc(&c.fd, 3 * n) == hipSuccess && dalloc(&c.src0, 3 * n) == hipSuccess;
+    h->fd_buf[0] = c.fd;
+    ok &= dalloc(&h->fd_buf[1], 3 * n) == hipSuccess;
+    ok &= hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking) == hipSuccess;
+    ok &= hipStreamCreateWithFlags(&h->map_stream, hipStreamNonBlocking) == hipSuccess;
+    ok &= hipEventCreateWithFlags(&h->ev_map, hipEventDisableTiming) == hipSuccess;
+    ok &= hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) == hipSuccess;
+    ok &= hipEventCreateWithFlags(&h->ev_gn, hipEventDisableTiming) == hipSuccess;
+    ok &= hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess;
+    c.overlap_pre = 1;
     ok &= dalloc(&c.src_cur, 3 * n) == hipSuccess && dalloc(&c.fdw, 3 * n) == hipSuccess;
     ok &= dalloc(&c.coltab, (size_t)c.W * 12) == hipSuccess;
     ok &= dalloc(&c.pslot, n) == hipSuccess && dalloc(&c.nxt, n) == hipSuccess;
@@ -227,11 +265,11 @@ static int icp_grow_traj(ptl_icp* h) {
     return PTL_OK;
 }
 
-static int map_rebuild(ptl_icp* h) {
+static int map_rebuild(ptl_icp* h, hipStream_t s) {
     Ctx& c = h->c;
-    HIPCHK(hipMemsetAsync(c.tab, 0xFF, ((size_t)c.tmask + 1) * sizeof(TabEnt), h->stream));
-    HIPCHK(hipMemsetAsync(&c.st->tab_used, 0, sizeof(unsigned), h->stream));
-    k_map_rebuild<<<(c.pool_cap + 255) / 256, 256, 0, h->stream>>>(c);
+    HIPCHK(hipMemsetAsync(c.tab, 0xFF, ((size_t)c.tmask + 1) * sizeof(TabEnt), s));
+    HIPCHK(hipMemsetAsync(&c.st->tab_used, 0, sizeof(unsigned), s));
+    k_map_rebuild<<<(c.pool_cap + 255) / 256, 256, 0, s>>>(c);
     return PTL_OK;
 }
 
@@ -254,13 +292,22 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
         c.row_mask = h->d_row_mask;
     }
     const int nb = (int)((n + 255) / 256) > 0 ? (int)((n + 255) / 256) : 1;
-    hipStream_t s = h->stream;
+    hipStream_t s = h->stream, sp = h->pre_stream;
     const int nb1 = (int)(((n > h->last_n ? n : h->last_n) + 255) / 256) > 0 ? (int)(((n > h->last_n ? n : h->last_n) + 255) / 256) : 1;
-    k_scan_prologue<<<1, 1024, 0, s>>>(c);
-    k_deskew_vds1<<<nb1, 256, 0, s>>>(c);
-    k_vds2<<<nb, 256, 0, s>>>(c);
-    k_compact_fd<<<nb, 256, 0, s>>>(c);
-    k_compact_src<<<nb, 256, 0, s>>>(c);
+    // frame_down of this scan goes to the buffer the previous scan's map update is not reading
+    c.fd = h->fd_buf[h->scans_done & 1];
+    h->c.fd = c.fd;
+    // K0-K4 on the preprocessing stream: after the previous GN (pose) and the input upload, beside the previous K7-K10
+    if (h->ev_gn_valid) HIPCHK(hipStreamWaitEvent(sp, h->ev_gn, 0));
+    if (h->ev_in_pending) { HIPCHK(hipStreamWaitEvent(sp, h->ev_in, 0)); h->ev_in_pending = false; }
+    k_scan_prologue<<<1, 1024, 0, sp>>>(c);
+    k_deskew_vds1<<<nb1, 256, 0, sp>>>(c);
+    k_vds2<<<nb, 256, 0, sp>>>(c);
+    k_compact_fd<<<nb, 256, 0, sp>>>(c);
+    k_compact_src<<<nb, 256, 0, sp>>>(c);
+    HIPCHK(hipEventRecord(h->ev_pre, sp));
+    HIPCHK(hipStreamWaitEvent(s, h->ev_pre, 0));
+    if (h->ev_map_valid) HIPCHK(hipStreamWaitEvent(s, h->ev_map, 0));
     if (h->gn_wait) HIPCHK(hipStreamWaitEvent(s, h->gn_wait, 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
@@ -272,15 +319,24 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     }
     if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0);  // ends with the post-ICP bookkeeping (kiss.py:116-128)
     if (h->prof) HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventRecord(h->ev_gn, s));
+    h->ev_gn_valid = true;
     if (h->gn_done) HIPCHK(hipEventRecord(h->gn_done, s));
-    // local_map.update(frame_downsample, new_pose)  (kiss.py:129)
-    k_map_insert_a<<<nb, 256, 0, s>>>(c, c.fd, &c.st->n_down, 0, 1);
-    k_map_insert_b<<<nb, 256, 0, s>>>(c, &c.st->n_down, 0);
-    k_map_insert_c<<<nb, 256, 0, s>>>(c, &c.st->n_down, 0);
-    k_map_prune<<<(c.pool_cap + 255) / 256, 256, 0, s>>>(c, nullptr, 1);
+    if (h->post_ekf.on)
+        k_ekf_step<<<1, 384, 0, s>>>(h->post_ekf.st, h->post_ekf.imu, h->post_ekf.i0, h->post_ekf.i1, c.traj + 16 * (size_t)h->scans_done,
+                                    nullptr, h->post_ekf.res_pose, h->post_ekf.res_t, h->post_ekf.rows, 1);
+    // local_map.update(frame_downsample, new_pose)  (kiss.py:129), on the map stream
+    hipStream_t sm = h->map_stream;
+    HIPCHK(hipStreamWaitEvent(sm, h->ev_gn, 0));
+    k_map_insert_a<<<nb, 256, 0, sm>>>(c, c.fd, &c.st->n_down_ins, 0, 1);
+    k_map_insert_b<<<nb, 256, 0, sm>>>(c, &c.st->n_down_ins, 0);
+    k_map_insert_c<<<nb, 256, 0, sm>>>(c, &c.st->n_down_ins, 0);
+    k_map_prune<<<(c.pool_cap + 255) / 256, 256, 0, sm>>>(c, nullptr, 1);
     h->last_n = n;
     h->scans_done++;
-    if (h->cfg.rebuild_every > 0 && (h->scans_done % h->cfg.rebuild_every) == 0) { int rc = map_rebuild(h); if (rc) return rc; }
+    if (h->cfg.rebuild_every > 0 && (h->scans_done % h->cfg.rebuild_every) == 0) { int rc = map_rebuild(h, sm); if (rc) return rc; }
+    HIPCHK(hipEventRecord(h->ev_map, sm));
+    h->ev_map_valid = true;
     HIPCHK(hipGetLastError());
     return PTL_OK;
 }
@@ -295,6 +351,7 @@ static void icp_collect_profile(ptl_icp* h) {
 
 static int icp_check_flags(ptl_icp* h) {
     int flags = 0;
+    HIPCHK(hipStreamSynchronize(h->map_stream));  // the last scan's map update
     k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);  // closes the last scan's bookkeeping (no-op when none is pending)
     HIPCHK(hipMemcpyAsync(&flags, &h->c.st->err_flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -322,10 +379,13 @@ extern "C" int ptl_icp_register_frame(ptl_icp* h, const void* xyz, int dtype, in
     if (n) HIPCHK(hipMemcpyAsync(h->d_in, xyz, (size_t)n * 3 * esz, hipMemcpyHostToDevice, h->stream));
     if (t01 && n) HIPCHK(hipMemcpyAsync(h->d_t01, t01, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     if (guess) HIPCHK(hipMemcpyAsync(h->d_ext, guess, 16 * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_in, h->stream));  // K0-K4 run on the preprocessing stream: order them after the upload
+    h->ev_in_pending = true;
     int rc = icp_enqueue_scan(h, dtype == PTL_F32 ? (const float*)h->d_in : nullptr,
                               dtype == PTL_F64 ? (const double*)h->d_in : nullptr, t01 ? h->d_t01 : nullptr, n,
                               guess ? h->d_ext : nullptr);
     if (rc) return rc;
+    if (h->ev_map_valid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_map, 0));  // map size is part of the row
     k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);  // close the scan before its stats row is read back
     const int64_t k = h->scans_done - 1;
     double pose[16];
@@ -404,7 +464,7 @@ static int copy_cloud(ptl_icp* h, const double* d_src, const int* d_n, double* o
     return PTL_OK;
 }
 extern "C" int ptl_icp_last_frame_down(ptl_icp* h, double* out, int64_t max_points, int64_t* n_written) {
-    return copy_cloud(h, h ? h->c.fd : nullptr, h ? &h->c.st->n_down : nullptr, out, max_points, n_written);
+    return copy_cloud(h, h ? h->c.fd : nullptr, h ? &h->c.st->n_down_ins : nullptr, out, max_points, n_written);
 }
 extern "C" int ptl_icp_last_source(ptl_icp* h, double* out, int64_t max_points, int64_t* n_written) {
     return copy_cloud(h, h ? h->c.src0 : nullptr, h ? &h->c.st->n_src : nullptr, out, max_points, n_written);
@@ -617,8 +677,11 @@ extern "C" int ptl_icp_register_range(ptl_icp* h, ptl_lut* lut, const uint32_t* 
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipMemcpyAsync(h->d_in, range_mm, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     if (guess) HIPCHK(hipMemcpyAsync(h->d_ext, guess, 16 * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_in, h->stream));  // K0-K4 run on the preprocessing stream: order them after the upload
+    h->ev_in_pending = true;
     int rc = icp_enqueue_scan(h, nullptr, nullptr, nullptr, n, guess ? h->d_ext : nullptr, (const unsigned*)h->d_in, lut);
     if (rc) return rc;
+    if (h->ev_map_valid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_map, 0));
     k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);
     const int64_t k = h->scans_done - 1;
     double pose[16];
@@ -856,6 +919,7 @@ static int seq_reset(ptl_seq* s) {
     if (rc) return rc;
     rc = ekf_reset(s->ekf);
     if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(s->ekf_stream));  // EKF launches may go to either stream afterwards
     s->scan_of_out.clear();
     s->n_out = 0;
     s->next_scan = 0;
@@ -873,22 +937,30 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
     const double* guess_ptr = (with_ekf && s->cfg.use_imu_prediction) ? (const double*)((char*)s->ekf->st + offsetof(EkfState, pose)) : nullptr;
     const size_t pps = (size_t)s->cfg.points_per_scan;
     const int64_t end = s->next_scan + n;
-    hipStream_t es = s->ekf_stream;
+    hipStream_t es = s->ekf_stream;  // used when the EKF does not feed the registration (no IMU prediction)
     for (int64_t k = s->next_scan; k < end; ++k) {
         // IMU samples that precede scan k and were not consumed yet (only before the very first scan of a run,
         // or when the previous scan was skipped: otherwise the previous scan's EKF launch already ran them)
         const int64_t e = with_ekf ? s->imu_end[(size_t)k] : s->imu_pos;
         if (e > s->imu_pos) {
-            k_ekf_step<<<1, 384, 0, es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+            k_ekf_step<<<1, 384, 0, guess_ptr ? s->stream : es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
             s->imus_per_scan += e - s->imu_pos;
             s->imu_pos = e;
         }
         s->next_scan = k + 1;
         if (with_ekf && !s->imus_per_scan) continue;  // ekf_bench.py:512-518
         s->imus_per_scan = 0;
-        if (with_ekf) {
-            if (guess_ptr) HIPCHK(hipEventRecord(s->ev_guess, es));  // the EKF nav pose scan k starts from
-            s->icp->gn_wait = guess_ptr ? s->ev_guess : nullptr;
+        const int64_t o = s->n_out;
+        const int64_t e2 = (k + 1 < s->cfg.n_scans) ? s->imu_end[(size_t)k + 1] : s->imu_pos;
+        const bool inline_ekf = with_ekf && guess_ptr != nullptr;
+        if (inline_ekf) {
+            // the EKF is on the critical path (scan k+1 starts from its pose): same stream as the GN kernel
+            s->icp->post_ekf.st = s->ekf->st; s->icp->post_ekf.imu = s->d_imu;
+            s->icp->post_ekf.i0 = (int)s->imu_pos; s->icp->post_ekf.i1 = (int)e2;
+            s->icp->post_ekf.res_pose = s->d_res_poses + 16 * o; s->icp->post_ekf.res_t = s->d_res_t + o;
+            s->icp->post_ekf.rows = s->d_rows + 8 * o;
+            s->icp->post_ekf.on = true;
+        } else if (with_ekf) {
             s->icp->gn_done = s->ev_gn;
         }
         int rc;
@@ -899,16 +971,16 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
         } else {
             rc = icp_enqueue_scan(s->icp, s->d_scans + (size_t)k * pps * 3, nullptr, nullptr, (int64_t)pps, guess_ptr);
         }
-        s->icp->gn_wait = nullptr; s->icp->gn_done = nullptr;
+        s->icp->gn_wait = nullptr; s->icp->gn_done = nullptr; s->icp->post_ekf.on = false;
         if (rc) return rc;
-        const int64_t o = s->n_out;
         const double* kiss_pose = s->icp->c.traj + 16 * (s->icp->scans_done - 1);
-        if (with_ekf) {
-            // one launch: update with scan k's pose, then predict through the IMU samples up to scan k+1
+        if (with_ekf && !inline_ekf) {
+            // nothing waits for this EKF step but the next one: its own stream, beside the map update
             HIPCHK(hipStreamWaitEvent(es, s->ev_gn, 0));
-            const int64_t e2 = (k + 1 < s->cfg.n_scans) ? s->imu_end[(size_t)k + 1] : s->imu_pos;
             k_ekf_step<<<1, 384, 0, es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e2, kiss_pose, nullptr,
                                          s->d_res_poses + 16 * o, s->d_res_t + o, s->d_rows + 8 * o, 1);
+        }
+        if (with_ekf) {
             s->imus_per_scan += e2 - s->imu_pos;
             s->imu_pos = e2;
         }
@@ -1121,6 +1193,7 @@ static int batch_push_ctx(ptl_batch* b) {
         Ctx c = b->icp[s]->c;
         c.in_f32 = nullptr; c.in_f64 = nullptr; c.in_range = nullptr; c.t01 = nullptr;
         c.n_in = (int)b->cfg.points_per_scan;
+        c.overlap_pre = 0;  // one stream: the prologue is ordered after the previous map update
         c.ext_guess = (with_ekf && b->cfg.use_imu_prediction) ? (const double*)((char*)b->ekf[s]->st + offsetof(EkfState, pose)) : nullptr;
         if (b->is_range) { c.lut_dir = b->lut->dir; c.lut_off = b->lut->off; c.row_mask = b->icp[s]->d_row_mask; }
         h[s].c = c;
