@@ -1,0 +1,14 @@
+"""per-call drop-in API rate: KissICPWrapper.register_frame + ESEKF.processImu / processPose driven from host arrays,
+one call per event as the reference's loop does (PCIe upload and a host round trip per call included)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ptudes_lab_amd  # noqa
+from ptudes_lab_amd.cli.ekf_bench import _synthetic_source
+from ptudes_lab_amd.sequence import run_events
+n = 120
+seq, info, events = _synthetic_source(1000, n)
+events = list(events)
+t0 = time.perf_counter()
+out = run_events(iter(events), info, kiss_min_range=1.0, kiss_max_range=70.0, use_imu_prediction=True)
+dt = time.perf_counter() - t0
+print("per-call API: %d scans in %.2f s = %.1f scans/s (timings %s)" % (len(out["res_poses"]), dt, len(out["res_poses"]) / dt, out.get("timings")))
