@@ -139,6 +139,11 @@ int ptl_lut_create(int device_id, int32_t H, int32_t W, const double *beam_altit
 int ptl_lut_destroy(ptl_lut *l);
 /* XYZLut.__call__: range image (H*W u32, mm, 0 = no return) -> H*W x 3 f64 metres */
 int ptl_lut_apply(ptl_lut *l, const uint32_t *range_mm, double *xyz_out);
+/* StreamStatsTracker.trackScan (reference ins/data.py:284-308): over the non-zero ranges of the rows
+ * np.linspace(0, H, beams_num, endpoint=False, dtype=int) (all rows when beams_num <= 0), scaled by range_to_m
+ * (0.001; 0.008 for the RNG15 profile, :242-252): out5 = {count, mean, population variance, min, max} */
+int ptl_range_stats(int device_id, const uint32_t *range, int32_t H, int32_t W, int32_t beams_num, double range_to_m,
+                    double out5[5]);
 /* rows kept active by reduce_active_beams(ls, beams_num); beams_num <= 0 = all rows.  Applies to range-image input. */
 int ptl_icp_set_active_beams(ptl_icp *h, int32_t H, int32_t beams_num);
 /* register_frame on a raw range image; per-pixel times are column-implicit (kiss.py:34-35) */

@@ -2,6 +2,7 @@
 import click
 
 from .ekf_bench import ptudes_ekf_bench
+from .stat import ptudes_stat
 
 
 @click.group(name="ptudes")
@@ -10,6 +11,7 @@ def ptudes_cli() -> None:
 
 
 ptudes_cli.add_command(ptudes_ekf_bench)
+ptudes_cli.add_command(ptudes_stat)
 
 
 def main():

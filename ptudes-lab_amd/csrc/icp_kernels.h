@@ -1074,6 +1074,51 @@ __global__ __launch_bounds__(256) void k_deskew_only(Ctx c, const double* xyz, c
     out[3 * (size_t)i] = p.x; out[3 * (size_t)i + 1] = p.y; out[3 * (size_t)i + 2] = p.z;
 }
 
+// ------------------------------------------------------------------------------------------------ range statistics
+// StreamStatsTracker.trackScan's per-scan moments (reference ins/data.py:286-308): over the non-zero ranges of the
+// selected beam rows, converted to metres - count, mean, population variance (two passes, like np.mean / np.var),
+// min, max.  One workgroup, fixed reduction tree: deterministic; min / max are selections and therefore exact.
+// out[5] = {n, mean, var, min, max}
+__global__ __launch_bounds__(1024) void k_range_stats(const unsigned* range, int H, int W, const unsigned char* row_mask,
+                                                      double to_m, double* out) {
+    __shared__ double sh[1024];
+    __shared__ double shmin[1024], shmax[1024];
+    __shared__ double s_mean, s_n;
+    const int tid = threadIdx.x, n_all = H * W;
+    for (int pass = 0; pass < 2; ++pass) {
+        const double mean = pass ? s_mean : 0.0;
+        double acc = 0.0, cnt = 0.0, lo = 1.7976931348623157e308, hi = -1.7976931348623157e308;
+        for (int i = tid; i < n_all; i += 1024) {
+            const unsigned r = range[i];
+            if (r == 0 || (row_mask && !row_mask[i / W])) continue;
+            const double x = (double)r * to_m;
+            if (pass == 0) { acc += x; cnt += 1.0; lo = fmin(lo, x); hi = fmax(hi, x); }
+            else { const double d = x - mean; acc += d * d; }
+        }
+        sh[tid] = acc;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) { if (tid < o) sh[tid] += sh[tid + o]; __syncthreads(); }
+        const double total = sh[0];
+        __syncthreads();
+        if (pass == 0) {
+            sh[tid] = cnt; shmin[tid] = lo; shmax[tid] = hi;
+            __syncthreads();
+            for (int o = 512; o > 0; o >>= 1) {
+                if (tid < o) { sh[tid] += sh[tid + o]; shmin[tid] = fmin(shmin[tid], shmin[tid + o]); shmax[tid] = fmax(shmax[tid], shmax[tid + o]); }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                s_n = sh[0];
+                s_mean = sh[0] > 0.0 ? total / sh[0] : 0.0;
+                out[0] = sh[0]; out[1] = s_mean; out[3] = shmin[0]; out[4] = shmax[0];
+            }
+            __syncthreads();
+        } else if (tid == 0) {
+            out[2] = s_n > 0.0 ? total / s_n : 0.0;
+        }
+    }
+}
+
 // ================================================================================================ launch wrappers
 // Every stage exists as a device function d_*(ctx, ...); k_* runs it for one sequence (context by value), kb_* runs
 // it for S sequences in one launch (blockIdx.y = sequence, contexts in device memory): the batched driver

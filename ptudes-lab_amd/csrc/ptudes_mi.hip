@@ -649,6 +649,36 @@ extern "C" int ptl_lut_apply(ptl_lut* l, const uint32_t* range_mm, double* xyz_o
     (void)hipFree(d_r); (void)hipFree(d_x);
     return PTL_OK;
 }
+// StreamStatsTracker.trackScan's reduction (reference ins/data.py:284-308) on a range image given by the host
+extern "C" int ptl_range_stats(int device_id, const uint32_t* range, int32_t H, int32_t W, int32_t beams_num,
+                               double range_to_m, double out5[5]) {
+    if (!range || !out5 || H < 1 || W < 1) return set_err(PTL_ERR_ARG, "bad argument");
+    if (ptl_device_count() <= device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", device_id);
+    HIPCHK(hipSetDevice(device_id));
+    const size_t n = (size_t)H * W;
+    unsigned* d_r = nullptr;
+    unsigned char* d_m = nullptr;
+    double* d_o = nullptr;
+    HIPCHK(dalloc(&d_r, n));
+    HIPCHK(dalloc(&d_o, 5));
+    HIPCHK(hipMemcpy(d_r, range, n * 4, hipMemcpyHostToDevice));
+    if (beams_num > 0) {  // np.linspace(0, H, num, endpoint=False, dtype=int) (:288-293)
+        std::vector<unsigned char> m((size_t)H, 0);
+        const double step = (double)H / (double)beams_num;
+        for (int i = 0; i < beams_num; ++i) {
+            const int r = (int)((double)i * step);
+            if (r >= 0 && r < H) m[(size_t)r] = 1;
+        }
+        HIPCHK(hipMalloc((void**)&d_m, (size_t)H));
+        HIPCHK(hipMemcpy(d_m, m.data(), (size_t)H, hipMemcpyHostToDevice));
+    }
+    k_range_stats<<<1, 1024>>>(d_r, H, W, d_m, range_to_m, d_o);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out5, d_o, 40, hipMemcpyDeviceToHost));
+    (void)hipFree(d_r); (void)hipFree(d_o);
+    if (d_m) (void)hipFree(d_m);
+    return PTL_OK;
+}
 // reduce_active_beams (reference utils.py:328-341): rows np.linspace(0, H, beams, endpoint=False, dtype=int) stay
 // active, every other row's RANGE is treated as 0.  beams_num <= 0 re-enables all rows.
 extern "C" int ptl_icp_set_active_beams(ptl_icp* h, int32_t H, int32_t beams_num) {

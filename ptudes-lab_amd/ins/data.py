@@ -2,8 +2,8 @@
 
 Host-side mirror of reference src/ptudes/ins/data.py (same names, argument meaning and results), written
 for this package: per-instance array defaults (the reference shares one class-level ndarray per field,
-SURVEY.md App. C1/C2), no ouster-sdk import.  `StreamStatsTracker` (range / IMU running statistics that
-are only printed) is not part of the pose path and is not provided.
+SURVEY.md App. C1/C2), no ouster-sdk import.  `StreamStatsTracker` (reference :207-369)
+reduces each scan's range image on the device (`ptl_range_stats`) and pools the moments on the host.
 """
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
@@ -142,3 +142,130 @@ def ekf_traj_ate(ekf_gt, ekf):
     """ATE between two filters at the update knots (reference :196-204)"""
     _, navs_gt, navs = _collect_navs_from_gt(ekf_gt, ekf)
     return calc_ate([n.pose_mat() for n in navs], [n.pose_mat() for n in navs_gt])
+
+
+class StreamStatsTracker:
+    """Tracks the mean / std of the scans' ranges and of the IMU samples (reference ins/data.py:207-369, same
+    methods, properties and report).  `trackScan` takes an Ouster LidarScan (when ouster-sdk is importable), or a
+    (H, W) uint32 range image with the last valid column timestamp in ns; the per-scan count / mean / variance /
+    min / max come from the HIP reduction `ptl_range_stats`, the pooling formula is the reference's (:310-316)."""
+
+    def __init__(self, use_beams_num: Optional[int] = None, metadata=None, device_id: int = 0):
+        self._metadata = metadata
+        self._device_id = device_id
+        self._mean = 0
+        self._scans_num = 0
+        self._points_num = 0
+        self._sigma_sq = 0
+        self._use_beams_num = use_beams_num
+        self._mean_acc = np.zeros(3)
+        self._mean_gyr = np.zeros(3)
+        self._sigman_acc = np.zeros(3)  # sigma^2 * n accumulators
+        self._sigman_gyr = np.zeros(3)
+        self._imu_num = 0
+        self._max_ts = 0
+        self._min_ts = 0
+        self._min_range = 0
+        self._max_range = 0
+
+    def _range_to_m(self) -> float:
+        coef = 0.001  # :242-252
+        md = self._metadata
+        if md is not None and str(getattr(getattr(md, "format", None), "udp_profile_lidar", "")).endswith("RNG15_RFL8_NIR8"):
+            coef = 8 * coef
+        return coef
+
+    def _track_min_max_ts(self, ts: float):  # :254-260
+        if not self._imu_num and not self._scans_num:
+            self._min_ts = ts
+            self._max_ts = ts
+        else:
+            self._min_ts = min(self._min_ts, ts)
+            self._max_ts = max(self._max_ts, ts)
+
+    def trackImu(self, imu: IMU):
+        """Update IMU mean / sigma (:266-282)"""
+        mean_acc_prev = self._mean_acc.copy()
+        mean_gyr_prev = self._mean_gyr.copy()
+        self._mean_acc += (imu.lacc - self._mean_acc) / (self._imu_num + 1)
+        self._sigman_acc += (imu.lacc - mean_acc_prev) * (imu.lacc - self._mean_acc)
+        self._mean_gyr += (imu.avel - self._mean_gyr) / (self._imu_num + 1)
+        self._sigman_gyr += (imu.avel - mean_gyr_prev) * (imu.avel - self._mean_gyr)
+        self._track_min_max_ts(imu.ts)
+        self._imu_num += 1
+
+    def trackScan(self, ls, last_valid_column_ts_ns: Optional[int] = None):
+        """Update the range mean / sigma with one scan (:284-321)"""
+        import ctypes as C
+        from .. import _lib as L
+        if hasattr(ls, "field") and hasattr(ls, "h"):  # ouster LidarScan, only when ouster-sdk is present
+            from ouster import client  # noqa: WPS433 (guarded import)
+            rng = np.ascontiguousarray(ls.field(client.ChanField.RANGE), dtype=np.uint32)
+            if last_valid_column_ts_ns is None:
+                last_valid_column_ts_ns = client.last_valid_column_ts(ls)
+        else:
+            rng = np.ascontiguousarray(ls, dtype=np.uint32)
+        if rng.ndim != 2:
+            raise ValueError("range image must be (H, W)")
+        if last_valid_column_ts_ns is None:
+            raise ValueError("a raw range image needs last_valid_column_ts_ns")
+        out = np.zeros(5)
+        L.check(L.lib().ptl_range_stats(self._device_id, rng.ctypes.data_as(C.c_void_p), rng.shape[0], rng.shape[1],
+                                        int(self._use_beams_num or 0), self._range_to_m(), L.dptr(out)))
+        n, m, v, lo, hi = int(out[0]), out[1], out[2], out[3], out[4]
+        if n == 0:
+            raise ValueError("scan has no valid returns")  # the reference divides by zero here
+        if not self._points_num:  # :262-264
+            self._min_range, self._max_range = lo, hi
+        else:
+            self._min_range, self._max_range = min(self._min_range, lo), max(self._max_range, hi)
+        s1 = 0 if not self._points_num else (self._points_num - 1) * self._sigma_sq
+        corr = self._points_num * n * np.square(self._mean - m) / ((self._points_num + n) * (self._points_num + n - 1))
+        self._sigma_sq = (s1 + n * v) / (self._points_num + n - 1) + corr
+        self._mean = (self._mean * self._points_num + m * n) / (self._points_num + n)
+        self._track_min_max_ts(last_valid_column_ts_ns * 1e-9)
+        self._scans_num += 1
+        self._points_num += n
+
+    @property
+    def range_mean(self) -> float:
+        return self._mean
+
+    @property
+    def range_std(self) -> float:
+        return np.sqrt(self._sigma_sq)
+
+    @property
+    def acc_mean(self) -> np.ndarray:
+        return self._mean_acc
+
+    @property
+    def acc_std(self) -> np.ndarray:
+        return np.sqrt(self._sigman_acc / self._imu_num)
+
+    @property
+    def gyr_mean(self) -> np.ndarray:
+        return self._mean_gyr
+
+    @property
+    def gyr_std(self) -> np.ndarray:
+        return np.sqrt(self._sigman_gyr / self._imu_num)
+
+    @property
+    def dt(self) -> float:
+        return self._max_ts - self._min_ts
+
+    def _formatted_str(self) -> str:  # :351-366
+        s3_min_range = max(self._min_range, self.range_mean - 3 * self.range_std)
+        s3_max_range = min(self._max_range, self.range_mean + 3 * self.range_std)
+        return (f"StreamStatsTracker[dt: {self.dt:.04f} s, imus: {self._imu_num}, scans: {self._scans_num}]:\n"
+                f"  range_mean: {self.range_mean:.03f} m,\n"
+                f"  range_std: {self.range_std:.03f} m (s3 span: [{s3_min_range:.03f} - {s3_max_range:.03f} m])\n"
+                f"  range min max: {self._min_range:.03f} - {self._max_range:.03f} m\n"
+                f"  acc_mean: {self.acc_mean} m/s^2\n"
+                f"  acc_std: {self.acc_std}\n"
+                f"  gyr_mean: {self.gyr_mean} rad/s\n"
+                f"  gyr_std: {self.gyr_std}")
+
+    def __repr__(self):
+        return self._formatted_str()

@@ -304,6 +304,47 @@ def case_imu_nav():
         rotvecs=np.array(rotvecs), pose_mat=ns.pose_mat(), **beam)
 
 
+def case_stream_stats():
+    """StreamStatsTracker (ins/data.py:207-369): running range mean / std over scans (with and without the
+    `use_beams_num` row selection), IMU mean / std, time span, and the text `ptudes stat` prints."""
+    import numpy as np
+    import ouster.client as client
+    from ptudes.ins.data import IMU, StreamStatsTracker
+    rng = np.random.default_rng(77)
+    H, W, T = 128, 96, 6
+    scans = rng.integers(300, 60000, size=(T, H, W)).astype(np.uint32)
+    scans[rng.random((T, H, W)) < 0.08] = 0            # missing returns
+    scans[2, 5:9] = 0                                  # whole rows missing
+    scan_ts_ns = (1_700_000_000_000_000_000 + np.arange(T) * 100_000_000 + 99_000_000).astype(np.int64)
+    imu_ts = 1_700_000_000.0 + np.arange(10 * T) * 0.01
+    imu_a = rng.normal([0.1, -0.2, 9.8], 0.05, (10 * T, 3))
+    imu_w = rng.normal([0.01, 0.0, -0.02], 0.01, (10 * T, 3))
+
+    class FakeScan:  # what trackScan touches: .h, .field(RANGE); last_valid_column_ts(ls) is mocked below
+        def __init__(self, r, ts):
+            self.h, self._r, self.ts = r.shape[0], r, ts
+
+        def field(self, _):
+            return self._r
+
+    client.last_valid_column_ts = lambda ls: ls.ts
+    out = {}
+    for name, beams in (("all", None), ("b32", 32)):
+        st = StreamStatsTracker(use_beams_num=beams, metadata=None)
+        rows = []
+        for k in range(T):
+            for i in range(10 * k, 10 * (k + 1)):
+                st.trackImu(IMU(imu_a[i].copy(), imu_w[i].copy(), float(imu_ts[i])))
+            st.trackScan(FakeScan(scans[k], int(scan_ts_ns[k])))
+            rows.append(np.concatenate([[st.range_mean, st.range_std, st._min_range, st._max_range, st._points_num,
+                                         st._scans_num, st.dt], st.acc_mean, st.acc_std, st.gyr_mean, st.gyr_std]))
+        out[f"rows_{name}"] = np.array(rows)
+        with open(os.path.join(HERE, f"stream_stats_{name}.txt"), "w") as f:
+            f.write(repr(st))
+    np.savez_compressed(os.path.join(HERE, "stream_stats.npz"), scans=scans, scan_ts_ns=scan_ts_ns, imu_ts=imu_ts,
+                        imu_a=imu_a, imu_w=imu_w, **out)
+
+
 CASES = {
     "ekf_steps_default": lambda: case_ekf_steps("default"),
     "ekf_steps_init": lambda: case_ekf_steps("init"),
@@ -314,6 +355,7 @@ CASES = {
     "ate": case_ate,
     "ts_filters": case_ts_filters,
     "imu_nav": case_imu_nav,
+    "stream_stats": case_stream_stats,
 }
 
 if __name__ == "__main__":

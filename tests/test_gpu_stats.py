@@ -1,0 +1,61 @@
+"""StreamStatsTracker on the device reduction (ptl_range_stats) against the reference's own vectors
+(tests/golden/stream_stats.npz, produced by gen_golden.py from /root/reference) and the numpy restatement.
+Tolerances: count / min / max / timestamps exact (selections and integers); mean and std 1e-12 relative (the
+device sums in a fixed tree, numpy pairwise)."""
+import os
+
+import numpy as np
+import pytest
+
+import ptudes_lab_amd  # noqa: F401  (import shim)
+from oracle.stats import StreamStats
+from ptudes_lab_amd.ins.data import IMU, StreamStatsTracker
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,beams", [("all", None), ("b32", 32)])
+def test_stream_stats_tracker_vs_reference_golden(golden_dir, name, beams):
+    g = np.load(os.path.join(golden_dir, "stream_stats.npz"))
+    st = StreamStatsTracker(use_beams_num=beams)
+    ref = StreamStats(use_beams_num=beams)
+    for k in range(len(g["scans"])):
+        for i in range(10 * k, 10 * (k + 1)):
+            st.trackImu(IMU(g["imu_a"][i].copy(), g["imu_w"][i].copy(), float(g["imu_ts"][i])))
+            ref.track_imu(g["imu_a"][i], g["imu_w"][i], float(g["imu_ts"][i]))
+        st.trackScan(g["scans"][k], int(g["scan_ts_ns"][k]))
+        ref.track_scan(g["scans"][k], int(g["scan_ts_ns"][k]))
+        row = np.concatenate([[st.range_mean, st.range_std, st._min_range, st._max_range, st._points_num, st._scans_num,
+                               st.dt], st.acc_mean, st.acc_std, st.gyr_mean, st.gyr_std])
+        want = g[f"rows_{name}"][k]
+        assert np.array_equal(row[2:7], want[2:7])       # min, max, counts, time span: exact
+        assert np.array_equal(row[7:], want[7:])         # IMU statistics: same host arithmetic
+        assert np.allclose(row[:2], want[:2], rtol=1e-12, atol=0)
+        assert np.allclose(row[:2], ref.row()[:2], rtol=1e-12, atol=0)
+    assert repr(st) == open(os.path.join(golden_dir, f"stream_stats_{name}.txt")).read()
+
+
+def test_range_stats_edge_cases():
+    st = StreamStatsTracker()
+    with pytest.raises(ValueError):
+        st.trackScan(np.zeros((4, 8), dtype=np.uint32), 1)          # no valid return
+    one = np.zeros((4, 8), dtype=np.uint32)
+    one[2, 3] = 12345
+    st.trackScan(one, 5_000_000_000)
+    assert st._points_num == 1 and st.range_mean == 12345 * 0.001 and st._min_range == st._max_range == 12345 * 0.001
+    big = np.full((128, 1024), 4_000_000, dtype=np.uint32)           # 4 km everywhere: no overflow in the sums
+    st2 = StreamStatsTracker(use_beams_num=32)
+    st2.trackScan(big, 1)
+    assert st2._points_num == 32 * 1024 and abs(st2.range_mean - 4000.0) < 1e-9 and st2.range_std == 0.0
+
+
+def test_stat_cli_synthetic():
+    """`ptudes stat --synthetic`: the reference command's report on the synthetic source"""
+    from click.testing import CliRunner
+    from ptudes_lab_amd.cli.run import ptudes_cli
+    res = CliRunner().invoke(ptudes_cli, ["stat", "--synthetic", "1000", "-t", "0.5", "--beams", "32"])
+    assert res.exit_code == 0, res.output
+    assert "StreamStatsTracker[dt: 0.5" in res.output and "scans: 5]" in res.output
+    assert "Gravity vector estimation" in res.output
+    g = [float(x) for x in res.output.split("Gravity vector estimation:")[1].replace("[", " ").replace("]", " ").split()]
+    assert abs(g[2] - 1.0) < 0.02  # level start: the specific force points along +z
