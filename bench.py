@@ -241,12 +241,12 @@ def main():
         gathered = parallel.gather_trajectories(rows, counts, dist)
 
     if rank == 0:
-        from oracle import cpu as orc
+        from ptudes_lab_amd.ins.data import calc_ate
         o, sq = outs[0], seqs[0]
         gt = sq.gt_poses(0.5)
         g0i = np.linalg.inv(gt[0])
         gt_rel = np.array([g0i @ g for g in gt])
-        ate_r, ate_t = orc.calc_ate(o["res_poses"], gt_rel[: len(o["res_poses"])])
+        ate_r, ate_t = calc_ate(list(o["res_poses"]), list(gt_rel[: len(o["res_poses"])]))
         rmse_gt = float(np.sqrt(np.mean(np.sum((o["res_poses"][:, :3, 3] - gt_rel[: len(o["res_poses"]), :3, 3]) ** 2, 1))))
         avg_gn_s = (gn_ms / 1e3) / max(gn_n, 1)
         avg_gn_bytes = gn_bytes / max(gn_n, 1)  # one launch carries the GN loops of all S sequences

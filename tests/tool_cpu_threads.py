@@ -1,7 +1,7 @@
 """thread-scaling of the CPU oracle's multi-core timing mode (oracle.h orc_set_threads) on this host"""
 import sys, time, numpy as np
 import os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ptudes_lab_amd
 from ptudes_lab_amd import synth
 from oracle import cpu as orc
