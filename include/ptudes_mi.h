@@ -174,10 +174,12 @@ typedef struct {
 int ptl_ekf_default_cfg(ptl_ekf_cfg *cfg);
 int ptl_ekf_create(const ptl_ekf_cfg *cfg, ptl_ekf **out);        /* ESEKF.__init__  (:73-179) */
 int ptl_ekf_destroy(ptl_ekf *h);
-int ptl_ekf_process_imu(ptl_ekf *h, const double lacc[3], const double avel[3], double ts); /* processImu (:191-237) */
+/* processImu (:191-237) and processPose (:259-329) only queue their launch (the payload travels in the kernel
+ * arguments): they return before the step has run; ptl_ekf_get_state / pose_mat / ts wait for it */
+int ptl_ekf_process_imu(ptl_ekf *h, const double lacc[3], const double avel[3], double ts);
 /* batch form: imu is n x 7 rows (ts, lacc[3], avel[3]); one launch for the whole batch */
 int ptl_ekf_process_imu_batch(ptl_ekf *h, const double *imu, int64_t n);
-int ptl_ekf_process_pose(ptl_ekf *h, const double pose[16], const double *meas_cov36);      /* processPose (:259-329) */
+int ptl_ekf_process_pose(ptl_ekf *h, const double pose[16], const double *meas_cov36);
 /* nav[19] = pos(3) quat_xyzw(4) vel(3) bias_gyr(3) bias_acc(3) grav(3) (ESEKF.nav, :181-184); cov 18x18 (._cov) */
 int ptl_ekf_get_state(ptl_ekf *h, double nav[19], double cov[324]);
 int ptl_ekf_pose_mat(ptl_ekf *h, double T[16]); /* NavState.pose_mat (ins/data.py:70-74) */

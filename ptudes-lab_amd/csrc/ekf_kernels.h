@@ -352,6 +352,24 @@ __global__ __launch_bounds__(384) void k_ekf_step(EkfState* e, const double* imu
                                                   double* out_row8, int update_first) {
     d_ekf_step(e, imu, i0, i1, pose, meas_cov, out_pose, out_t, out_row8, update_first);
 }
+// One IMU sample (processImu) / one pose measurement (processPose) with the payload passed by value in the kernel
+// arguments: no staging copy, so the per-call API neither copies nor synchronises - the call returns once the
+// launch is queued, and the state is read back (and the stream drained) only when the caller asks for it.
+struct EkfRow7 { double v[7]; };
+struct EkfPoseArg { double pose[16]; double cov[36]; int has_cov; };
+__global__ __launch_bounds__(384) void k_ekf_imu_value(EkfState* e, EkfRow7 row) {
+    __shared__ double srow[7];
+    if (threadIdx.x < 7) srow[threadIdx.x] = row.v[threadIdx.x];
+    __syncthreads();
+    d_ekf_step(e, srow, 0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+}
+__global__ __launch_bounds__(384) void k_ekf_pose_value(EkfState* e, EkfPoseArg a) {
+    __shared__ double sp[16 + 36];
+    if (threadIdx.x < 16) sp[threadIdx.x] = a.pose[threadIdx.x];
+    if (threadIdx.x < 36) sp[16 + threadIdx.x] = a.cov[threadIdx.x];
+    __syncthreads();
+    d_ekf_step(e, nullptr, 0, 0, sp, a.has_cov ? sp + 16 : nullptr, nullptr, nullptr, nullptr, 0);
+}
 // S filters in one launch (blockIdx.x = sequence)
 #define EKF_MAX_SEQ 8
 struct EkfBatchArgs {

@@ -793,17 +793,21 @@ extern "C" int ptl_ekf_process_imu_batch(ptl_ekf* h, const double* imu, int64_t 
 }
 extern "C" int ptl_ekf_process_imu(ptl_ekf* h, const double lacc[3], const double avel[3], double ts) {
     if (!h || !lacc || !avel) return set_err(PTL_ERR_ARG, "null argument");
-    const double row[7] = {ts, lacc[0], lacc[1], lacc[2], avel[0], avel[1], avel[2]};
-    return ptl_ekf_process_imu_batch(h, row, 1);
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const EkfRow7 row = {{ts, lacc[0], lacc[1], lacc[2], avel[0], avel[1], avel[2]}};
+    k_ekf_imu_value<<<1, 384, 0, h->stream>>>(h->st, row);  // asynchronous: the getters synchronise
+    HIPCHK(hipGetLastError());
+    return PTL_OK;
 }
 extern "C" int ptl_ekf_process_pose(ptl_ekf* h, const double pose[16], const double* meas_cov36) {
     if (!h || !pose) return set_err(PTL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    HIPCHK(hipMemcpyAsync(h->d_buf, pose, 128, hipMemcpyHostToDevice, h->stream));
-    if (meas_cov36) HIPCHK(hipMemcpyAsync(h->d_buf + 16, meas_cov36, 288, hipMemcpyHostToDevice, h->stream));
-    k_ekf_step<<<1, 384, 0, h->stream>>>(h->st, nullptr, 0, 0, h->d_buf, meas_cov36 ? h->d_buf + 16 : nullptr, nullptr, nullptr, nullptr, 0);
+    EkfPoseArg a;
+    memcpy(a.pose, pose, sizeof a.pose);
+    a.has_cov = meas_cov36 ? 1 : 0;
+    if (meas_cov36) memcpy(a.cov, meas_cov36, sizeof a.cov); else memset(a.cov, 0, sizeof a.cov);
+    k_ekf_pose_value<<<1, 384, 0, h->stream>>>(h->st, a);  // asynchronous: the getters synchronise
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
     return PTL_OK;
 }
 extern "C" int ptl_ekf_get_state(ptl_ekf* h, double nav[19], double cov[324]) {

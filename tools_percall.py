@@ -8,6 +8,7 @@ from ptudes_lab_amd.sequence import run_events
 n = 120
 seq, info, events = _synthetic_source(1000, n)
 events = list(events)
+run_events(iter(events[:60]), info, kiss_min_range=1.0, kiss_max_range=70.0, use_imu_prediction=True)  # library warm-up
 t0 = time.perf_counter()
 out = run_events(iter(events), info, kiss_min_range=1.0, kiss_max_range=70.0, use_imu_prediction=True)
 dt = time.perf_counter() - t0
