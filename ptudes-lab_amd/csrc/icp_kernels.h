@@ -55,6 +55,7 @@ struct DevState {
     unsigned bar_grp[8 * 32];
     unsigned bar_gen[8 * 32];
     unsigned bar_top;
+    unsigned gn_epoch;  // bumped before every single-sequence GN launch: part of the flag of its published words
     int gn_iters, gn_ncorr, gn_pad;
     long long gn_cand;
     double gn_max_dist, gn_kernel;
@@ -120,6 +121,8 @@ struct Ctx {
     double* traj;        // [T][16] kiss poses
     ScanStats* sstats;   // [T]
     const double* ext_guess;  // device 4x4 or null
+    unsigned long long* gn_rows_ll;  // [2][G][64]      per-workgroup sums as (32 data bits | 32 flag bits) words
+    unsigned long long* gn_xsum_ll;  // [2][8][8][64]   per-group sums, one copy per consumer slot
     int overlap_pre;          // the next scan's K0-K4 run beside this scan's map update (own stream): see flush_map_stats
     long long* wg_clk;        // [2 G] diagnostic: ticks each GN workgroup spent in the search phase (all waves / first wave)
     int traj_cap;
@@ -194,6 +197,13 @@ __global__ void k_finish_scan(Ctx c) {
     flush_map_stats(c, c.st);
 }
 
+// the exchange buffers of the GN kernel are zeroed again whenever the 22-bit launch epoch wraps (flags restart)
+__device__ __forceinline__ void gn_ll_clear_on_wrap(const Ctx& c) {
+    if (c.st->gn_epoch != 0u || !c.gn_rows_ll) return;
+    const size_t n_rows = (size_t)2 * c.G * 64, n_xsum = (size_t)2 * 8 * 8 * 64;
+    for (size_t i = threadIdx.x; i < n_rows; i += blockDim.x) c.gn_rows_ll[i] = 0ull;
+    for (size_t i = threadIdx.x; i < n_xsum; i += blockDim.x) c.gn_xsum_ll[i] = 0ull;
+}
 __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
     DevState* st = c.st;
     if (threadIdx.x == 0) {
@@ -203,6 +213,7 @@ __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
     st->n_valid = 0; st->n_down = 0; st->n_src = 0;
     for (int g = 0; g < 8; ++g) { st->bar_grp[g * 32] = 0; st->bar_gen[g * 32] = 0; }
     st->bar_top = 0;
+    st->gn_epoch = (st->gn_epoch + 1u) & 0x3FFFFFu;
     st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0;
     // deskew: xi = Log(P[-2]^-1 P[-1])  (Deskew.cpp)
     st->do_deskew = (c.deskew && st->n_poses >= 2) ? 1 : 0;
@@ -241,6 +252,7 @@ __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
     __threadfence_block();
     }
     __syncthreads();
+    gn_ll_clear_on_wrap(c);
     // per-column deskew transforms Exp((j/W - 0.5) xi): only W distinct times exist in a sweep (kiss.py:34-35)
     if (st->do_deskew && c.t01 == nullptr) {
         double xi[6];
@@ -717,6 +729,38 @@ __device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_emp
     st->stats_pending = k;
 }
 
+// ---- flag-in-word exchange of the 29 sums (single-sequence GN kernel) -------------------------------------------
+// A double travels as two 8-byte words, each (32 data bits | 32-bit flag); an aligned 8-byte store is single-copy
+// atomic, so a reader that sees the flag sees the data - no acknowledgement wait, no counter, no release word.
+// The flag is unique per (launch, iteration): gn_epoch << 10 | iteration + 1 (never 0; the buffers start zeroed and
+// are zeroed again when the epoch wraps).  Rows are double-buffered by iteration parity: nobody can be two
+// iterations ahead of a reader (a workgroup leaves iteration i only after every leader published i, and a leader
+// publishes only after every one of its members did).
+#define GN_LL_WORDS 64   /* words per row: 58 used */
+#define GN_LL_SPINS (1u << 22)
+__device__ __forceinline__ unsigned gn_flag(unsigned epoch, int it) { return (epoch << 10) | (unsigned)(it + 1); }
+// word `w` (0..57) of a row holding the doubles vals[0..28]
+__device__ __forceinline__ unsigned long long gn_ll_word(const double* vals, int w, unsigned flag) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[w >> 1]);
+    const unsigned half = (w & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+    return (unsigned long long)half | ((unsigned long long)flag << 32);
+}
+// spin until the word carries `flag`; returns its data half (sets *ok = false on a timeout)
+__device__ __forceinline__ unsigned gn_ll_wait(const unsigned long long* p, unsigned flag, bool* ok) {
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == flag) return (unsigned)v;
+        if (++spins > GN_LL_SPINS) { *ok = false; return 0u; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// lanes (2e, 2e + 1) of a wavefront hold the low / high half of entry e: the even lane returns the double
+__device__ __forceinline__ double gn_ll_join(unsigned half) {
+    const unsigned other = (unsigned)__shfl_xor((int)half, 1);
+    return __longlong_as_double((long long)(((unsigned long long)other << 32) | half));  // meaningful in even lanes
+}
+
 // Persistent Gauss-Newton loop (Registration.cpp RegisterFrame).  G workgroups, all resident; one grid
 // barrier per iteration; every workgroup sums all partials in the same fixed order and solves the 6x6
 // system redundantly, so all agree bit-for-bit on dx and on convergence.  Within a 32-lane group lane k
@@ -735,12 +779,15 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     __shared__ double tot[32];
     __shared__ double Esh[12];
     __shared__ double Tsh[12];
+    __shared__ double stage[32];
+    __shared__ double redL[64][32];  // a leader's member rows (G <= 512)
     __shared__ int flag_done;
     DevState* st = c.st;
     const int tid = threadIdx.x, lane32 = tid & 31, grp = tid >> 5, gbase = (tid & 63) & 32;
     const int NG = blockDim.x >> 5;
     const int G = gridDim.x, wg = blockIdx.x;
     const int n = st->n_src;
+    const unsigned epoch = st->gn_epoch;
     if (wg == 0 && tid == 0 && mode == 0) flush_map_stats(c, st);  // the previous scan's map update precedes this launch
     if (st->n_live == 0 && mode != 1) {  // voxel_map.Empty() => return initial_guess
         if (wg == 0 && tid == 0) {
@@ -818,7 +865,6 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         }
         __syncthreads();
         const long long c1b = __builtin_readcyclecounter();
-        double* part = c.partials + ((size_t)(it & 1) * G + wg) * 32;
         if (tid < 128) {
             const int col = tid & 31, seg = tid >> 5, NW = NG >> 1, per = (NW + 3) >> 2;
             double s = 0.0;
@@ -826,38 +872,55 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             red2[seg][col] = s;
         }
         __syncthreads();
-        if (tid < 29) {
-            const double s = ((red2[0][tid] + red2[1][tid]) + red2[2][tid]) + red2[3][tid];
-            __hip_atomic_store(&part[tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- exchange: workgroup row -> the leader of its group (wg & 7) -> group sums to everybody.  The leader adds
+        // its members' rows in member order and everybody adds the group sums in group order: the association the
+        // counter-barrier version used (8 strided partial sums, then 8 -> 1), bit for bit.
+        const unsigned flag = gn_flag(epoch, it);
+        const int par = it & 1, ngroups = G < 8 ? G : 8;
+        bool ok = true;
+        if (tid < 64) {  // one wavefront
+            if (tid < 29) stage[tid] = ((red2[0][tid] + red2[1][tid]) + red2[2][tid]) + red2[3][tid];
+            __builtin_amdgcn_wave_barrier();
+            if (tid < 58)
+                __hip_atomic_store(&c.gn_rows_ll[((size_t)par * G + wg) * GN_LL_WORDS + tid], gn_ll_word(stage, tid, flag),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         const long long c2 = __builtin_readcyclecounter();
-        if (tid == 0) grid_barrier(st, G, wg, it);
+        if (wg < ngroups) {  // leader of group wg: members wg, wg + 8, ...
+            const int nmem = (G - wg + 7) / 8;
+            for (int j = grp; j < nmem; j += NG) {
+                const unsigned long long* row = c.gn_rows_ll + ((size_t)par * G + (wg + 8 * j)) * GN_LL_WORDS;
+                const unsigned h0 = gn_ll_wait(row + lane32, flag, &ok);
+                const unsigned h1 = (lane32 + 32 < 58) ? gn_ll_wait(row + lane32 + 32, flag, &ok) : 0u;
+                const double v0 = gn_ll_join(h0), v1 = gn_ll_join(h1);
+                if ((lane32 & 1) == 0) {
+                    redL[j][lane32 >> 1] = v0;
+                    if (16 + (lane32 >> 1) < 29) redL[j][16 + (lane32 >> 1)] = v1;
+                }
+            }
+            __syncthreads();
+            if (tid < 29) {
+                double s = 0.0;
+                for (int j = 0; j < nmem; ++j) s += redL[j][tid];
+                stage[tid] = s;
+            }
+            __syncthreads();
+            if (tid < 8 * 64 && (tid & 63) < 58)  // one copy per consumer slot
+                __hip_atomic_store(&c.gn_xsum_ll[(((size_t)par * 8 + (tid >> 6)) * 8 + wg) * GN_LL_WORDS + (tid & 63)],
+                                   gn_ll_word(stage, tid & 63, flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // everybody: the group sums addressed to this workgroup's slot
+        if (tid < 8 * 64) {
+            const int xg = tid >> 6, w = tid & 63;
+            unsigned h = 0u;
+            if (xg < ngroups && w < 58)
+                h = gn_ll_wait(c.gn_xsum_ll + (((size_t)par * 8 + (wg & 7)) * 8 + xg) * GN_LL_WORDS + w, flag, &ok);
+            const double v = gn_ll_join(h);
+            if ((w & 1) == 0 && (w >> 1) < 29) red[xg][w >> 1] = (xg < ngroups) ? v : 0.0;
+        }
+        if (!ok) atomicOr(&st->err_flags, ERR_GN_TIMEOUT);
         __syncthreads();
         const long long c3 = __builtin_readcyclecounter();
-        // every workgroup: total = sum over workgroups, fixed order (8 strided partial sums, then 8 -> 1)
-        if (tid < 256) {
-            const int col = tid & 31, part8 = tid >> 5;
-            double s = 0.0;
-            if (col < 29) {
-                const double* base = c.partials + (size_t)(it & 1) * G * 32 + col;
-                int w = part8;
-                // eight independent L1-bypassing loads in flight per round, summed in a fixed order
-                for (; w + 56 < G; w += 64) {
-                    double v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        v[u] = __hip_atomic_load(&base[(size_t)(w + 8 * u) * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) s += v[u];
-                }
-                for (; w < G; w += 8)
-                    s += __hip_atomic_load(&base[(size_t)w * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            red[part8][col] = s;
-        }
-        __syncthreads();
         if (tid < 29) {
             double s = 0.0;
             for (int g = 0; g < 8; ++g) s += red[g][tid];

@@ -109,7 +109,7 @@ static int icp_free(ptl_icp* h) {
     (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
     void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, h->fd_buf[0], h->fd_buf[1], c.src0,
-                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.partials, c.wg_clk,
+                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.partials, c.wg_clk, c.gn_rows_ll, c.gn_xsum_ll,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter, h->d_row_mask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -146,6 +146,8 @@ static int icp_reset_device(ptl_icp* h) {
     HIPCHK(hipMemsetAsync(c.vmin2, 0xFF, vcap * 4, h->stream));
     HIPCHK(hipMemsetAsync(c.tab, 0xFF, ((size_t)c.tmask + 1) * sizeof(TabEnt), h->stream));
     HIPCHK(hipMemsetAsync(c.blocks, 0, (size_t)c.pool_cap * c.bstride, h->stream));
+    HIPCHK(hipMemsetAsync(c.gn_rows_ll, 0, (size_t)2 * c.G * 64 * 8, h->stream));  // the launch epoch restarts with the state
+    HIPCHK(hipMemsetAsync(c.gn_xsum_ll, 0, (size_t)2 * 8 * 8 * 64 * 8, h->stream));
     k_fill_free_stack<<<(c.pool_cap + 255) / 256, 256, 0, h->stream>>>(c.free_stack, c.pool_cap);
     k_state_init<<<1, 64, 0, h->stream>>>(c.st, c.pool_cap);
     HIPCHK(hipGetLastError());
@@ -163,7 +165,8 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     if (cfg->max_points_per_voxel < 1 || cfg->max_points_per_voxel > 254) return set_err(PTL_ERR_ARG, "max_points_per_voxel must be in [1, 254]");
     if (cfg->map_block_capacity < 1 || cfg->map_block_capacity >= (1 << 24) - 1) return set_err(PTL_ERR_ARG, "map_block_capacity must be below 2^24 - 1");
     if (cfg->map_table_capacity & (cfg->map_table_capacity - 1)) return set_err(PTL_ERR_ARG, "map_table_capacity must be a power of two");
-    if (cfg->max_points_per_scan < 1 || cfg->gn_workgroups < 1) return set_err(PTL_ERR_ARG, "bad capacity");
+    if (cfg->max_points_per_scan < 1 || cfg->gn_workgroups < 1 || cfg->gn_workgroups > 512) return set_err(PTL_ERR_ARG, "bad capacity (gn_workgroups must be in [1, 512])");
+    if (cfg->max_iterations < 1 || cfg->max_iterations > 1000) return set_err(PTL_ERR_ARG, "max_iterations must be in [1, 1000]");
     if (cfg->gn_threads < 256 || cfg->gn_threads > GN_MAX_THREADS || (cfg->gn_threads & 63)) return set_err(PTL_ERR_ARG, "gn_threads must be a multiple of 64 in [256, GN_MAX_THREADS]");
     if (ptl_device_count() <= cfg->device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->device_id);
     HIPCHK(hipSetDevice(cfg->device_id));
@@ -227,6 +230,8 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= hipMalloc((void**)&c.blocks, (size_t)c.pool_cap * c.bstride) == hipSuccess;
     ok &= dalloc(&c.free_stack, c.pool_cap) == hipSuccess;
     ok &= dalloc(&c.partials, (size_t)2 * c.G * 32) == hipSuccess;
+    ok &= dalloc(&c.gn_rows_ll, (size_t)2 * c.G * 64) == hipSuccess && hipMemset(c.gn_rows_ll, 0, (size_t)2 * c.G * 64 * 8) == hipSuccess;
+    ok &= dalloc(&c.gn_xsum_ll, (size_t)2 * 8 * 8 * 64) == hipSuccess && hipMemset(c.gn_xsum_ll, 0, (size_t)2 * 8 * 8 * 64 * 8) == hipSuccess;
     ok &= hipMalloc((void**)&c.wg_clk, (size_t)c.G * 16) == hipSuccess && hipMemset(c.wg_clk, 0, (size_t)c.G * 16) == hipSuccess;
     ok &= dalloc(&c.st, 1) == hipSuccess;
     ok &= dalloc(&c.traj, (size_t)h->traj_cap * 16) == hipSuccess;
@@ -503,12 +508,18 @@ extern "C" int ptl_icp_map_add(ptl_icp* h, const double* xyz_world, int64_t n, c
     return icp_check_flags(h);
 }
 
-__global__ void k_set_gn(DevState* st, int n_src, double max_dist, double kernel, const double* guess) {
-    if (threadIdx.x || blockIdx.x) return;
-    st->n_src = n_src; st->gn_max_dist = max_dist; st->gn_kernel = kernel;
-    for (int g = 0; g < 8; ++g) { st->bar_grp[g * 32] = 0; st->bar_gen[g * 32] = 0; }
-    st->bar_top = 0;
-    if (guess) for (int i = 0; i < 16; ++i) st->guess[i] = guess[i];
+__global__ void k_set_gn(Ctx c, int n_src, double max_dist, double kernel, const double* guess) {
+    DevState* st = c.st;
+    if (threadIdx.x == 0) {
+        st->n_src = n_src; st->gn_max_dist = max_dist; st->gn_kernel = kernel;
+        for (int g = 0; g < 8; ++g) { st->bar_grp[g * 32] = 0; st->bar_gen[g * 32] = 0; }
+        st->bar_top = 0;
+        st->gn_epoch = (st->gn_epoch + 1u) & 0x3FFFFFu;
+        if (guess) for (int i = 0; i < 16; ++i) st->guess[i] = guess[i];
+        __threadfence_block();
+    }
+    __syncthreads();
+    gn_ll_clear_on_wrap(c);
 }
 extern "C" int ptl_icp_linear_system(ptl_icp* h, const double* src_world, int64_t n, double max_dist, double kernel,
                                      double sums[27], int64_t* n_corr, int64_t* n_cand) {
@@ -517,7 +528,7 @@ extern "C" int ptl_icp_linear_system(ptl_icp* h, const double* src_world, int64_
     HIPCHK(hipSetDevice(h->cfg.device_id));
     Ctx& c = h->c;
     HIPCHK(hipMemcpyAsync(c.src_cur, src_world, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
-    k_set_gn<<<1, 64, 0, h->stream>>>(c.st, (int)n, max_dist, kernel, nullptr);
+    k_set_gn<<<1, 64, 0, h->stream>>>(c, (int)n, max_dist, kernel, nullptr);
     if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1);
     double out[32];
     HIPCHK(hipMemcpyAsync(out, (char*)c.st + offsetof(DevState, dbg_sums), sizeof out, hipMemcpyDeviceToHost, h->stream));
@@ -536,7 +547,7 @@ extern "C" int ptl_icp_align(ptl_icp* h, const double* frame, int64_t n, const d
     Ctx& c = h->c;
     HIPCHK(hipMemcpyAsync(c.src0, frame, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_ext, guess, 128, hipMemcpyHostToDevice, h->stream));
-    k_set_gn<<<1, 64, 0, h->stream>>>(c.st, (int)n, max_dist, kernel, h->d_ext);
+    k_set_gn<<<1, 64, 0, h->stream>>>(c, (int)n, max_dist, kernel, h->d_ext);
     if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 2); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 2);  // new_pose = T_icp * guess, trajectory untouched
     DevState st;
     HIPCHK(hipMemcpyAsync(&st, c.st, sizeof st, hipMemcpyDeviceToHost, h->stream));
