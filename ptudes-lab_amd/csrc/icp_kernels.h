@@ -669,10 +669,17 @@ struct PointWalk {
 __device__ __forceinline__ PointWalk point_walk(int n, int G, int wg, int NG, int grp) {
     PointWalk w;
     if ((G & 7) == 0) {
-        const int chunk = (n + 7) >> 3, x = wg & 7, j = wg >> 3;
-        w.first = x * chunk + j * NG + grp;
+        const int chunk = (n + 7) >> 3, x = wg & 7, j = wg >> 3, J = G >> 3;
         w.last = (x + 1) * chunk < n ? (x + 1) * chunk : n;
-        w.step = (G >> 3) * NG;
+        if (J > 1 && chunk <= (J - 1) * NG) {
+            // the share fits without the group leaders (wg < 8, j == 0): they take no points, so they are already
+            // waiting for their members' rows when the first one arrives (see the exchange in k_gn_loop)
+            w.first = (j == 0) ? w.last : x * chunk + (j - 1) * NG + grp;
+            w.step = (J - 1) * NG;
+        } else {
+            w.first = x * chunk + j * NG + grp;
+            w.step = J * NG;
+        }
     } else {
         w.first = wg * NG + grp; w.last = n; w.step = G * NG;
     }
@@ -755,6 +762,19 @@ __device__ __forceinline__ unsigned gn_ll_wait(const unsigned long long* p, unsi
         __builtin_amdgcn_s_sleep(1);
     }
 }
+// the same for two words of one row at once (both loads in flight together)
+__device__ __forceinline__ void gn_ll_wait2(const unsigned long long* p0, const unsigned long long* p1, bool second,
+                                            unsigned flag, unsigned* h0, unsigned* h1, bool* ok) {
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned long long a = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = second ? __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                            : ((unsigned long long)flag << 32);
+        if ((unsigned)(a >> 32) == flag && (unsigned)(b >> 32) == flag) { *h0 = (unsigned)a; *h1 = (unsigned)b; return; }
+        if (++spins > GN_LL_SPINS) { *ok = false; *h0 = 0u; *h1 = 0u; return; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 // lanes (2e, 2e + 1) of a wavefront hold the low / high half of entry e: the even lane returns the double
 __device__ __forceinline__ double gn_ll_join(unsigned half) {
     const unsigned other = (unsigned)__shfl_xor((int)half, 1);
@@ -816,9 +836,9 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     __syncthreads();
     long long cand_total = 0;
     int iters = 0, ncorr_last = 0;
-    long long ph[5] = {0, 0, 0, 0, 0}, ph_wait = 0;
+    long long ph[5] = {0, 0, 0, 0, 0}, ph_wait = 0, ph_x1 = 0, ph_x2 = 0;
     // one point per 32-lane group for the whole loop => its probe results can be cached across iterations
-    const bool single_pass = ((G & 7) == 0) ? (((n + 7) >> 3) <= (G >> 3) * NG) : (n <= G * NG);
+    const bool single_pass = ((G & 7) == 0) ? (((n + 7) >> 3) <= (G >> 3) * NG) : (n <= G * NG);  // (also true when the leaders idle)
     unsigned long long ckey = EMPTY_KEY;
     int cblk = -1;
     for (int it = 0; it < max_iter; ++it) {
@@ -886,47 +906,74 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const long long c2 = __builtin_readcyclecounter();
-        if (wg < ngroups) {  // leader of group wg: members wg, wg + 8, ...
+        if (wg < ngroups) {  // leader of group wg: members wg, wg + 8, ... ; every wavefront takes two of their rows
             const int nmem = (G - wg + 7) / 8;
             for (int j = grp; j < nmem; j += NG) {
                 const unsigned long long* row = c.gn_rows_ll + ((size_t)par * G + (wg + 8 * j)) * GN_LL_WORDS;
-                const unsigned h0 = gn_ll_wait(row + lane32, flag, &ok);
-                const unsigned h1 = (lane32 + 32 < 58) ? gn_ll_wait(row + lane32 + 32, flag, &ok) : 0u;
+                unsigned h0, h1;
+                gn_ll_wait2(row + lane32, row + lane32 + 32, lane32 + 32 < 58, flag, &h0, &h1, &ok);
                 const double v0 = gn_ll_join(h0), v1 = gn_ll_join(h1);
                 if ((lane32 & 1) == 0) {
                     redL[j][lane32 >> 1] = v0;
                     if (16 + (lane32 >> 1) < 29) redL[j][16 + (lane32 >> 1)] = v1;
                 }
             }
+            if (!ok) atomicOr(&st->err_flags, ERR_GN_TIMEOUT);
             __syncthreads();
-            if (tid < 29) {
+            ph_x1 += __builtin_readcyclecounter() - c2;
+            if (tid < 29) {  // sum in member order; each summing lane publishes both halves of its entry, one copy per consumer slot
                 double s = 0.0;
                 for (int j = 0; j < nmem; ++j) s += redL[j][tid];
-                stage[tid] = s;
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(s), fl = (unsigned long long)flag << 32;
+                const unsigned long long lo = (bits & 0xFFFFFFFFull) | fl, hi = (bits >> 32) | fl;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    unsigned long long* dst = c.gn_xsum_ll + (((size_t)par * 8 + r) * 8 + wg) * GN_LL_WORDS + 2 * tid;
+                    __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
-            __syncthreads();
-            if (tid < 8 * 64 && (tid & 63) < 58)  // one copy per consumer slot
-                __hip_atomic_store(&c.gn_xsum_ll[(((size_t)par * 8 + (tid >> 6)) * 8 + wg) * GN_LL_WORDS + (tid & 63)],
-                                   gn_ll_word(stage, tid & 63, flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // everybody: the group sums addressed to this workgroup's slot
-        if (tid < 8 * 64) {
-            const int xg = tid >> 6, w = tid & 63;
-            unsigned h = 0u;
-            if (xg < ngroups && w < 58)
-                h = gn_ll_wait(c.gn_xsum_ll + (((size_t)par * 8 + (wg & 7)) * 8 + xg) * GN_LL_WORDS + w, flag, &ok);
-            const double v = gn_ll_join(h);
-            if ((w & 1) == 0 && (w >> 1) < 29) red[xg][w >> 1] = (xg < ngroups) ? v : 0.0;
+        // The group sums are collected by ONE wavefront (lane l <-> word l of a row; lanes 2e, 2e + 1 hold the halves of
+        // entry e): nothing between the arrival of the last word and the solve needs LDS traffic but the 29 totals.
+        if (tid < 64) {
+            const bool mine = tid < 58, even = (tid & 1) == 0;
+            ok = true;
+            ph_x2 += __builtin_readcyclecounter() - c2;
+            // everybody: the group sums addressed to this workgroup's slot, added in group order
+            unsigned h[8];
+            unsigned spins = 0;
+            for (;;) {
+                unsigned long long vv[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    vv[g] = (unsigned long long)flag << 32;
+                    if (mine && g < ngroups)
+                        vv[g] = __hip_atomic_load(c.gn_xsum_ll + (((size_t)par * 8 + (wg & 7)) * 8 + g) * GN_LL_WORDS + tid,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                unsigned bad = 0u;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    bad |= (unsigned)(vv[g] >> 32) ^ flag;
+                    h[g] = (unsigned)vv[g];
+                }
+                if (__all(bad == 0u)) break;
+                if (++spins > GN_LL_SPINS) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            double t = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const double v = gn_ll_join(h[g]);
+                if (g < ngroups) t += v;
+            }
+            if (mine && even) tot[tid >> 1] = t;
+            if (!ok && tid == 0) atomicOr(&st->err_flags, ERR_GN_TIMEOUT);
         }
-        if (!ok) atomicOr(&st->err_flags, ERR_GN_TIMEOUT);
         __syncthreads();
         const long long c3 = __builtin_readcyclecounter();
-        if (tid < 29) {
-            double s = 0.0;
-            for (int g = 0; g < 8; ++g) s += red[g][tid];
-            tot[tid] = s;
-        }
-        __syncthreads();
+
         const long long c4 = __builtin_readcyclecounter();
         if (tid < 64) {  // one wavefront; every lane ends up with the same dx, lane 0 publishes
             double dx[6];
@@ -965,7 +1012,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         st->gn_cand = cand_total;
         for (int k = 0; k < 5; ++k) st->gn_phase_clk[k] += ph[k];
         st->gn_phase_clk[5] += iters;
-        st->gn_phase_clk[6] += ph_wait;  // part of phase 1 spent waiting for the workgroup's other wavefronts
+        st->gn_phase_clk[6] += ph_x1; st->gn_phase_clk[7] += ph_x2;  // part of phase 1 spent waiting for the workgroup's other wavefronts
         if (mode != 1) gn_post(c, st, false, mode == 0);
     }
 }

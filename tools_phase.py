@@ -13,7 +13,7 @@ r.run()
 icp = C.c_void_p(); L.check(L.lib().ptl_seq_icp(r._h, C.byref(icp)))
 out = (C.c_int64*8)(); L.check(L.lib().ptl_icp_gn_phases(icp, out))
 o = np.array(list(out), dtype=float); it=o[5]
-print("iters", it, "ticks/iter: nn %.0f wgred %.0f barrier %.0f gridred %.0f solve %.0f" % tuple(o[:5]/it), "total/iter", o[:5].sum()/it, "| of wgred, waiting for own WG: %.0f" % (o[6]/it))
+print("iters", it, "ticks/iter: nn %.0f wgred %.0f barrier %.0f gridred %.0f solve %.0f" % tuple(o[:5]/it), "total/iter", o[:5].sum()/it, "| leader: members in at +%.0f, group sum out at +%.0f (ticks after own publish)" % (o[6]/it, o[7]/it))
 
 G = kw.get("gn_workgroups", 256)
 wc = (C.c_int64 * (2 * G))(); L.check(L.lib().ptl_icp_gn_wg_clocks(icp, wc, G))
