@@ -150,7 +150,8 @@ int ptl_icp_set_active_beams(ptl_icp *h, int32_t H, int32_t beams_num);
 int ptl_icp_register_range(ptl_icp *h, ptl_lut *lut, const uint32_t *range_mm, double scan_ts, const double *guess,
                            double out_pose[16], ptl_icp_stats *stats);
 
-/* profiling: HIP-event time of the dominant kernel (the persistent Gauss-Newton loop) since last reset */
+/* profiling: HIP-event time of the dominant kernel (the persistent Gauss-Newton loop) since last reset; enable = n > 1
+ * times every n-th launch only (the two event records cost ~18 us per scan) */
 int ptl_icp_profile(ptl_icp *h, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
 /* diagnostic: accumulated clock ticks of workgroup 0 per phase of that kernel (nn, wg-reduce+publish, barrier,
  * grid-reduce, solve) and out[5] = iterations, since the handle was created / reset */

@@ -53,6 +53,7 @@ struct ptl_icp {
     int64_t last_n;      // points of the previous scan (its pass-2 VDS slots are released by the next K1)
     // profiling of the dominant kernel
     bool prof;
+    int prof_every;  // time every n-th GN launch (two event records cost ~18 us of command-processor time per scan)
     std::vector<hipEvent_t> ev;
     size_t ev_used;
     // set by the sequence runner: the GN kernel waits for `gn_wait` (the EKF stream produced the guess) and
@@ -174,7 +175,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     h->cfg = *cfg;
     h->own_stream = shared_stream == nullptr;
     h->stream = shared_stream;
-    h->prof = false; h->ev_used = 0; h->gn_ms = 0; h->gn_launches = 0;
+    h->prof = false; h->prof_every = 1; h->ev_used = 0; h->gn_ms = 0; h->gn_launches = 0;
     h->gn_wait = nullptr; h->gn_done = nullptr;
     h->post_ekf.on = false;
     h->map_stream = nullptr; h->ev_map = nullptr; h->ev_map_valid = false;
@@ -315,7 +316,8 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     if (h->ev_map_valid) HIPCHK(hipStreamWaitEvent(s, h->ev_map, 0));
     if (h->gn_wait) HIPCHK(hipStreamWaitEvent(s, h->gn_wait, 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->prof) {
+    const bool timed = h->prof && (h->scans_done % h->prof_every) == 0;
+    if (timed) {
         if (h->ev_used + 2 > h->ev.size()) {
             for (int k = 0; k < 2; ++k) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev.push_back(e); }
         }
@@ -323,7 +325,7 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
         HIPCHK(hipEventRecord(e0, s));
     }
     if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0);  // ends with the post-ICP bookkeeping (kiss.py:116-128)
-    if (h->prof) HIPCHK(hipEventRecord(e1, s));
+    if (timed) HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipEventRecord(h->ev_gn, s));
     h->ev_gn_valid = true;
     if (h->gn_done) HIPCHK(hipEventRecord(h->gn_done, s));
@@ -587,6 +589,7 @@ extern "C" int ptl_icp_profile(ptl_icp* h, int enable, double* gn_ms_total, int6
     if (gn_launches) *gn_launches = h->gn_launches;
     if (reset) { h->gn_ms = 0; h->gn_launches = 0; }
     h->prof = enable != 0;
+    h->prof_every = enable > 1 ? enable : 1;
     return PTL_OK;
 }
 
