@@ -499,25 +499,27 @@ __device__ __forceinline__ int voxel_index(double x, double vs, double inv_vs) {
 // voxel can offer neither.  The surviving voxels are scanned two at a time.
 // Returns in every lane of the group: best squared distance, best target, found flag; adds this lane's probe
 // count to ncand (the caller sums the lanes).
-template <int PC, class CT>
-__device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
-                                            long long& ncand, unsigned long long& ck, int& cblk, bool use_cache) {
-    const int P = (PC > 0) ? PC : c.P;  // compile-time for the default 20: y / z become immediate offsets of x
-    const double inv_vs = 1.0 / c.vs;   // loop-invariant
-    const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
-    const unsigned long long key = pack_key(kx, ky, kz);
+// probe of this lane's neighbour voxel (lanes 0..26, (i,j,k) ascending): packed block id | count << 24, or -1
+template <class CT>
+__device__ __forceinline__ int nn_probe32(const CT& c, int kx, int ky, int kz, int lane32) {
+    if (lane32 >= 27) return -1;
     const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
-    int pb = -1;
-    if (use_cache && key == ck) {
-        pb = cblk;
-    } else if (lane32 < 27) {
-        pb = map_find(c, pack_key(kx + di, ky + dj, kz + dk));
-    }
-    ck = key;
-    cblk = pb;
+    return map_find(c, pack_key(kx + di, ky + dj, kz + dk));
+}
+// The scan proper, given the probe results.  With MARGIN it also returns, squared and with 1e-6 relative slack, how
+// far the point may move before the answer has to be searched again: if it moves by delta, the neighbour found is
+// at most d_best + delta away and every other candidate at least d_other - delta, so while 2 delta < d_other - d_best
+// the neighbour is unchanged and strictly closest (no tie rule applies).  d_other bounds ALL other candidates of the
+// 27 voxels: those examined and the voxels dropped by their box distance - provided the point stays in its voxel
+// (same candidate set), which the caller checks.
+template <int PC, bool MARGIN, class CT>
+__device__ __forceinline__ bool nn_scan32(const CT& c, V3 s, int kx, int ky, int kz, int pb, int lane32, int gbase,
+                                          V3& best, double& best_d2, double& margin2) {
+    const int P = (PC > 0) ? PC : c.P;  // compile-time for the default 20: y / z become immediate offsets of x
+    const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
     const int cnt0 = (pb < 0) ? 0 : (int)((unsigned)pb >> 24);
-    ncand += cnt0;
     double bd = 1.7976931348623157e308;
+    double sec = 1.7976931348623157e308;  // MARGIN: lower bound (squared) on this lane's candidates other than its best
     unsigned border = 0xFFFFFFFFu;  // visiting order of a candidate: voxel lane * 32 + slot
     V3 bp = v3(0, 0, 0);
     bool keep = lane32 != 13 && cnt0 > 0;
@@ -546,7 +548,10 @@ __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int g
         }
         double m = bd;
         for (int o = 16; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));
-        keep = keep && !(gap2 > m);
+        if (keep && gap2 > m) {  // a dropped voxel: every point in it is at least this far
+            keep = false;
+            if (MARGIN) sec = gap2;
+        }
     }
     unsigned todo = (unsigned)(__ballot(keep) >> gbase);  // this group's surviving voxels, visited in ascending order
     while (todo) {
@@ -564,13 +569,19 @@ __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int g
             const double dx = q0x - s.x, dy = q0y - s.y, dz = q0z - s.z;
             const double d2 = dx * dx + dy * dy + dz * dz;
             const unsigned id = (unsigned)(v0 * 32 + lane32);
-            if (d2 < bd || (d2 == bd && id < border)) { bd = d2; border = id; bp = v3(q0x, q0y, q0z); }
+            if (d2 < bd || (d2 == bd && id < border)) {
+                if (MARGIN) sec = fmin(sec, bd);
+                bd = d2; border = id; bp = v3(q0x, q0y, q0z);
+            } else if (MARGIN) sec = fmin(sec, d2);
         }
         if (a1) {
             const double dx = q1x - s.x, dy = q1y - s.y, dz = q1z - s.z;
             const double d2 = dx * dx + dy * dy + dz * dz;
             const unsigned id = (unsigned)(v1 * 32 + lane32);
-            if (d2 < bd || (d2 == bd && id < border)) { bd = d2; border = id; bp = v3(q1x, q1y, q1z); }
+            if (d2 < bd || (d2 == bd && id < border)) {
+                if (MARGIN) sec = fmin(sec, bd);
+                bd = d2; border = id; bp = v3(q1x, q1y, q1z);
+            } else if (MARGIN) sec = fmin(sec, d2);
         }
     }
     // lexicographic (d2, visiting order) minimum over the 32 lanes: the distance, then the order among the lanes
@@ -580,11 +591,35 @@ __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int g
     unsigned bo = (bd == m) ? border : 0xFFFFFFFFu;
     for (int o = 16; o > 0; o >>= 1) bo = min(bo, (unsigned)__shfl_xor((int)bo, o));
     const bool found = bo != 0xFFFFFFFFu;
-    const unsigned win = (unsigned)(__ballot(found && bd == m && border == bo) >> gbase);
+    const bool winner = found && bd == m && border == bo;
+    const unsigned win = (unsigned)(__ballot(winner) >> gbase);
     const int wl = gbase + (win ? __ffs(win) - 1 : 0);
     best = v3(__shfl(bp.x, wl), __shfl(bp.y, wl), __shfl(bp.z, wl));
     best_d2 = m;
+    if (MARGIN) {
+        double o2 = winner ? sec : fmin(sec, bd);  // the winner's own best is the answer itself
+        for (int o = 16; o > 0; o >>= 1) o2 = fmin(o2, __shfl_xor(o2, o));
+        margin2 = 0.0;
+        if (found) {
+            const double gapd = sqrt(o2) - sqrt(m);
+            if (gapd > 1e-6) margin2 = gapd * gapd * (1.0 - 1e-6);
+        }
+    }
     return found;
+}
+// probe (or reuse this lane's previous probe while the point has not left its voxel) + scan
+template <int PC, class CT>
+__device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
+                                            long long& ncand, unsigned long long& ck, int& cblk, bool use_cache) {
+    const double inv_vs = 1.0 / c.vs;   // loop-invariant
+    const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
+    const unsigned long long key = pack_key(kx, ky, kz);
+    const int pb = (use_cache && key == ck) ? cblk : nn_probe32(c, kx, ky, kz, lane32);
+    ck = key;
+    cblk = pb;
+    ncand += (pb < 0) ? 0 : (int)((unsigned)pb >> 24);
+    double unused;
+    return nn_scan32<PC, false>(c, s, kx, ky, kz, pb, lane32, gbase, best, best_d2, unused);
 }
 
 // column `idx` of the 3x7 matrix [ I | -hat(s) | r ]: the Jacobian J = [I | -hat(s)] of Registration.cpp
