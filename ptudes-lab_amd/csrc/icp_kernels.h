@@ -835,6 +835,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     __shared__ double Esh[12];
     __shared__ double Tsh[12];
     __shared__ double stage[32];
+    __shared__ double scur[GN_MAX_GROUPS][4];
     __shared__ double redL[64][32];  // a leader's member rows (G <= 512)
     __shared__ int flag_done;
     DevState* st = c.st;
@@ -893,8 +894,14 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             V3 s;
             if (it == 0 && mode != 1) s = rt_apply(E, v3(c.src0[3 * (size_t)i], c.src0[3 * (size_t)i + 1], c.src0[3 * (size_t)i + 2]));
             else if (it == 0) s = v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]);
+            else if (single_pass) s = rt_apply(E, v3(scur[grp][0], scur[grp][1], scur[grp][2]));  // the group's only point
             else s = rt_apply(E, v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]));
-            if (lane32 == 0 && !(it == 0 && mode == 1)) {
+            if (single_pass) {
+                // one point per group for the whole loop: its current position stays in LDS (a global round trip at
+                // the head of every iteration's dependent chain otherwise)
+                __builtin_amdgcn_wave_barrier();
+                if (lane32 == 0) { scur[grp][0] = s.x; scur[grp][1] = s.y; scur[grp][2] = s.z; }
+            } else if (lane32 == 0 && !(it == 0 && mode == 1)) {
                 c.src_cur[3 * (size_t)i] = s.x; c.src_cur[3 * (size_t)i + 1] = s.y; c.src_cur[3 * (size_t)i + 2] = s.z;
             }
             V3 t;
