@@ -499,6 +499,32 @@ __device__ __forceinline__ int voxel_index(double x, double vs, double inv_vs) {
 // voxel can offer neither.  The surviving voxels are scanned two at a time.
 // Returns in every lane of the group: best squared distance, best target, found flag; adds this lane's probe
 // count to ncand (the caller sums the lanes).
+// Minimum over the 32 lanes of a group, result in every lane.  Four of the five butterfly steps are DPP moves inside the
+// VALU (quad permutes, then the half-row / row mirrors: every lane of a quad already holds the quad's minimum, so
+// pairing mirrored lanes is as good as xor 4 / xor 8); only the step across the two 16-lane rows goes through the
+// LDS crossbar.  min is exact and commutative: the value is the one the plain xor butterfly gives.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double group_min32(double v) {
+    v = fmin(v, dpp_f64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmin(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmin(v, dpp_f64<0x141>(v));  // row_half_mirror
+    v = fmin(v, dpp_f64<0x140>(v));  // row_mirror
+    return fmin(v, __shfl_xor(v, 16));
+}
+__device__ __forceinline__ unsigned group_min32(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));
+    return min(v, (unsigned)__shfl_xor((int)v, 16));
+}
+
 // probe of this lane's neighbour voxel (lanes 0..26, (i,j,k) ascending): packed block id | count << 24, or -1
 template <class CT>
 __device__ __forceinline__ int nn_probe32(const CT& c, int kx, int ky, int kz, int lane32) {
@@ -546,8 +572,7 @@ __device__ __forceinline__ bool nn_scan32(const CT& c, V3 s, int kx, int ky, int
             g = (d[a] == 0) ? 0.0 : fmax(g, 0.0);
             gap2 += g * g;
         }
-        double m = bd;
-        for (int o = 16; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));
+        const double m = group_min32(bd);
         if (keep && gap2 > m) {  // a dropped voxel: every point in it is at least this far
             keep = false;
             if (MARGIN) sec = gap2;
@@ -586,10 +611,8 @@ __device__ __forceinline__ bool nn_scan32(const CT& c, V3 s, int kx, int ky, int
     }
     // lexicographic (d2, visiting order) minimum over the 32 lanes: the distance, then the order among the lanes
     // that hold it, then the winner lane hands out its point
-    double m = bd;
-    for (int o = 16; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));
-    unsigned bo = (bd == m) ? border : 0xFFFFFFFFu;
-    for (int o = 16; o > 0; o >>= 1) bo = min(bo, (unsigned)__shfl_xor((int)bo, o));
+    const double m = group_min32(bd);
+    const unsigned bo = group_min32((bd == m) ? border : 0xFFFFFFFFu);
     const bool found = bo != 0xFFFFFFFFu;
     const bool winner = found && bd == m && border == bo;
     const unsigned win = (unsigned)(__ballot(winner) >> gbase);
