@@ -525,6 +525,14 @@ __device__ __forceinline__ unsigned group_min32(unsigned v) {
     return min(v, (unsigned)__shfl_xor((int)v, 16));
 }
 
+__device__ __forceinline__ int group_sum32(int v) {  // integer sum over the 32 lanes of a group (order-free), same moves
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    return v + __shfl_xor(v, 16);
+}
+
 // probe of this lane's neighbour voxel (lanes 0..26, (i,j,k) ascending): packed block id | count << 24, or -1
 template <class CT>
 __device__ __forceinline__ int nn_probe32(const CT& c, int kx, int ky, int kz, int lane32) {
@@ -940,8 +948,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         }
         const long long c1 = __builtin_readcyclecounter();
         // workgroup reduction in fixed order (column 28 carries the candidate count)
-        long long ncand0 = ncand;  // sum of the per-lane probe counts over the 32 lanes of the group
-        for (int o = 16; o > 0; o >>= 1) ncand0 += __shfl_xor(ncand0, o);
+        const int ncand0 = group_sum32((int)ncand);  // sum of the per-lane probe counts over the 32 lanes of the group
         {
             // workgroup reduction, fixed tree: the two groups of a wavefront, then 4 segments of wavefronts, then 4 -> 1
             const double mine = (lane32 == 28) ? (double)ncand0 : acc;
@@ -1463,8 +1470,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
                     else if (lane32 == 27) acc += 1.0;
                 }
             }
-            long long ncand0 = ncand;
-            for (int o = 16; o > 0; o >>= 1) ncand0 += __shfl_xor(ncand0, o);
+            const int ncand0 = group_sum32((int)ncand);
             const double mine = (lane32 == 28) ? (double)ncand0 : acc;
             const double pair = mine + __shfl_xor(mine, 32);
             if ((tid & 63) < 32) red[s][tid >> 6][lane32] = pair;
