@@ -843,7 +843,7 @@ __device__ __forceinline__ void gn_ll_wait2(const unsigned long long* p0, const 
 }
 // lanes (2e, 2e + 1) of a wavefront hold the low / high half of entry e: the even lane returns the double
 __device__ __forceinline__ double gn_ll_join(unsigned half) {
-    const unsigned other = (unsigned)__shfl_xor((int)half, 1);
+    const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)half, 0xB1, 0xF, 0xF, true);  // lane ^ 1
     return __longlong_as_double((long long)(((unsigned long long)other << 32) | half));  // meaningful in even lanes
 }
 
