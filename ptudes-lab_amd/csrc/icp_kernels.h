@@ -114,7 +114,6 @@ struct Ctx {
     int bstride, pool_cap;
     int* free_stack;
     // GN
-    double* partials;
     int G;
     // state / outputs
     DevState* st;
@@ -847,10 +846,11 @@ __device__ __forceinline__ double gn_ll_join(unsigned half) {
     return __longlong_as_double((long long)(((unsigned long long)other << 32) | half));  // meaningful in even lanes
 }
 
-// Persistent Gauss-Newton loop (Registration.cpp RegisterFrame).  G workgroups, all resident; one grid
-// barrier per iteration; every workgroup sums all partials in the same fixed order and solves the 6x6
-// system redundantly, so all agree bit-for-bit on dx and on convergence.  Within a 32-lane group lane k
-// accumulates entry k of the 27 sums (21 JTJ upper triangle + 6 JTr); lane 27 counts pairs.
+// Persistent Gauss-Newton loop (Registration.cpp RegisterFrame).  G workgroups, all resident; per iteration the
+// workgroups' 29 sums meet through the flag-in-word exchange above (rows -> 8 group leaders -> group sums to everybody,
+// fixed summation order), and every workgroup solves the 6x6 system redundantly from the same totals, so all agree
+// bit-for-bit on dx and on convergence.  Within a 32-lane group lane k accumulates entry k of the 27 sums (21 JTJ
+// upper triangle + 6 JTr); lane 27 counts pairs.
 // mode 0: a scan: source = guess * src0, loop to convergence, then the post-ICP bookkeeping.
 // mode 1: src_cur given in world frame, one pass, sums exported to st->dbg_sums (teacher-forced entry).
 // mode 2: like 0 without touching the trajectory (ptl_icp_align).
