@@ -250,3 +250,23 @@ def test_dense_map_config_vs_oracle():
         dt, dr = _pose_diff(Tr, Tg)
         assert dt <= ICP_T_TOL and dr <= ICP_R_TOL, (k, dt, dr)
     assert sg["n_src"] > 20000 and sg["map_voxels"] > 100000
+
+
+@pytest.mark.parametrize("wgs,threads", [(1, 256), (3, 512), (8, 1024), (20, 256), (64, 1024), (256, 512)])
+def test_gn_launch_shapes_agree(seq, wgs, threads):
+    """The Gauss-Newton kernel's exchange (group leaders, idle leaders, multi-pass point walk, fewer than 8 groups)
+    must not depend on the launch shape beyond the association of the sums: poses within 1e-10 of the default shape,
+    integer statistics identical."""
+    gt = seq.gt_poses(0.5)
+    g0i = np.linalg.inv(gt[0])
+    ref = core.Icp(70.0, 1.0)
+    alt = core.Icp(70.0, 1.0, gn_workgroups=wgs, gn_threads=threads)
+    for k in range(5):
+        x = seq.scan(k)
+        guess = g0i @ gt[k]
+        Tr = ref.register_frame(x, None, guess)
+        Ta = alt.register_frame(x, None, guess)
+        dt, dr = _pose_diff(Tr, Ta)
+        assert dt <= 1e-10 and dr <= 1e-10, (k, dt, dr)
+        for key in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "sum_cand", "map_voxels", "map_points"):
+            assert ref.stats[-1][key] == alt.stats[-1][key], (k, key)
