@@ -640,7 +640,7 @@ __device__ __forceinline__ bool nn_scan32(const CT& c, V3 s, int kx, int ky, int
 // probe (or reuse this lane's previous probe while the point has not left its voxel) + scan
 template <int PC, class CT>
 __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
-                                            long long& ncand, unsigned long long& ck, int& cblk, bool use_cache) {
+                                            int& ncand, unsigned long long& ck, int& cblk, bool use_cache) {
     const double inv_vs = 1.0 / c.vs;   // loop-invariant
     const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
     const unsigned long long key = pack_key(kx, ky, kz);
@@ -854,6 +854,14 @@ __device__ __forceinline__ double gn_ll_join(unsigned half) {
 // mode 0: a scan: source = guess * src0, loop to convergence, then the post-ICP bookkeeping.
 // mode 1: src_cur given in world frame, one pass, sums exported to st->dbg_sums (teacher-forced entry).
 // mode 2: like 0 without touching the trajectory (ptl_icp_align).
+// In-kernel phase clocks (tools_phase.py, ptl_icp_gn_phases / ptl_icp_gn_wg_clocks) are compiled in only with
+// -DGN_PHASE_CLOCKS (make PHASES=1): eight 64-bit accumulators and the counter reads otherwise compete with the loop's
+// live values for scalar and vector registers (the kernel runs at its 128-VGPR cap and spills).
+#ifdef GN_PHASE_CLOCKS
+#define GN_CLK() ((long long)__builtin_readcyclecounter())
+#else
+#define GN_CLK() (0ll)
+#endif
 #ifndef GN_MAX_THREADS
 #define GN_MAX_THREADS 512
 #endif
@@ -901,20 +909,21 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
     }
     __syncthreads();
-    long long cand_total = 0;
-    int iters = 0, ncorr_last = 0;
+    __shared__ long long cand_total_sh;  // (kept out of the registers: only workgroup 0 reads it, after the loop)
+    if (tid == 0) cand_total_sh = 0;
+    int iters = 0;
     long long ph[5] = {0, 0, 0, 0, 0}, ph_wait = 0, ph_x1 = 0, ph_x2 = 0;
     // one point per 32-lane group for the whole loop => its probe results can be cached across iterations
     const bool single_pass = ((G & 7) == 0) ? (((n + 7) >> 3) <= (G >> 3) * NG) : (n <= G * NG);  // (also true when the leaders idle)
     unsigned long long ckey = EMPTY_KEY;
     int cblk = -1;
     for (int it = 0; it < max_iter; ++it) {
-        const long long c0 = __builtin_readcyclecounter();
+        const long long c0 = GN_CLK();
         // T_icp <- e T_icp for the previous iteration's increment, off the serial tail: one lane of the second
         // wavefront does it while everybody searches (Esh is not rewritten before the next solve)
         if (tid == 64 && it > 0) gn_compose(Esh, Tsh);
         double acc = 0.0;
-        long long ncand = 0;
+        int ncand = 0;
         const PointWalk pw = point_walk(n, G, wg, NG, grp);
         for (int i = pw.first; i < pw.last; i += pw.step) {
             // lazily apply the previous iteration's increment (TransformPoints(estimation, source)); the increment is
@@ -946,9 +955,9 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
                 else if (lane32 == 27) acc += 1.0;
             }
         }
-        const long long c1 = __builtin_readcyclecounter();
+        const long long c1 = GN_CLK();
         // workgroup reduction in fixed order (column 28 carries the candidate count)
-        const int ncand0 = group_sum32((int)ncand);  // sum of the per-lane probe counts over the 32 lanes of the group
+        const int ncand0 = group_sum32(ncand);  // sum of the per-lane probe counts over the 32 lanes of the group
         {
             // workgroup reduction, fixed tree: the two groups of a wavefront, then 4 segments of wavefronts, then 4 -> 1
             const double mine = (lane32 == 28) ? (double)ncand0 : acc;
@@ -956,7 +965,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             if ((tid & 63) < 32) red[tid >> 6][lane32] = pair;
         }
         __syncthreads();
-        const long long c1b = __builtin_readcyclecounter();
+        const long long c1b = GN_CLK();
         if (tid < 128) {
             const int col = tid & 31, seg = tid >> 5, NW = NG >> 1, per = (NW + 3) >> 2;
             double s = 0.0;
@@ -977,7 +986,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
                 __hip_atomic_store(&c.gn_rows_ll[((size_t)par * G + wg) * GN_LL_WORDS + tid], gn_ll_word(stage, tid, flag),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const long long c2 = __builtin_readcyclecounter();
+        const long long c2 = GN_CLK();
         if (wg < ngroups) {  // leader of group wg: members wg, wg + 8, ... ; every wavefront takes two of their rows
             const int nmem = (G - wg + 7) / 8;
             for (int j = grp; j < nmem; j += NG) {
@@ -992,7 +1001,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             }
             if (!ok) atomicOr(&st->err_flags, ERR_GN_TIMEOUT);
             __syncthreads();
-            ph_x1 += __builtin_readcyclecounter() - c2;
+            ph_x1 += GN_CLK() - c2;
             if (tid < 29) {  // sum in member order; each summing lane publishes both halves of its entry, one copy per consumer slot
                 double s = 0.0;
                 for (int j = 0; j < nmem; ++j) s += redL[j][tid];
@@ -1011,7 +1020,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         if (tid < 64) {
             const bool mine = tid < 58, even = (tid & 1) == 0;
             ok = true;
-            ph_x2 += __builtin_readcyclecounter() - c2;
+            ph_x2 += GN_CLK() - c2;
             // everybody: the group sums addressed to this workgroup's slot, added in group order
             unsigned h[8];
             unsigned spins = 0;
@@ -1044,9 +1053,9 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             if (!ok && tid == 0) atomicOr(&st->err_flags, ERR_GN_TIMEOUT);
         }
         __syncthreads();
-        const long long c3 = __builtin_readcyclecounter();
+        const long long c3 = GN_CLK();
 
-        const long long c4 = __builtin_readcyclecounter();
+        const long long c4 = GN_CLK();
         if (tid < 64) {  // one wavefront; every lane ends up with the same dx, lane 0 publishes
             double dx[6];
             solve6_ldlt_wave(tot, tid, dx);
@@ -1060,11 +1069,10 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
           }
         }
         __syncthreads();
-        const long long c5 = __builtin_readcyclecounter();
+        const long long c5 = GN_CLK();
         ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
         ph_wait += c1b - c1;
-        cand_total += (long long)tot[28];
-        ncorr_last = (int)tot[27];
+        if (tid == 0) cand_total_sh += (long long)tot[28];
         iters = it + 1;
         const int done = flag_done;
         if (mode == 1 && wg == 0 && tid < 29) st->dbg_sums[tid] = tot[tid];
@@ -1080,8 +1088,8 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         for (int k = 0; k < 3; ++k) T.t[k] = Tsh[9 + k];
         rt_to16(T, st->T_icp);
         st->gn_iters = iters;
-        st->gn_ncorr = ncorr_last;
-        st->gn_cand = cand_total;
+        st->gn_ncorr = iters > 0 ? (int)tot[27] : 0;  // the last iteration's totals are still in LDS
+        st->gn_cand = cand_total_sh;
         for (int k = 0; k < 5; ++k) st->gn_phase_clk[k] += ph[k];
         st->gn_phase_clk[5] += iters;
         st->gn_phase_clk[6] += ph_x1; st->gn_phase_clk[7] += ph_x2;  // part of phase 1 spent waiting for the workgroup's other wavefronts
@@ -1428,7 +1436,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
     long long ph[5] = {0, 0, 0, 0, 0};
     int n_it = 0;
     for (int it = 0; it < b.max_iter; ++it) {
-        const long long c0 = __builtin_readcyclecounter();
+        const long long c0 = GN_CLK();
         bool all_done = true;
         for (int s = 0; s < S; ++s) all_done = all_done && (done_sh[s] != 0);
         if (all_done) break;
@@ -1448,7 +1456,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
             const int n = c.st->n_src;
             const double max_dist = c.st->gn_max_dist, kern = c.st->gn_kernel, k2 = kern * kern;
             double acc = 0.0;
-            long long ncand = 0;
+            int ncand = 0;
             Rt E;
             for (int k = 0; k < 9; ++k) E.R[k] = Esh[s][k];
             for (int k = 0; k < 3; ++k) E.t[k] = Esh[s][9 + k];
@@ -1470,13 +1478,13 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
                     else if (lane32 == 27) acc += 1.0;
                 }
             }
-            const int ncand0 = group_sum32((int)ncand);
+            const int ncand0 = group_sum32(ncand);
             const double mine = (lane32 == 28) ? (double)ncand0 : acc;
             const double pair = mine + __shfl_xor(mine, 32);
             if ((tid & 63) < 32) red[s][tid >> 6][lane32] = pair;
         }
         __syncthreads();
-        const long long c1 = __builtin_readcyclecounter();
+        const long long c1 = GN_CLK();
         // workgroup reduction of every active sequence, same tree as k_gn_loop, then publish
         for (int s = 0; s < S; ++s) {
             if (done_sh[s]) continue;
@@ -1496,10 +1504,10 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const long long c2 = __builtin_readcyclecounter();
+        const long long c2 = GN_CLK();
         if (tid == 0) grid_barrier(st0, G, wg, it);
         __syncthreads();
-        const long long c3 = __builtin_readcyclecounter();
+        const long long c3 = GN_CLK();
         // grid reduction, up to four sequences per round with the single-sequence tree (8 strided parts, then 8 -> 1)
         const int per_round = (int)(blockDim.x >> 8) < 4 ? (int)(blockDim.x >> 8) : 4;  // 256 threads per sequence
         for (int s0 = 0; s0 < S; s0 += per_round) {
@@ -1534,7 +1542,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
             }
             __syncthreads();
         }
-        const long long c4 = __builtin_readcyclecounter();
+        const long long c4 = GN_CLK();
         // one solving thread per sequence, in different wavefronts
         if ((tid & 63) == 0 && (tid >> 6) < S && !done_sh[tid >> 6]) {
             const int s = tid >> 6;
@@ -1555,7 +1563,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
             if (sqrt(nn) < b.q[s].conv) done_sh[s] = 1;
         }
         __syncthreads();
-        const long long c5 = __builtin_readcyclecounter();
+        const long long c5 = GN_CLK();
         ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
         ++n_it;
     }
