@@ -966,25 +966,36 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         }
         __syncthreads();
         const long long c1b = GN_CLK();
-        if (tid < 128) {
-            const int col = tid & 31, seg = tid >> 5, NW = NG >> 1, per = (NW + 3) >> 2;
-            double s = 0.0;
-            for (int g = seg * per; g < (seg + 1) * per && g < NW; ++g) s += red[g][col];
-            red2[seg][col] = s;
-        }
-        __syncthreads();
         // ---- exchange: workgroup row -> the leader of its group (wg & 7) -> group sums to everybody.  The leader adds
         // its members' rows in member order and everybody adds the group sums in group order: the association the
         // counter-barrier version used (8 strided partial sums, then 8 -> 1), bit for bit.
         const unsigned flag = gn_flag(epoch, it);
         const int par = it & 1, ngroups = G < 8 ? G : 8;
         bool ok = true;
-        if (tid < 64) {  // one wavefront
-            if (tid < 29) stage[tid] = ((red2[0][tid] + red2[1][tid]) + red2[2][tid]) + red2[3][tid];
-            __builtin_amdgcn_wave_barrier();
-            if (tid < 58)
-                __hip_atomic_store(&c.gn_rows_ll[((size_t)par * G + wg) * GN_LL_WORDS + tid], gn_ll_word(stage, tid, flag),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 58) {
+            // lanes 2e, 2e + 1 of the first wavefront both form entry e of the workgroup's row - the 4 segments of
+            // wavefronts, then 4 -> 1, the tree the batched kernel builds through LDS - and store one half each
+            const int e = tid >> 1, NW = NG >> 1, per = (NW + 3) >> 2;
+            double sg[4];
+            if (NW == 16) {  // 1024 threads: all 16 reads in flight, then the same additions
+                double r[16];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) r[g] = red[g][e];
+#pragma unroll
+                for (int seg = 0; seg < 4; ++seg) sg[seg] = (((0.0 + r[4 * seg]) + r[4 * seg + 1]) + r[4 * seg + 2]) + r[4 * seg + 3];
+            } else {
+#pragma unroll
+                for (int seg = 0; seg < 4; ++seg) {
+                    double v = 0.0;
+                    for (int g = seg * per; g < (seg + 1) * per && g < NW; ++g) v += red[g][e];
+                    sg[seg] = v;
+                }
+            }
+            const double rowv = ((sg[0] + sg[1]) + sg[2]) + sg[3];
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(rowv);
+            const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+            __hip_atomic_store(&c.gn_rows_ll[((size_t)par * G + wg) * GN_LL_WORDS + tid],
+                               (unsigned long long)half | ((unsigned long long)flag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const long long c2 = GN_CLK();
         if (wg < ngroups) {  // leader of group wg: members wg, wg + 8, ... ; every wavefront takes two of their rows
