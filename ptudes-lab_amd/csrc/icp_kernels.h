@@ -1015,7 +1015,15 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             ph_x1 += GN_CLK() - c2;
             if (tid < 29) {  // sum in member order; each summing lane publishes both halves of its entry, one copy per consumer slot
                 double s = 0.0;
-                for (int j = 0; j < nmem; ++j) s += redL[j][tid];
+                if (nmem == 32) {  // 256 workgroups: all reads in flight, then the same additions in member order
+                    double r[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) r[j] = redL[j][tid];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) s += r[j];
+                } else {
+                    for (int j = 0; j < nmem; ++j) s += redL[j][tid];
+                }
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(s), fl = (unsigned long long)flag << 32;
                 const unsigned long long lo = (bits & 0xFFFFFFFFull) | fl, hi = (bits >> 32) | fl;
 #pragma unroll
