@@ -809,6 +809,9 @@ __device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_emp
 // iterations ahead of a reader (a workgroup leaves iteration i only after every leader published i, and a leader
 // publishes only after every one of its members did).
 #define GN_LL_WORDS 64   /* words per row: 58 used */
+#ifndef GN_XSUM_COPIES
+#define GN_XSUM_COPIES 8  /* copies of every group sum (power of two <= 8): consumers are spread over them */
+#endif
 #define GN_LL_SPINS (1u << 22)
 __device__ __forceinline__ unsigned gn_flag(unsigned epoch, int it) { return (epoch << 10) | (unsigned)(it + 1); }
 // word `w` (0..57) of a row holding the doubles vals[0..28]
@@ -1027,7 +1030,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(s), fl = (unsigned long long)flag << 32;
                 const unsigned long long lo = (bits & 0xFFFFFFFFull) | fl, hi = (bits >> 32) | fl;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
+                for (int r = 0; r < GN_XSUM_COPIES; ++r) {
                     unsigned long long* dst = c.gn_xsum_ll + (((size_t)par * 8 + r) * 8 + wg) * GN_LL_WORDS + 2 * tid;
                     __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1049,7 +1052,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
                 for (int g = 0; g < 8; ++g) {
                     vv[g] = (unsigned long long)flag << 32;
                     if (mine && g < ngroups)
-                        vv[g] = __hip_atomic_load(c.gn_xsum_ll + (((size_t)par * 8 + (wg & 7)) * 8 + g) * GN_LL_WORDS + tid,
+                        vv[g] = __hip_atomic_load(c.gn_xsum_ll + (((size_t)par * 8 + (wg & (GN_XSUM_COPIES - 1))) * 8 + g) * GN_LL_WORDS + tid,
                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 unsigned bad = 0u;
