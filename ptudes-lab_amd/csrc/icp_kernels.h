@@ -205,8 +205,31 @@ __device__ __forceinline__ void gn_ll_clear_on_wrap(const Ctx& c) {
 }
 __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
     DevState* st = c.st;
+    // The pose block of the state (first, previous, last, new, model deviation: 80 doubles) is brought into LDS by 80
+    // threads at once, one thread does the bookkeeping on it, and the three poses that changed go back in parallel:
+    // two memory round trips instead of a chain of about a hundred dependent global accesses by one thread.
+    __shared__ double sp[5][16];
+    __shared__ int s_closed, s_nposes, s_moved;
+    __shared__ double s_err;
+    if (threadIdx.x < 80) {
+        const int a = threadIdx.x >> 4, k = threadIdx.x & 15;
+        const double* src = a == 0 ? st->pose_first : a == 1 ? st->pose_prev : a == 2 ? st->pose_last : a == 3 ? st->new_pose : st->model_dev;
+        sp[a][k] = src[k];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-    finish_pending(c, st);
+    // finish_pending() on the LDS copy: KissICP.poses.append of the previous scan (kiss.py:130)
+    int n_poses = st->n_poses;
+    s_closed = 0;
+    if (st->pending_finish) {
+        st->pending_finish = 0;
+        if (!c.overlap_pre) flush_map_stats(c, st);  // single stream: the map update of that scan is complete here
+        if (n_poses == 0) for (int i = 0; i < 16; ++i) sp[0][i] = sp[3][i];
+        for (int i = 0; i < 16; ++i) { sp[1][i] = sp[2][i]; sp[2][i] = sp[3][i]; }
+        s_closed = (n_poses == 0) ? 2 : 1;
+        n_poses += 1;
+        st->n_poses = n_poses;
+    }
     st->prev_n_in = st->n_in;
     st->n_in = c.n_in;
     st->n_valid = 0; st->n_down = 0; st->n_src = 0;
@@ -214,41 +237,56 @@ __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
     st->bar_top = 0;
     st->gn_epoch = (st->gn_epoch + 1u) & 0x3FFFFFu;
     st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0;
-    // deskew: xi = Log(P[-2]^-1 P[-1])  (Deskew.cpp)
-    st->do_deskew = (c.deskew && st->n_poses >= 2) ? 1 : 0;
-    Rt last = rt_from16(st->pose_last), prev = rt_from16(st->pose_prev);
-    Rt rel = rt_mul(rt_inv(prev), last);
-    if (st->do_deskew) {
+    st->do_deskew = (c.deskew && n_poses >= 2) ? 1 : 0;
+    s_nposes = n_poses;
+    __threadfence_block();
+    }
+    __syncthreads();
+    // four independent chains of single-lane fp64 transcendentals, one wavefront each instead of one after the other
+    const int n_poses = s_nposes;
+    if (threadIdx.x == 0 && st->do_deskew) {  // deskew: xi = Log(P[-2]^-1 P[-1])  (Deskew.cpp)
         double xi[6];
-        se3_log(rel, xi);
+        se3_log(rt_mul(rt_inv(rt_from16(sp[1])), rt_from16(sp[2])), xi);
         for (int i = 0; i < 6; ++i) st->xi[i] = xi[i];
     }
-    // adaptive threshold
-    double sigma = c.init_thr;
-    bool moved = false;
-    if (st->n_poses >= 1) {
-        Rt d = rt_mul(rt_inv(rt_from16(st->pose_first)), last);
-        moved = sqrt(d.t[0] * d.t[0] + d.t[1] * d.t[1] + d.t[2] * d.t[2]) > 5.0 * c.min_motion;
+    if (threadIdx.x == 64) {  // has the sensor moved away from its first pose?
+        bool moved = false;
+        if (n_poses >= 1) {
+            Rt d = rt_mul(rt_inv(rt_from16(sp[0])), rt_from16(sp[2]));
+            moved = sqrt(d.t[0] * d.t[0] + d.t[1] * d.t[1] + d.t[2] * d.t[2]) > 5.0 * c.min_motion;
+        }
+        s_moved = moved ? 1 : 0;
     }
-    if (moved) {
-        Rt dev = rt_from16(st->model_dev);
+    if (threadIdx.x == 128) {  // model error of the last registration (Threshold.cpp ComputeModelError)
+        Rt dev = rt_from16(sp[4]);
         const double theta = rot_angle(dev.R);
-        const double err = sqrt(dev.t[0] * dev.t[0] + dev.t[1] * dev.t[1] + dev.t[2] * dev.t[2]) +
-                           2.0 * c.max_range * sin(0.5 * theta);
-        if (err > c.min_motion) { st->sse += err * err; st->n_samples += 1; }
-        sigma = (st->n_samples < 1) ? c.init_thr : sqrt(st->sse / (double)st->n_samples);
+        s_err = sqrt(dev.t[0] * dev.t[0] + dev.t[1] * dev.t[1] + dev.t[2] * dev.t[2]) + 2.0 * c.max_range * sin(0.5 * theta);
     }
-    st->sigma = sigma;
-    st->gn_max_dist = 3.0 * sigma;
-    st->gn_kernel = sigma / 3.0;
-    // initial guess: the constant-velocity model here; a caller-supplied one (c.ext_guess) is read by the GN kernel
-    // itself, so that whatever produces it (the EKF predict on its own stream) may still be running during K0-K4
-    if (!c.ext_guess) {
-        Rt pred = (st->n_poses >= 2) ? rel : rt_identity();
-        Rt lp = (st->n_poses >= 1) ? last : rt_identity();
+    if (threadIdx.x == 192 && !c.ext_guess) {
+        // initial guess: the constant-velocity model here; a caller-supplied one (c.ext_guess) is read by the GN kernel
+        // itself, so that whatever produces it (the EKF predict on its own stream) may still be running during K0-K4
+        Rt last = rt_from16(sp[2]);
+        Rt pred = (n_poses >= 2) ? rt_mul(rt_inv(rt_from16(sp[1])), last) : rt_identity();
+        Rt lp = (n_poses >= 1) ? last : rt_identity();
         rt_to16(rt_mul(lp, pred), st->guess);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // adaptive threshold
+        double sigma = c.init_thr;
+        if (s_moved) {
+            const double err = s_err;
+            if (err > c.min_motion) { st->sse += err * err; st->n_samples += 1; }
+            sigma = (st->n_samples < 1) ? c.init_thr : sqrt(st->sse / (double)st->n_samples);
+        }
+        st->sigma = sigma;
+        st->gn_max_dist = 3.0 * sigma;
+        st->gn_kernel = sigma / 3.0;
+    }
     __threadfence_block();
+    if (s_closed && threadIdx.x < 48) {  // the poses the bookkeeping changed
+        const int a = threadIdx.x >> 4, k = threadIdx.x & 15;
+        double* dst = a == 0 ? st->pose_first : a == 1 ? st->pose_prev : st->pose_last;
+        if (a > 0 || s_closed == 2) dst[k] = sp[a][k];
     }
     __syncthreads();
     gn_ll_clear_on_wrap(c);
