@@ -73,6 +73,7 @@ struct DevState {
     long long n_samples;
     double model_dev[16];
     int prev_n_in, pending_finish;
+    int n_src_last;     // n_src of the last registered scan (n_src itself belongs to the next scan's K0-K4 already)
     int n_down_ins;     // frame_down points of the scan whose map update is in flight (n_down belongs to the next scan's K3 already)
     int stats_pending;  // scan whose map_voxels / map_points are still to be recorded once its map update is complete, or -1
     // map
@@ -120,6 +121,8 @@ struct Ctx {
     double* traj;        // [T][16] kiss poses
     ScanStats* sstats;   // [T]
     const double* ext_guess;  // device 4x4 or null
+    unsigned long long* pc_key;  // [n_max]      multi-pass probe cache: voxel key of source point i at its last probe
+    int* pc_pb;                  // [n_max][32]  and the 27 probe results (block id | count << 24, -1 = absent)
     unsigned long long* gn_rows_ll;  // [2][G][64]      per-workgroup sums as (32 data bits | 32 flag bits) words
     unsigned long long* gn_xsum_ll;  // [2][8][8][64]   per-group sums, one copy per consumer slot
     int overlap_pre;          // the next scan's K0-K4 run beside this scan's map update (own stream): see flush_map_stats
@@ -836,6 +839,7 @@ __device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_emp
     }
     st->pending_finish = 1;
     st->n_down_ins = st->n_down;
+    st->n_src_last = st->n_src;
     st->stats_pending = k;
 }
 
@@ -907,7 +911,10 @@ __device__ __forceinline__ double gn_ll_join(unsigned half) {
 #define GN_MAX_THREADS 512
 #endif
 #define GN_MAX_GROUPS (GN_MAX_THREADS / 32)
-template <int PC>
+// MC (compile time): keep the probe results of every source point in memory when a group serves several points per
+// iteration (dense scans: N_s > workgroups x groups).  The host picks the variant from the previous scan's N_s (a hint
+// copied back asynchronously; both variants are correct for any N_s), so the single-pass code carries none of it.
+template <int PC, bool MC>
 __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     __shared__ double red[GN_MAX_GROUPS][32];
     __shared__ double red2[4][32];
@@ -987,7 +994,20 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             }
             V3 t;
             double d2;
-            const bool found = nn_search32<PC>(c, s, lane32, gbase, t, d2, ncand, ckey, cblk, single_pass && it > 0);
+            // several points per group: one 128-byte row of probe results per source point in memory (the map is constant
+            // during the loop, so a row stays valid while the point keeps its voxel) - a coalesced read instead of 27
+            // dependent random reads of the hash table per point and iteration
+            unsigned long long key_before = EMPTY_KEY;
+            if (MC && !single_pass) {
+                ckey = (it > 0) ? c.pc_key[i] : EMPTY_KEY;
+                cblk = (it > 0) ? c.pc_pb[32 * (size_t)i + lane32] : -1;
+                key_before = ckey;
+            }
+            const bool found = nn_search32<PC>(c, s, lane32, gbase, t, d2, ncand, ckey, cblk, (single_pass || MC) && it > 0);
+            if (MC && !single_pass && ckey != key_before) {
+                c.pc_pb[32 * (size_t)i + lane32] = cblk;
+                if (lane32 == 0) c.pc_key[i] = ckey;
+            }
             if (found && sqrt(d2) < max_dist) {  // uniform over the group
                 const V3 r = v3(s.x - t.x, s.y - t.y, s.z - t.z);
                 const double den = kern + (r.x * r.x + r.y * r.y + r.z * r.z);

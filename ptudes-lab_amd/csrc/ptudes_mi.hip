@@ -74,6 +74,7 @@ struct ptl_icp {
     hipStream_t pre_stream;
     hipEvent_t ev_pre, ev_gn, ev_in;
     bool ev_gn_valid, ev_in_pending;
+    int* n_src_hint;  // pinned host copy of the last scan's N_s, written by an asynchronous copy on the map stream
     double* fd_buf[2];
     double gn_ms;
     int64_t gn_launches;
@@ -110,13 +111,14 @@ static int icp_free(ptl_icp* h) {
     (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
     void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, h->fd_buf[0], h->fd_buf[1], c.src0,
-                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.wg_clk, c.gn_rows_ll, c.gn_xsum_ll,
+                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.wg_clk, c.pc_key, c.pc_pb, c.gn_rows_ll, c.gn_xsum_ll,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter, h->d_row_mask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : {h->ev_pre, h->ev_gn, h->ev_in, h->ev_map})
         if (e) (void)hipEventDestroy(e);
+    if (h->n_src_hint) (void)hipHostFree(h->n_src_hint);
     if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
     if (h->map_stream) (void)hipStreamDestroy(h->map_stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -177,6 +179,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     h->stream = shared_stream;
     h->prof = false; h->prof_every = 1; h->ev_used = 0; h->gn_ms = 0; h->gn_launches = 0;
     h->gn_wait = nullptr; h->gn_done = nullptr;
+    h->n_src_hint = nullptr;
     h->post_ekf.on = false;
     h->map_stream = nullptr; h->ev_map = nullptr; h->ev_map_valid = false;
     h->pre_stream = nullptr; h->ev_pre = nullptr; h->ev_gn = nullptr; h->ev_in = nullptr;
@@ -230,6 +233,9 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= dalloc(&c.tab, (size_t)cfg->map_table_capacity) == hipSuccess;
     ok &= hipMalloc((void**)&c.blocks, (size_t)c.pool_cap * c.bstride) == hipSuccess;
     ok &= dalloc(&c.free_stack, c.pool_cap) == hipSuccess;
+    ok &= dalloc(&c.pc_key, n) == hipSuccess && dalloc(&c.pc_pb, 32 * n) == hipSuccess;
+    ok &= hipHostMalloc((void**)&h->n_src_hint, sizeof(int)) == hipSuccess;
+    if (h->n_src_hint) *h->n_src_hint = 0;
     ok &= dalloc(&c.gn_rows_ll, (size_t)2 * c.G * 64) == hipSuccess && hipMemset(c.gn_rows_ll, 0, (size_t)2 * c.G * 64 * 8) == hipSuccess;
     ok &= dalloc(&c.gn_xsum_ll, (size_t)2 * 8 * 8 * 64) == hipSuccess && hipMemset(c.gn_xsum_ll, 0, (size_t)2 * 8 * 8 * 64 * 8) == hipSuccess;
     ok &= hipMalloc((void**)&c.wg_clk, (size_t)c.G * 16) == hipSuccess && hipMemset(c.wg_clk, 0, (size_t)c.G * 16) == hipSuccess;
@@ -323,7 +329,11 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
         e0 = h->ev[h->ev_used++]; e1 = h->ev[h->ev_used++];
         HIPCHK(hipEventRecord(e0, s));
     }
-    if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0);  // ends with the post-ICP bookkeeping (kiss.py:116-128)
+    // ends with the post-ICP bookkeeping (kiss.py:116-128).  Dense scans (more source points than 32-lane groups) run the
+    // variant that keeps probe results in memory; the previous scan's N_s, copied back without a wait, is the hint
+    const bool dense = *h->n_src_hint > (int64_t)c.G * (h->cfg.gn_threads / 32);
+    if (c.P == 20) { if (dense) k_gn_loop<20, true><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<20, false><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
+    else { if (dense) k_gn_loop<0, true><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<0, false><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
     if (timed) HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipEventRecord(h->ev_gn, s));
     h->ev_gn_valid = true;
@@ -341,6 +351,7 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     h->last_n = n;
     h->scans_done++;
     if (h->cfg.rebuild_every > 0 && (h->scans_done % h->cfg.rebuild_every) == 0) { int rc = map_rebuild(h, sm); if (rc) return rc; }
+    HIPCHK(hipMemcpyAsync(h->n_src_hint, &c.st->n_src_last, sizeof(int), hipMemcpyDeviceToHost, sm));  // hint for the next launches
     HIPCHK(hipEventRecord(h->ev_map, sm));
     h->ev_map_valid = true;
     HIPCHK(hipGetLastError());
@@ -473,7 +484,7 @@ extern "C" int ptl_icp_last_frame_down(ptl_icp* h, double* out, int64_t max_poin
     return copy_cloud(h, h ? h->c.fd : nullptr, h ? &h->c.st->n_down_ins : nullptr, out, max_points, n_written);
 }
 extern "C" int ptl_icp_last_source(ptl_icp* h, double* out, int64_t max_points, int64_t* n_written) {
-    return copy_cloud(h, h ? h->c.src0 : nullptr, h ? &h->c.st->n_src : nullptr, out, max_points, n_written);
+    return copy_cloud(h, h ? h->c.src0 : nullptr, h ? &h->c.st->n_src_last : nullptr, out, max_points, n_written);
 }
 
 extern "C" int ptl_icp_deskew(ptl_icp* h, const double* xyz, const double* t01, int64_t n, double* out) {
@@ -530,7 +541,7 @@ extern "C" int ptl_icp_linear_system(ptl_icp* h, const double* src_world, int64_
     Ctx& c = h->c;
     HIPCHK(hipMemcpyAsync(c.src_cur, src_world, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     k_set_gn<<<1, 64, 0, h->stream>>>(c, (int)n, max_dist, kernel, nullptr);
-    if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1);
+    if (c.P == 20) k_gn_loop<20, false><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1); else k_gn_loop<0, false><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1);
     double out[32];
     HIPCHK(hipMemcpyAsync(out, (char*)c.st + offsetof(DevState, dbg_sums), sizeof out, hipMemcpyDeviceToHost, h->stream));
     int rc = icp_check_flags(h);
@@ -549,7 +560,7 @@ extern "C" int ptl_icp_align(ptl_icp* h, const double* frame, int64_t n, const d
     HIPCHK(hipMemcpyAsync(c.src0, frame, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_ext, guess, 128, hipMemcpyHostToDevice, h->stream));
     k_set_gn<<<1, 64, 0, h->stream>>>(c, (int)n, max_dist, kernel, h->d_ext);
-    if (c.P == 20) k_gn_loop<20><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 2); else k_gn_loop<0><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 2);  // new_pose = T_icp * guess, trajectory untouched
+    if (c.P == 20) k_gn_loop<20, false><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 2); else k_gn_loop<0, false><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 2);  // new_pose = T_icp * guess, trajectory untouched
     DevState st;
     HIPCHK(hipMemcpyAsync(&st, c.st, sizeof st, hipMemcpyDeviceToHost, h->stream));
     int rc = icp_check_flags(h);
