@@ -270,3 +270,72 @@ def test_gn_launch_shapes_agree(seq, wgs, threads):
         assert dt <= 1e-10 and dr <= 1e-10, (k, dt, dr)
         for key in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "sum_cand", "map_voxels", "map_points"):
             assert ref.stats[-1][key] == alt.stats[-1][key], (k, key)
+
+
+def _room_points(rng, n):
+    """points on the walls / floor / ceiling of a 40 x 30 x 8 m room (the oracle KATs' scene)"""
+    face = rng.integers(0, 6, n)
+    u, v = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    L = np.array([40.0, 30.0, 8.0])
+    P = np.empty((n, 3))
+    for f in range(6):
+        a, s = f // 2, f % 2
+        b, c_ = (a + 1) % 3, (a + 2) % 3
+        m = face == f
+        P[m, a] = s * L[a]
+        P[m, b] = u[m] * L[b]
+        P[m, c_] = v[m] * L[c_]
+    return P - L / 2 + rng.normal(0, 0.003, (n, 3))
+
+
+def test_known_answer_registration_on_device():
+    """the algebraic known-answer cases of the ICP restatement, on the HIP path itself: a known rigid
+    motion is recovered (exactly when the source is the map's own points, to the sampling texture otherwise), an
+    empty map and a scan without correspondences return the guess."""
+    rng = np.random.default_rng(5)
+    M = _room_points(rng, 300000)
+    icp = core.Icp(1e6, 0.0, voxel_size=0.7, map_block_capacity=1 << 17, max_points_per_scan=300000)
+    icp.map_add(M)
+    ref = orc.Map(0.7, 1e9, 20)
+    ref.add_points(M)
+    sub = ref.points()[::9]
+    Tt = orc.se3_exp(np.array([0.2, -0.1, 0.05, 0.01, -0.02, 0.03]))
+    body = (np.linalg.inv(Tt) @ np.c_[sub, np.ones(len(sub))].T).T[:, :3]
+    out, it = icp.align(body, np.eye(4), 6.0, 2 / 3)
+    assert np.abs(out - Tt).max() < 1e-4 and it < 60
+    S = orc.voxel_downsample(orc.voxel_downsample(_room_points(rng, 60000), 0.35), 1.05)
+    body = (np.linalg.inv(Tt) @ np.c_[S, np.ones(len(S))].T).T[:, :3]
+    out, it = icp.align(body, np.eye(4), 6.0, 2 / 3)
+    assert np.linalg.norm(out[:3, 3] - Tt[:3, 3]) < 0.03 and orc.rot_angle(np.linalg.inv(Tt) @ out) < 2e-3
+    out_ref, _, _, _ = ref.register(body, np.eye(4), 6.0, 2 / 3)
+    dt, dr = _pose_diff(out_ref, out)
+    assert dt <= ICP_T_TOL and dr <= ICP_R_TOL
+    g = orc.se3_exp(np.array([1.0, 2.0, 3.0, 0.1, 0.2, 0.3]))
+    out, it = core.Icp(100.0, 1.0).align(body, g, 6.0, 2 / 3)       # empty map => the guess
+    assert np.array_equal(out, g) and it == 0
+    out, it = icp.align(body + 1000.0, np.eye(4), 6.0, 2 / 3)        # no correspondences => the guess
+    assert np.array_equal(out, np.eye(4)) and it == 1
+
+
+def test_threshold_landmarks_on_device():
+    """sigma stays at the initial 2.0 until the sensor has moved 0.5 m from its first pose, then
+    becomes the RMS of the model deviations above min_motion_th (Threshold.cpp), as in the oracle scan by scan."""
+    rng = np.random.default_rng(7)
+    scan = _room_points(rng, 30000)
+    t01 = rng.uniform(0, 1, len(scan))
+    icp, ref = core.Icp(100.0, 1.0), orc.ICP(100.0, 1.0)
+    T0 = icp.register_frame(scan, t01)
+    ref.register_frame(scan, t01)
+    assert np.array_equal(T0, np.eye(4)) and icp.stats[0]["iterations"] == 0
+    T1 = icp.register_frame(scan, t01)
+    ref.register_frame(scan, t01)
+    assert np.abs(T1 - np.eye(4)).max() < 1e-12 and icp.stats[1]["iterations"] == 1 and icp.stats[1]["sigma"] == 2.0
+    for k in range(1, 4):
+        G = np.eye(4)
+        G[0, 3] = 1.0 * k
+        guess = G @ orc.se3_exp(np.array([0.15, 0, 0, 0, 0, 0]))
+        icp.register_frame(scan - G[:3, 3], t01, guess)
+        ref.register_frame(scan - G[:3, 3], t01, guess=guess)
+    sig = [s["sigma"] for s in icp.stats]
+    assert sig[2] == 2.0 and 0.1 < sig[-1] < 0.6
+    assert np.allclose(sig, [s["sigma"] for s in ref.stats], rtol=0, atol=1e-9)
