@@ -128,13 +128,28 @@ def ptudes_ekf_ouster(file: Optional[str], meta: Optional[str], start_scan: int,
     if synthetic is None:
         try:
             import ouster.client  # noqa: F401
+            from ouster.sdk.util import resolve_metadata
         except Exception:
             raise click.ClickException("reading .pcap/.bag needs ouster-sdk, which is not installed; "
                                        "use --synthetic SEED to run the same path on a synthetic sequence")
-        raise click.ClickException("packet-file ingestion is not part of this build (SURVEY.md 8(f) rank 3)")
-    n_scans = (end_scan + 1) if end_scan is not None else 100
-    seq, info, events = _synthetic_source(synthetic, n_scans)
-    file = f"synthetic:{synthetic}"
+        # the reference's feed (ekf_bench.py:426-448): packets -> OusterLidarData -> (scan idx, LidarScan | IMU)
+        from ..data import OusterLidarData
+        from ..utils import read_metadata_json, read_packet_source
+        meta = resolve_metadata(file, meta)
+        if not meta:
+            raise click.ClickException("File not found, please specify a metadata file with `-m`")
+        info = read_metadata_json(meta)
+        data_source = OusterLidarData(read_packet_source(file, meta=info))
+        seq = None
+        events = ((("imu", d) if hasattr(d, "lacc") else ("lidar_scan", d))
+                  for _, d in data_source.withScanIdx(start_scan=start_scan, end_scan=end_scan))
+        start_scan_feed = 0  # withScanIdx already applied the range
+    else:
+        n_scans = (end_scan + 1) if end_scan is not None else 100
+        seq, info, events = _synthetic_source(synthetic, n_scans)
+        start_scan_feed = start_scan
+    if synthetic is not None:
+        file = f"synthetic:{synthetic}"
     display_header = f"data path: {file}\n"
     display_header += f"metadata path: {meta}\n\n"
     display_header += f"scans range: {start_scan} - {end_scan}\n"
@@ -148,7 +163,7 @@ def ptudes_ekf_ouster(file: Optional[str], meta: Optional[str], start_scan: int,
         scan_idx = 0
         for ev in events:
             if ev[0] == "scan":
-                if scan_idx >= start_scan:
+                if scan_idx >= start_scan_feed:
                     xyz = ev[1]
                     if beams:
                         img = xyz.reshape(seq.H, seq.W, 3)
@@ -157,7 +172,12 @@ def ptudes_ekf_ouster(file: Optional[str], meta: Optional[str], start_scan: int,
                         img[drop] = 0
                     yield ev
                 scan_idx += 1
-            elif scan_idx >= start_scan:  # IMUs before start_scan are dropped (reference data.py:76)
+            elif ev[0] == "lidar_scan":  # ouster LidarScan (the packet feed applied start_scan / end_scan)
+                if beams:
+                    from ..utils import reduce_active_beams
+                    reduce_active_beams(ev[1], beams)  # reference ekf_bench.py:520-521
+                yield ev
+            elif scan_idx >= start_scan_feed:  # IMUs before start_scan are dropped (reference data.py:76)
                 yield ev
 
     out = run_events(feed(), info, kiss_min_range=kiss_min_range, kiss_max_range=kiss_max_range,

@@ -38,7 +38,10 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
         if not imus_per_scan:  # ekf_bench.py:512-518
             continue
         imus_per_scan = 0
-        _, xyz, t01, ts = ev
+        if ev[0] == "lidar_scan":  # an ouster LidarScan from the packet feed (data.OusterLidarData)
+            xyz, t01, ts = None, None, float(getattr(ev[1], "timestamp", [0])[-1]) * 1e-9 if hasattr(ev[1], "timestamp") else 0.0
+        else:
+            _, xyz, t01, ts = ev
         if use_imu_prediction:
             guess = ekf.nav.pose_mat()
         elif guess_fn is not None:
@@ -47,7 +50,10 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
             last = kiss_icp._kiss.poses[-1] if kiss_icp._kiss.poses else np.eye(4)
             guess = last @ kiss_icp._kiss.get_prediction_model()
         t1 = time.monotonic()
-        kiss_icp.register_points(xyz, t01, ts, initial_guess=guess)
+        if ev[0] == "lidar_scan":
+            kiss_icp.register_frame(ev[1], initial_guess=guess)  # reference ekf_bench.py:549
+        else:
+            kiss_icp.register_points(xyz, t01, ts, initial_guess=guess)
         t_kiss += time.monotonic() - t1
         t1 = time.monotonic()
         ekf.processPose(kiss_icp.pose)

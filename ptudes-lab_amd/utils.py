@@ -18,6 +18,30 @@ NC_OS_SENSOR_TO_BASE[:3, 3] = [0.001, 0.000, 0.091]
 NC_OS_IMU_TO_BASE = NC_OS_SENSOR_TO_BASE @ NC_OS_IMU_TO_OS_SENSOR
 
 
+def read_metadata_json(meta_path: str):
+    """SensorInfo from a metadata .json (reference utils.py:157-168, including the lidar_mode back-fill for the
+    Newer College 2020 beam_intrinsics files).  Needs ouster-sdk."""
+    import json
+    from ouster import client  # guarded: raises ImportError where ouster-sdk is absent
+    with open(meta_path) as f:
+        js = json.loads(f.read())
+    if "beam_altitude_angles" in js and "beam_azimuth_angles" in js and "lidar_mode" not in js:
+        print(f"WARNING: lidar_mode is not present in legacy metadata '{meta_path}' so using lidar_mode: 1024x10")
+        js["lidar_mode"] = "1024x10"
+    return client.SensorInfo(json.dumps(js))
+
+
+def read_packet_source(file_path: str, meta=None):
+    """Ouster raw packet source of a .pcap (reference utils.py:171-187).  ROS bags need the reference's rosbags-based
+    reader (bag.py), which this build does not provide."""
+    from pathlib import Path
+    from ouster import pcap  # guarded
+    file = Path(file_path)
+    if file.is_file() and file.suffix == ".pcap":
+        return pcap.Pcap(file_path, meta)
+    raise ValueError(f"'{file_path}': only .pcap packet files are supported by this build (no rosbags reader)")
+
+
 def vee(vec: np.ndarray) -> np.ndarray:
     """3-vector -> skew-symmetric matrix, hat(v) w = v x w (reference utils.py:28-36 names it `vee`)"""
     x, y, z = vec[0], vec[1], vec[2]

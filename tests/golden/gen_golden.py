@@ -345,6 +345,76 @@ def case_stream_stats():
                         imu_a=imu_a, imu_w=imu_w, **out)
 
 
+def case_packet_feed():
+    """OusterLidarData.withScanIdx (data.py:31-77): event order of a packet stream - scans batched from lidar packets,
+    IMU packets passed through, start_scan / end_scan, the trailing partial scan.  ouster-sdk is absent, so its types are
+    replaced by minimal stand-ins here: packets carry (kind, frame_id, payload); the stand-in ScanBatcher completes a scan
+    when the frame id changes, which is all the reference's loop relies on."""
+    import numpy as np
+    import ouster.client as client
+    import ouster.client._client as _client
+    from types import SimpleNamespace
+
+    class LidarPacket:
+        def __init__(self, frame, col0):
+            self.frame, self.col0 = frame, col0
+
+    class ImuPacket:
+        def __init__(self, ts):
+            self.sys_ts, self.accel, self.angular_vel = ts, np.array([0.0, 0.0, 1.0]), np.array([1.0, 2.0, 3.0])
+
+    class LidarScan:
+        def __init__(self, h, w, fields, cpp):
+            self.h, self.w, self.frame_id, self.cols = h, w, -1, []
+
+    class ScanBatcher:  # completes when a packet of the next frame arrives (that packet starts the next scan)
+        def __init__(self, w, pf):
+            self.cur = None
+
+        def __call__(self, packet, ls):
+            if self.cur is not None and packet.frame != self.cur:
+                self.cur = packet.frame
+                return True
+            self.cur = packet.frame
+            ls.frame_id = packet.frame
+            ls.cols.append(packet.col0)
+            return False
+
+    client.LidarPacket, client.ImuPacket, client.LidarScan = LidarPacket, ImuPacket, LidarScan
+    _client.ScanBatcher = ScanBatcher
+    _client.PacketFormat = SimpleNamespace(from_info=lambda info: None)
+    import importlib
+    import ptudes.data as pdata
+    importlib.reload(pdata)
+    meta = SimpleNamespace(format=SimpleNamespace(columns_per_frame=64, pixels_per_column=8, columns_per_packet=16,
+                                                   udp_profile_lidar="LEGACY"))
+    packets = []
+    ts = 1000
+    for frame in range(6):
+        for k in range(4):
+            packets.append(LidarPacket(frame, 16 * k))
+            if k % 2 == 1:
+                ts += 5_000_000
+                packets.append(ImuPacket(ts))
+    packets = packets[:-3]  # the stream ends inside the last frame
+    enc = [("L", p.frame, p.col0) if isinstance(p, LidarPacket) else ("I", p.sys_ts, 0) for p in packets]
+    out = {}
+    for name, kw in (("all", {}), ("from2", dict(start_scan=2)), ("from1to3", dict(start_scan=1, end_scan=3))):
+        class Src:
+            metadata = meta
+
+            def __iter__(self):
+                return iter(packets)
+
+        src = Src()
+        ev = []
+        for idx, d in pdata.OusterLidarData(src).withScanIdx(**kw):
+            ev.append([idx, 0, d.frame_id] if isinstance(d, LidarScan) else [idx, 1, int(round(d.ts * 1e9))])
+        out[name] = ev
+    with open(os.path.join(HERE, "packet_feed.json"), "w") as f:
+        json.dump({"packets": enc, "events": out}, f)
+
+
 CASES = {
     "ekf_steps_default": lambda: case_ekf_steps("default"),
     "ekf_steps_init": lambda: case_ekf_steps("init"),
@@ -356,6 +426,7 @@ CASES = {
     "ts_filters": case_ts_filters,
     "imu_nav": case_imu_nav,
     "stream_stats": case_stream_stats,
+    "packet_feed": case_packet_feed,
 }
 
 if __name__ == "__main__":
