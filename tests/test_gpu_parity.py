@@ -339,3 +339,26 @@ def test_threshold_landmarks_on_device():
     sig = [s["sigma"] for s in icp.stats]
     assert sig[2] == 2.0 and 0.1 < sig[-1] < 0.6
     assert np.allclose(sig, [s["sigma"] for s in ref.stats], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed,min_range,max_range", [(1003, 1.0, 70.0), (1006, 2.0, 50.0)])
+def test_sequence_other_seeds_and_ranges_vs_oracle(seed, min_range, max_range):
+    """the free-running loop on other sequences and range settings (voxel size follows max_range / 100): GPU and
+    oracle stay together far below the 1 cm bar, and every integer statistic of every scan is identical"""
+    n = 24
+    sq = synth.make_sequence(seed=seed, n_scans=n, min_range=min_range, max_range=max_range)
+    orc.set_threads(8)
+    try:
+        ref = orc.run_sequence(sq.events(n), max_range=max_range, min_range=min_range, use_imu_prediction=True)
+    finally:
+        orc.set_threads(1)
+    r = core.SeqRunner(n, sq.H * sq.W, sq.imu_range_for_scan(n - 1)[1], max_range=max_range, min_range=min_range,
+                       use_imu_prediction=True, with_ekf=True)
+    _upload(sq, r, n)
+    r.run()
+    out = r.results()
+    d = [np.linalg.norm(out["res_poses"][k][:3, 3] - ref["res_poses"][k][:3, 3]) for k in range(n)]
+    assert max(d) <= 1e-9, d
+    for k in range(n):
+        for key in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "map_voxels", "map_points"):
+            assert out["stats"][k][key] == ref["stats"][k][key], (k, key)
