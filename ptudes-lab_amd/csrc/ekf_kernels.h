@@ -109,9 +109,12 @@ __device__ __forceinline__ unsigned ekf_row_mask(int i) {
 __device__ __forceinline__ void d_ekf_step(EkfState* e, const double* imu, int i0, int i1, const double* pose,
                                            const double* meas_cov, double* out_pose, double* out_t,
                                            double* out_row8, int update_first) {
-    __shared__ double sP[EKF_N * EKF_N], sF[EKF_N * EKF_N], sW[EKF_N * EKF_N], sT[EKF_N * EKF_N];
+    // Fx / W are double-buffered: the mechanisation thread writes the blocks of sample j into buffer j & 1 while the
+    // covariance products of sample j - 1 still read buffer (j - 1) & 1 (every active sample rewrites all the blocks,
+    // the other entries never change, so both buffers always agree outside the blocks in flight)
+    __shared__ double sP[EKF_N * EKF_N], sF2[2][EKF_N * EKF_N], sW2[2][EKF_N * EKF_N], sT[EKF_N * EKF_N];
+    __shared__ int sAct[2], s_lastbuf;
     __shared__ double sK[EKF_N * 6], sSi[36], sr[6], sdx[EKF_N];
-    __shared__ int active;
     __shared__ double sM[6][12];
     __shared__ int sPiv;
     __shared__ double sRd[EKF_CHUNK][10];  // per-sample Exp(dtheta) (9) and dt
@@ -119,7 +122,11 @@ __device__ __forceinline__ void d_ekf_step(EkfState* e, const double* imu, int i
     const int tid = threadIdx.x;
     const int ti = tid / EKF_N, tj = tid % EKF_N;
     const bool cell = tid < EKF_N * EKF_N;
-    if (cell) { sP[tid] = e->P[tid]; sF[tid] = e->Fx[tid]; sW[tid] = e->W[tid]; }
+    if (cell) { sP[tid] = e->P[tid]; sF2[0][tid] = sF2[1][tid] = e->Fx[tid]; sW2[0][tid] = sW2[1][tid] = e->W[tid]; }
+    if (tid == 0) s_lastbuf = 0;
+    // the mechanisation (one lane) runs in a wavefront of its own when the launch has one to spare, so that it overlaps
+    // the covariance products instead of preceding them
+    const int TS = (blockDim.x > EKF_N * EKF_N + 60) ? 384 : 0;
     // the nav state lives in LDS for the whole launch (only thread 0 touches it; written back once at the end)
     __shared__ EkfNav nv;
     if (tid < (int)(sizeof(EkfNav) / 8)) ((double*)&nv)[tid] = ((const double*)&e->nav)[tid];
@@ -146,73 +153,84 @@ __device__ __forceinline__ void d_ekf_step(EkfState* e, const double* imu, int i
                     sRd[tid][9] = dt;
                 }
                 __syncthreads();
-                for (int j = 0; j < nc; ++j) {
-                    // ---- processImu: scalar part on thread 0 (mechanisation + Fx/W blocks)
-                    if (tid == 0) {
+                // Software pipeline over the samples, two barriers per sample: while the mechanisation lane works on sample
+                // j (stage 1: _insMech; stage 2: the Fx / W blocks), the 324 cell threads form P = Fx P Fx^T + W of
+                // sample j - 1 (stage 1: Fx P; stage 2: (Fx P) Fx^T + W).
+                double Rp[9], a[3], Rd[9], dtj = 0.0;
+                int act_j = 0;
+                for (int j = 0; j <= nc; ++j) {
+                    const int bj = j & 1, bp = (j - 1) & 1;
+                    const bool prev_active = j >= 1 && sAct[bp] != 0;
+                    // ---- stage 1
+                    if (tid == TS && j < nc) {  // processImu of sample j: latch + mechanisation (:191-214, _insMech :239-257)
                         const double* row = imu + 7 * (size_t)(c0 + j);
                         nv.cur_dt = sRd[j][9];
                         nv.cur_ts = row[0];
                         for (int k = 0; k < 3; ++k) { nv.cur_lacc[k] = row[1 + k]; nv.cur_avel[k] = row[4 + k]; }
                         if (!nv.initialized) {  // :201-203 the first sample only latches
                             nv.initialized = 1;
-                            active = 0;
+                            act_j = 0;
                         } else {
-                            active = 1;
-                            const double dt = nv.cur_dt;
-                            double Rp[9], a[3], Rd[9], Rn[9];
+                            act_j = 1;
+                            dtj = nv.cur_dt;
+                            double Rn[9];
                             quat_to_R(nv.q, Rp);  // nav_prev.att_h
                             for (int k = 0; k < 3; ++k) a[k] = row[1 + k] - nv.ba[k];
                             for (int k = 0; k < 9; ++k) Rd[k] = sRd[j][k];
-                            // _insMech (:239-257)
                             for (int k = 0; k < 3; ++k) {
                                 const double ag = (Rp[3 * k] * a[0] + Rp[3 * k + 1] * a[1] + Rp[3 * k + 2] * a[2]) + nv.grav[k];
-                                nv.pos[k] = nv.pos[k] + nv.vel[k] * dt + 0.5 * ag * dt * dt;
-                                nv.vel[k] = nv.vel[k] + ag * dt;
+                                nv.pos[k] = nv.pos[k] + nv.vel[k] * dtj + 0.5 * ag * dtj * dtj;
+                                nv.vel[k] = nv.vel[k] + ag * dtj;
                             }
                             mat3_mul(Rp, Rd, Rn);
                             R_to_quat(Rn, nv.q);
-                            // Fx blocks (:216-223)
-                            double K[9], B[9];
-                            lds_diag3(sF, EKF_POS, EKF_VEL, dt);
-                            skew(a, K);
-                            mat3_mul(Rp, K, B);
-                            for (int k = 0; k < 9; ++k) B[k] = -dt * B[k];
-                            lds_blk3(sF, EKF_VEL, EKF_PHI, B);
-                            for (int k = 0; k < 9; ++k) B[k] = -dt * Rp[k];
-                            lds_blk3(sF, EKF_VEL, EKF_BA, B);
-                            for (int r = 0; r < 3; ++r)
-                                for (int cc = 0; cc < 3; ++cc) B[3 * r + cc] = Rd[3 * cc + r];
-                            lds_blk3(sF, EKF_PHI, EKF_PHI, B);
-                            lds_diag3(sF, EKF_PHI, EKF_BG, -dt);
-                            // W blocks (:226-233); the reference's names do not match their use, this copies the use
-                            lds_diag3(sW, EKF_VEL, EKF_VEL, dt * dt * (0.049 * 0.049));
-                            lds_diag3(sW, EKF_PHI, EKF_PHI, dt * dt * (0.38 * 0.38));
-                            lds_diag3(sW, EKF_BA, EKF_BA, dt * (0.0043 * 0.0043));
-                            lds_diag3(sW, EKF_BG, EKF_BG, dt * (0.000466 * 0.000466));
                         }
+                        sAct[bj] = act_j;
+                    }
+                    if (prev_active && cell) {
+                        // P = Fx P Fx^T + W (:235), dense like the reference.  Only the structurally non-zero columns of
+                        // each Fx row are visited, in ascending order: skipping exact-zero products leaves every
+                        // partial sum bit-identical to the dense loop.
+                        const double* sF = sF2[bp];
+                        double acc = 0.0;
+                        for (unsigned m = ekf_row_mask(ti); m; m &= m - 1) {
+                            const int k = __ffs(m) - 1;
+                            acc += sF[ti * EKF_N + k] * sP[k * EKF_N + tj];
+                        }
+                        sT[tid] = acc;
                     }
                     __syncthreads();
-                    if (active) {
-                        // ---- P = Fx P Fx^T + W (:235), dense like the reference.  Only the structurally non-zero
-                        // columns of each Fx row are visited, in ascending order: skipping exact-zero products
-                        // leaves every partial sum bit-identical to the dense loop.
-                        if (cell) {
-                            double acc = 0.0;
-                            for (unsigned m = ekf_row_mask(ti); m; m &= m - 1) {
-                                const int k = __ffs(m) - 1;
-                                acc += sF[ti * EKF_N + k] * sP[k * EKF_N + tj];
-                            }
-                            sT[tid] = acc;
+                    // ---- stage 2
+                    if (tid == TS && j < nc && act_j) {  // Fx blocks (:216-223) and W blocks (:226-233) of sample j
+                        double* sF = sF2[bj];
+                        double* sW = sW2[bj];
+                        double K[9], B[9];
+                        lds_diag3(sF, EKF_POS, EKF_VEL, dtj);
+                        skew(a, K);
+                        mat3_mul(Rp, K, B);
+                        for (int k = 0; k < 9; ++k) B[k] = -dtj * B[k];
+                        lds_blk3(sF, EKF_VEL, EKF_PHI, B);
+                        for (int k = 0; k < 9; ++k) B[k] = -dtj * Rp[k];
+                        lds_blk3(sF, EKF_VEL, EKF_BA, B);
+                        for (int r = 0; r < 3; ++r)
+                            for (int cc = 0; cc < 3; ++cc) B[3 * r + cc] = Rd[3 * cc + r];
+                        lds_blk3(sF, EKF_PHI, EKF_PHI, B);
+                        lds_diag3(sF, EKF_PHI, EKF_BG, -dtj);
+                        // the reference's names of the noise terms do not match their use, this copies the use
+                        lds_diag3(sW, EKF_VEL, EKF_VEL, dtj * dtj * (0.049 * 0.049));
+                        lds_diag3(sW, EKF_PHI, EKF_PHI, dtj * dtj * (0.38 * 0.38));
+                        lds_diag3(sW, EKF_BA, EKF_BA, dtj * (0.0043 * 0.0043));
+                        lds_diag3(sW, EKF_BG, EKF_BG, dtj * (0.000466 * 0.000466));
+                        s_lastbuf = bj;
+                    }
+                    if (prev_active && cell) {
+                        const double* sF = sF2[bp];
+                        double acc = 0.0;
+                        for (unsigned m = ekf_row_mask(tj); m; m &= m - 1) {
+                            const int k = __ffs(m) - 1;
+                            acc += sT[ti * EKF_N + k] * sF[tj * EKF_N + k];
                         }
-                        __syncthreads();
-                        if (cell) {
-                            double acc = 0.0;
-                            for (unsigned m = ekf_row_mask(tj); m; m &= m - 1) {
-                                const int k = __ffs(m) - 1;
-                                acc += sT[ti * EKF_N + k] * sF[tj * EKF_N + k];
-                            }
-                            sP[tid] = acc + sW[tid];
-                        }
+                        sP[tid] = acc + sW2[bp][tid];
                     }
                     __syncthreads();
                 }
@@ -343,11 +361,12 @@ __device__ __forceinline__ void d_ekf_step(EkfState* e, const double* imu, int i
         }
         __syncthreads();
     }
-    if (cell) { e->P[tid] = sP[tid]; e->Fx[tid] = sF[tid]; e->W[tid] = sW[tid]; }
+    if (cell) { e->P[tid] = sP[tid]; e->Fx[tid] = sF2[s_lastbuf][tid]; e->W[tid] = sW2[s_lastbuf][tid]; }
     if (tid == 0) { e->nav = nv; ekf_write_pose(e); }
 }
 
-__global__ __launch_bounds__(384) void k_ekf_step(EkfState* e, const double* imu, int i0, int i1, const double* pose,
+#define EKF_THREADS 448  /* 324 covariance cells (six wavefronts) + a seventh wavefront for the mechanisation lane */
+__global__ __launch_bounds__(EKF_THREADS) void k_ekf_step(EkfState* e, const double* imu, int i0, int i1, const double* pose,
                                                   const double* meas_cov, double* out_pose, double* out_t,
                                                   double* out_row8, int update_first) {
     d_ekf_step(e, imu, i0, i1, pose, meas_cov, out_pose, out_t, out_row8, update_first);

@@ -339,7 +339,7 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     h->ev_gn_valid = true;
     if (h->gn_done) HIPCHK(hipEventRecord(h->gn_done, s));
     if (h->post_ekf.on)
-        k_ekf_step<<<1, 384, 0, s>>>(h->post_ekf.st, h->post_ekf.imu, h->post_ekf.i0, h->post_ekf.i1, c.traj + 16 * (size_t)h->scans_done,
+        k_ekf_step<<<1, EKF_THREADS, 0, s>>>(h->post_ekf.st, h->post_ekf.imu, h->post_ekf.i0, h->post_ekf.i1, c.traj + 16 * (size_t)h->scans_done,
                                     nullptr, h->post_ekf.res_pose, h->post_ekf.res_t, h->post_ekf.rows, 1);
     // local_map.update(frame_downsample, new_pose)  (kiss.py:129), on the map stream
     hipStream_t sm = h->map_stream;
@@ -809,7 +809,7 @@ extern "C" int ptl_ekf_process_imu_batch(ptl_ekf* h, const double* imu, int64_t 
     for (int64_t off = 0; off < n; off += h->buf_rows) {
         const int m = (int)((n - off) < h->buf_rows ? (n - off) : h->buf_rows);
         HIPCHK(hipMemcpyAsync(h->d_buf, imu + 7 * off, (size_t)m * 56, hipMemcpyHostToDevice, h->stream));
-        k_ekf_step<<<1, 384, 0, h->stream>>>(h->st, h->d_buf, 0, m, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+        k_ekf_step<<<1, EKF_THREADS, 0, h->stream>>>(h->st, h->d_buf, 0, m, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
         HIPCHK(hipStreamSynchronize(h->stream));  // staging buffer reuse
     }
     HIPCHK(hipGetLastError());
@@ -1001,7 +1001,7 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
         // or when the previous scan was skipped: otherwise the previous scan's EKF launch already ran them)
         const int64_t e = with_ekf ? s->imu_end[(size_t)k] : s->imu_pos;
         if (e > s->imu_pos) {
-            k_ekf_step<<<1, 384, 0, guess_ptr ? s->stream : es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+            k_ekf_step<<<1, EKF_THREADS, 0, guess_ptr ? s->stream : es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
             s->imus_per_scan += e - s->imu_pos;
             s->imu_pos = e;
         }
@@ -1035,7 +1035,7 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
         if (with_ekf && !inline_ekf) {
             // nothing waits for this EKF step but the next one: its own stream, beside the map update
             HIPCHK(hipStreamWaitEvent(es, s->ev_gn, 0));
-            k_ekf_step<<<1, 384, 0, es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e2, kiss_pose, nullptr,
+            k_ekf_step<<<1, EKF_THREADS, 0, es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e2, kiss_pose, nullptr,
                                          s->d_res_poses + 16 * o, s->d_res_t + o, s->d_rows + 8 * o, 1);
         }
         if (with_ekf) {
