@@ -56,24 +56,17 @@ struct ptl_icp {
     int prof_every;  // time every n-th GN launch (two event records cost ~18 us of command-processor time per scan)
     std::vector<hipEvent_t> ev;
     size_t ev_used;
-    // set by the sequence runner: the GN kernel waits for `gn_wait` (the EKF stream produced the guess) and
-    // `gn_done` is recorded right after it (the EKF update may start while the map update still runs)
-    hipEvent_t gn_wait, gn_done;
-    // K0-K4 of a scan run on `pre_stream`, beside the previous scan's map update (K7-K10 on `stream`): they need the
-    // previous pose (ev_gn: recorded right after each GN launch) and the uploaded input (ev_in), not the map.
+    // set by the sequence runner around a scan: the GN kernel waits for `gn_wait` (the EKF stream produced the guess)
+    hipEvent_t gn_wait, gn_done;  // ... and `gn_done` is recorded right after it (a second event: two streams waiting on one measured slower)
+    // ev_gn is recorded right after each GN launch: the map update (and the sequence runner's EKF step) start from it.
     // frame_down is double-buffered so that K3 of scan k+1 does not overwrite what K7 of scan k still reads.
-    // set by the sequence runner when the next guess comes from the EKF: its step (update with this scan's pose, then
-    // the IMU predicts up to the next scan) is launched on `stream` right after the GN kernel - a cross-stream event
-    // costs ~20 us of wake-up latency on either side, more than the step's overlap with the map update would save
-    struct { EkfState* st; const double* imu; int i0, i1; double *res_pose, *res_t, *rows; bool on; } post_ekf;
     // the map update (K7-K10, rebuild) runs on `map_stream`: it needs the GN result (ev_gn) and must be complete before
-    // the next GN launch (ev_map); beside it, on `stream`, runs whatever else follows the GN kernel (the inline EKF step)
+    // the next GN launch (ev_map); beside it, on `stream`, run K0-K4 of the next scan
     hipStream_t map_stream;
     hipEvent_t ev_map;
     bool ev_map_valid;
-    hipStream_t pre_stream;
-    hipEvent_t ev_pre, ev_gn, ev_in;
-    bool ev_gn_valid, ev_in_pending;
+    hipEvent_t ev_gn;
+    bool ev_gn_valid;
     int* n_src_hint;  // pinned host copy of the last scan's N_s, written by an asynchronous copy on the map stream
     double* fd_buf[2];
     double gn_ms;
@@ -116,10 +109,9 @@ static int icp_free(ptl_icp* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {h->ev_pre, h->ev_gn, h->ev_in, h->ev_map})
+    for (hipEvent_t e : {h->ev_gn, h->ev_map})
         if (e) (void)hipEventDestroy(e);
     if (h->n_src_hint) (void)hipHostFree(h->n_src_hint);
-    if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
     if (h->map_stream) (void)hipStreamDestroy(h->map_stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -154,10 +146,9 @@ static int icp_reset_device(ptl_icp* h) {
     k_fill_free_stack<<<(c.pool_cap + 255) / 256, 256, 0, h->stream>>>(c.free_stack, c.pool_cap);
     k_state_init<<<1, 64, 0, h->stream>>>(c.st, c.pool_cap);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->pre_stream));
     HIPCHK(hipStreamSynchronize(h->map_stream));
     HIPCHK(hipStreamSynchronize(h->stream));  // the other streams must not start on half-reset tables
-    h->ev_gn_valid = false; h->ev_in_pending = false; h->ev_map_valid = false;
+    h->ev_gn_valid = false; h->ev_map_valid = false;
     h->scans_done = 0;
     h->last_n = 0;
     return PTL_OK;
@@ -180,10 +171,9 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     h->prof = false; h->prof_every = 1; h->ev_used = 0; h->gn_ms = 0; h->gn_launches = 0;
     h->gn_wait = nullptr; h->gn_done = nullptr;
     h->n_src_hint = nullptr;
-    h->post_ekf.on = false;
     h->map_stream = nullptr; h->ev_map = nullptr; h->ev_map_valid = false;
-    h->pre_stream = nullptr; h->ev_pre = nullptr; h->ev_gn = nullptr; h->ev_in = nullptr;
-    h->ev_gn_valid = false; h->ev_in_pending = false; h->fd_buf[0] = h->fd_buf[1] = nullptr;
+    h->ev_gn = nullptr;
+    h->ev_gn_valid = false; h->fd_buf[0] = h->fd_buf[1] = nullptr;
     h->d_in = nullptr; h->d_t01 = nullptr; h->d_ext = nullptr; h->d_counter = nullptr; h->d_row_mask = nullptr;
     memset(&h->c, 0, sizeof(Ctx));
     if (h->own_stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -219,12 +209,9 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= dalloc(&c.fd, 3 * n) == hipSuccess && dalloc(&c.src0, 3 * n) == hipSuccess;
     h->fd_buf[0] = c.fd;
     ok &= dalloc(&h->fd_buf[1], 3 * n) == hipSuccess;
-    ok &= hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking) == hipSuccess;
     ok &= hipStreamCreateWithFlags(&h->map_stream, hipStreamNonBlocking) == hipSuccess;
     ok &= hipEventCreateWithFlags(&h->ev_map, hipEventDisableTiming) == hipSuccess;
-    ok &= hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) == hipSuccess;
     ok &= hipEventCreateWithFlags(&h->ev_gn, hipEventDisableTiming) == hipSuccess;
-    ok &= hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess;
     c.overlap_pre = 1;
     ok &= dalloc(&c.src_cur, 3 * n) == hipSuccess && dalloc(&c.fdw, 3 * n) == hipSuccess;
     ok &= dalloc(&c.coltab, (size_t)c.W * 12) == hipSuccess;
@@ -303,21 +290,19 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
         c.row_mask = h->d_row_mask;
     }
     const int nb = (int)((n + 255) / 256) > 0 ? (int)((n + 255) / 256) : 1;
-    hipStream_t s = h->stream, sp = h->pre_stream;
+    hipStream_t s = h->stream;
     const int nb1 = (int)(((n > h->last_n ? n : h->last_n) + 255) / 256) > 0 ? (int)(((n > h->last_n ? n : h->last_n) + 255) / 256) : 1;
     // frame_down of this scan goes to the buffer the previous scan's map update is not reading
     c.fd = h->fd_buf[h->scans_done & 1];
     h->c.fd = c.fd;
-    // K0-K4 on the preprocessing stream: after the previous GN (pose) and the input upload, beside the previous K7-K10
-    if (h->ev_gn_valid) HIPCHK(hipStreamWaitEvent(sp, h->ev_gn, 0));
-    if (h->ev_in_pending) { HIPCHK(hipStreamWaitEvent(sp, h->ev_in, 0)); h->ev_in_pending = false; }
-    k_scan_prologue<<<1, 1024, 0, sp>>>(c);
-    k_deskew_vds1<<<nb1, 256, 0, sp>>>(c);
-    k_vds2<<<nb, 256, 0, sp>>>(c);
-    k_compact_fd<<<nb, 256, 0, sp>>>(c);
-    k_compact_src<<<nb, 256, 0, sp>>>(c);
-    HIPCHK(hipEventRecord(h->ev_pre, sp));
-    HIPCHK(hipStreamWaitEvent(s, h->ev_pre, 0));
+    // K0-K4 on the main stream, right behind the previous GN kernel (no hand-over: a stream that has to wait for another
+    // pays ~20 us of wake-up latency); beside them run the previous scan's map update (map stream) and, in the sequence
+    // runner, the EKF step (its own stream) - both are done before this chain is, so the waits below do not block
+    k_scan_prologue<<<1, 1024, 0, s>>>(c);
+    k_deskew_vds1<<<nb1, 256, 0, s>>>(c);
+    k_vds2<<<nb, 256, 0, s>>>(c);
+    k_compact_fd<<<nb, 256, 0, s>>>(c);
+    k_compact_src<<<nb, 256, 0, s>>>(c);
     if (h->ev_map_valid) HIPCHK(hipStreamWaitEvent(s, h->ev_map, 0));
     if (h->gn_wait) HIPCHK(hipStreamWaitEvent(s, h->gn_wait, 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -338,9 +323,6 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     HIPCHK(hipEventRecord(h->ev_gn, s));
     h->ev_gn_valid = true;
     if (h->gn_done) HIPCHK(hipEventRecord(h->gn_done, s));
-    if (h->post_ekf.on)
-        k_ekf_step<<<1, EKF_THREADS, 0, s>>>(h->post_ekf.st, h->post_ekf.imu, h->post_ekf.i0, h->post_ekf.i1, c.traj + 16 * (size_t)h->scans_done,
-                                    nullptr, h->post_ekf.res_pose, h->post_ekf.res_t, h->post_ekf.rows, 1);
     // local_map.update(frame_downsample, new_pose)  (kiss.py:129), on the map stream
     hipStream_t sm = h->map_stream;
     HIPCHK(hipStreamWaitEvent(sm, h->ev_gn, 0));
@@ -396,8 +378,6 @@ extern "C" int ptl_icp_register_frame(ptl_icp* h, const void* xyz, int dtype, in
     if (n) HIPCHK(hipMemcpyAsync(h->d_in, xyz, (size_t)n * 3 * esz, hipMemcpyHostToDevice, h->stream));
     if (t01 && n) HIPCHK(hipMemcpyAsync(h->d_t01, t01, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     if (guess) HIPCHK(hipMemcpyAsync(h->d_ext, guess, 16 * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipEventRecord(h->ev_in, h->stream));  // K0-K4 run on the preprocessing stream: order them after the upload
-    h->ev_in_pending = true;
     int rc = icp_enqueue_scan(h, dtype == PTL_F32 ? (const float*)h->d_in : nullptr,
                               dtype == PTL_F64 ? (const double*)h->d_in : nullptr, t01 ? h->d_t01 : nullptr, n,
                               guess ? h->d_ext : nullptr);
@@ -731,8 +711,6 @@ extern "C" int ptl_icp_register_range(ptl_icp* h, ptl_lut* lut, const uint32_t* 
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipMemcpyAsync(h->d_in, range_mm, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     if (guess) HIPCHK(hipMemcpyAsync(h->d_ext, guess, 16 * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipEventRecord(h->ev_in, h->stream));  // K0-K4 run on the preprocessing stream: order them after the upload
-    h->ev_in_pending = true;
     int rc = icp_enqueue_scan(h, nullptr, nullptr, nullptr, n, guess ? h->d_ext : nullptr, (const unsigned*)h->d_in, lut);
     if (rc) return rc;
     if (h->ev_map_valid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_map, 0));
@@ -1001,7 +979,7 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
         // or when the previous scan was skipped: otherwise the previous scan's EKF launch already ran them)
         const int64_t e = with_ekf ? s->imu_end[(size_t)k] : s->imu_pos;
         if (e > s->imu_pos) {
-            k_ekf_step<<<1, EKF_THREADS, 0, guess_ptr ? s->stream : es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+            k_ekf_step<<<1, EKF_THREADS, 0, es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
             s->imus_per_scan += e - s->imu_pos;
             s->imu_pos = e;
         }
@@ -1010,17 +988,13 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
         s->imus_per_scan = 0;
         const int64_t o = s->n_out;
         const int64_t e2 = (k + 1 < s->cfg.n_scans) ? s->imu_end[(size_t)k + 1] : s->imu_pos;
-        const bool inline_ekf = with_ekf && guess_ptr != nullptr;
-        if (inline_ekf) {
-            // the EKF is on the critical path (scan k+1 starts from its pose): same stream as the GN kernel
-            s->icp->post_ekf.st = s->ekf->st; s->icp->post_ekf.imu = s->d_imu;
-            s->icp->post_ekf.i0 = (int)s->imu_pos; s->icp->post_ekf.i1 = (int)e2;
-            s->icp->post_ekf.res_pose = s->d_res_poses + 16 * o; s->icp->post_ekf.res_t = s->d_res_t + o;
-            s->icp->post_ekf.rows = s->d_rows + 8 * o;
-            s->icp->post_ekf.on = true;
-        } else if (with_ekf) {
-            s->icp->gn_done = s->ev_gn;
+        if (with_ekf && guess_ptr) {
+            // the EKF step (update with scan k-1's pose, IMU predicts up to scan k) runs on its own stream beside K0-K4 and
+            // the map update; the GN launch of scan k waits for its pose - by then (K0-K4 take longer) it is there
+            HIPCHK(hipEventRecord(s->ev_guess, es));
+            s->icp->gn_wait = s->ev_guess;
         }
+        if (with_ekf) s->icp->gn_done = s->ev_gn;
         int rc;
         if (s->is_range[(size_t)k]) {
             if (!s->lut) rc = set_err(PTL_ERR_STATE, "scan %lld is a range image but no LUT was set", (long long)k);
@@ -1029,14 +1003,13 @@ extern "C" int ptl_seq_enqueue(ptl_seq* s, int64_t n) {
         } else {
             rc = icp_enqueue_scan(s->icp, s->d_scans + (size_t)k * pps * 3, nullptr, nullptr, (int64_t)pps, guess_ptr);
         }
-        s->icp->gn_wait = nullptr; s->icp->gn_done = nullptr; s->icp->post_ekf.on = false;
+        s->icp->gn_wait = nullptr; s->icp->gn_done = nullptr;
         if (rc) return rc;
         const double* kiss_pose = s->icp->c.traj + 16 * (s->icp->scans_done - 1);
-        if (with_ekf && !inline_ekf) {
-            // nothing waits for this EKF step but the next one: its own stream, beside the map update
-            HIPCHK(hipStreamWaitEvent(es, s->ev_gn, 0));
+        if (with_ekf) {
+            HIPCHK(hipStreamWaitEvent(es, s->ev_gn, 0));  // recorded right after the GN launch
             k_ekf_step<<<1, EKF_THREADS, 0, es>>>(s->ekf->st, s->d_imu, (int)s->imu_pos, (int)e2, kiss_pose, nullptr,
-                                         s->d_res_poses + 16 * o, s->d_res_t + o, s->d_rows + 8 * o, 1);
+                                                 s->d_res_poses + 16 * o, s->d_res_t + o, s->d_rows + 8 * o, 1);
         }
         if (with_ekf) {
             s->imus_per_scan += e2 - s->imu_pos;
