@@ -293,6 +293,20 @@ __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
     }
     __syncthreads();
     gn_ll_clear_on_wrap(c);
+    // per-column deskew transforms Exp((j/W - 0.5) xi): only W distinct times exist in a sweep (kiss.py:34-35)
+    if (st->do_deskew && c.t01 == nullptr) {
+        double xi[6];
+        for (int k = 0; k < 6; ++k) xi[k] = st->xi[k];
+        for (int j = threadIdx.x; j < c.W; j += blockDim.x) {
+            const double sft = (double)j * (1.0 / (double)c.W) - 0.5;
+            double x[6];
+            for (int k = 0; k < 6; ++k) x[k] = sft * xi[k];
+            const Rt M = se3_exp(x);
+            double* o = c.coltab + 12 * (size_t)j;
+            for (int k = 0; k < 9; ++k) o[k] = M.R[k];
+            for (int k = 0; k < 3; ++k) o[9 + k] = M.t[k];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ XYZLut
@@ -351,13 +365,11 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c) {
                 for (int k = 0; k < 6; ++k) x[k] = s * st->xi[k];
                 p = rt_apply(se3_exp(x), p);
             } else {
-                // column-implicit times (kiss.py:34-35): Exp((col / W - 1/2) xi), evaluated per point - 250 VALU
-                // instructions here cost less than the microseconds a per-column table added to K0, which sits on
-                // the critical path between two GN launches
-                const double sft = (double)(i % c.W) * (1.0 / (double)c.W) - 0.5;
-                double x[6];
-                for (int k = 0; k < 6; ++k) x[k] = sft * st->xi[k];
-                p = rt_apply(se3_exp(x), p);
+                const double* m = c.coltab + 12 * (size_t)(i % c.W);
+                Rt M;
+                for (int k = 0; k < 9; ++k) M.R[k] = m[k];
+                for (int k = 0; k < 3; ++k) M.t[k] = m[9 + k];
+                p = rt_apply(M, p);
             }
         }
         const double r = sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
