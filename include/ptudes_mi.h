@@ -159,6 +159,8 @@ int ptl_icp_gn_phases(ptl_icp *h, int64_t out[8]);
 /* diagnostic: ticks each Gauss-Newton workgroup spent in the search phase since creation; out holds 2 * gn_workgroups
  * values (until the last / the first wavefront finished) */
 int ptl_icp_gn_wg_clocks(ptl_icp *h, int64_t *out, int32_t max_wgs);
+/* test hook: set the 22-bit launch epoch of the Gauss-Newton exchange (exercises its wrap-around) */
+int ptl_icp_debug_set_epoch(ptl_icp *h, uint32_t epoch);
 
 /* ------------------------------------------------------------------------------------------------
  * EKF handle == reference ESEKF (src/ptudes/ins/es_ekf.py:57-365)

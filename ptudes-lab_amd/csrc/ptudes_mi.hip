@@ -550,6 +550,18 @@ extern "C" int ptl_icp_align(ptl_icp* h, const double* frame, int64_t n, const d
     return PTL_OK;
 }
 
+// test hook: set the launch epoch of the Gauss-Newton exchange (its 22-bit wrap-around is otherwise 4 million scans away)
+__global__ void k_set_epoch(DevState* st, unsigned v) { if (threadIdx.x == 0 && blockIdx.x == 0) st->gn_epoch = v & 0x3FFFFFu; }
+extern "C" int ptl_icp_debug_set_epoch(ptl_icp* h, uint32_t epoch) {
+    if (!h) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    int rc = icp_check_flags(h);
+    if (rc) return rc;
+    k_set_epoch<<<1, 64, 0, h->stream>>>(h->c.st, epoch);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PTL_OK;
+}
+
 // diagnostic: ticks every GN workgroup spent in the search phase since creation: out[0..G) until its last wavefront
 // finished, out[G..2G) its first wavefront
 extern "C" int ptl_icp_gn_wg_clocks(ptl_icp* h, int64_t* out, int32_t max_wgs) {

@@ -362,3 +362,20 @@ def test_sequence_other_seeds_and_ranges_vs_oracle(seed, min_range, max_range):
     for k in range(n):
         for key in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "map_voxels", "map_points"):
             assert out["stats"][k][key] == ref["stats"][k][key], (k, key)
+
+
+def test_exchange_epoch_wraparound(seq):
+    """the flag of the Gauss-Newton exchange carries a 22-bit launch epoch; crossing its wrap-around (buffers are cleared
+    and flags restart) must not change a single bit of the result"""
+    from ptudes_lab_amd import _lib as L
+    gt = seq.gt_poses(0.5)
+    g0i = np.linalg.inv(gt[0])
+    ref, alt = core.Icp(70.0, 1.0), core.Icp(70.0, 1.0)
+    L.check(L.lib().ptl_icp_debug_set_epoch(alt._h, 0x3FFFFD))
+    for k in range(6):
+        x = seq.scan(k)
+        guess = g0i @ gt[k]
+        Tr = ref.register_frame(x, None, guess)
+        Ta = alt.register_frame(x, None, guess)
+        assert np.array_equal(Tr, Ta), k
+        assert ref.stats[-1]["iterations"] == alt.stats[-1]["iterations"]
