@@ -257,7 +257,9 @@ static int icp_grow_traj(ptl_icp* h) {
     HIPCHK(hipMemcpyAsync(nt, c.traj, (size_t)h->traj_cap * 16 * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(ns, c.sstats, (size_t)h->traj_cap * sizeof(ScanStats), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    hipFree(c.traj); hipFree(c.sstats);
+    HIPCHK(hipStreamSynchronize(h->map_stream));
+    HIPCHK(hipDeviceSynchronize());  // (a sequence runner's EKF stream may still read the old trajectory rows)
+    (void)hipFree(c.traj); (void)hipFree(c.sstats);
     c.traj = nt; c.sstats = ns;
     h->traj_cap = ncap; c.traj_cap = (int)ncap;
     return PTL_OK;
