@@ -55,24 +55,6 @@ def scan_bytes(s, n_raw):
     return b_pre + b_ds + icp_bytes(s) + b_map
 
 
-def usable_cores():
-    """cores this process may actually use: the affinity mask capped by the cgroup CPU quota"""
-    n = len(os.sched_getaffinity(0))
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            n = min(n, max(1, int(q) // int(per)))
-    except (OSError, ValueError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except (OSError, ValueError):
-            pass
-    return n
-
-
 def _cpu_pass(seq, n_total, use_imu_prediction, budget_s):
     from oracle import cpu as orc
     icp = orc.ICP(max_range=seq.max_range, min_range=seq.min_range)
@@ -104,6 +86,7 @@ def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0):
     trajectory) and one pass with the loops kiss-icp runs under TBB spread over every usable core (oracle.h
     orc_set_threads).  `value` is the faster of the two."""
     from oracle import cpu as orc
+    from ptudes_lab_amd.synth import usable_cores
     cores = usable_cores()
     orc.set_threads(1)
     d1, s1, kiss, res = _cpu_pass(seq, n_total, use_imu_prediction, budget_s / 3.0)

@@ -113,12 +113,19 @@ static double cast(const double o[3], const double d[3], const double room[6], c
     return best;
 }
 
+/* Rows are rendered by at most this many threads (every ray has its own seed, so the result does not depend on
+ * it). The default OpenMP team is one thread per visible core, which is far more than a container's CPU quota
+ * allows to run: 256 threads on a 16-core quota made one sweep take 124 ms instead of 4. */
+static int synth_threads = 1;
+void ptl_synth_set_threads(int32_t n) { synth_threads = n < 1 ? 1 : n; }
+
 /* col_poses: W x 12 doubles, per column R (row-major 9) then t (3): world <- sensor at firing time */
 void ptl_synth_render(const double room[6], const double *boxes, int32_t nb, const double *cyls, int32_t nc,
                       const ptl_synth_sensor *s, const double *col_poses, uint64_t seed, float *xyz_out) {
     const int H = s->H, W = s->W;
     const double deg = M_PI / 180.0;
-#pragma omp parallel for schedule(static)
+    const int nthr = (H * W < 8192) ? 1 : (synth_threads < H ? synth_threads : H);
+#pragma omp parallel for schedule(static) num_threads(nthr)
     for (int row = 0; row < H; ++row) {
         double el = (H > 1) ? s->el_top_deg + (s->el_bot_deg - s->el_top_deg) * (double)row / (double)(H - 1)
                             : s->el_top_deg;

@@ -49,7 +49,28 @@ def _l():
         _lib.ptl_synth_trajectory.restype = None
         _lib.ptl_synth_trajectory.argtypes = [dp, dp, C.c_int32, dp, dp, C.c_int32, C.c_double, C.c_double,
                                               C.c_int64, dp, C.c_double, dp, dp, dp, dp]
+        _lib.ptl_synth_set_threads.restype = None
+        _lib.ptl_synth_set_threads.argtypes = [C.c_int32]
+        _lib.ptl_synth_set_threads(min(usable_cores(), 16))
     return _lib
+
+
+def usable_cores():
+    """cores this process may actually use: the affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def _p(a):

@@ -379,3 +379,24 @@ def test_exchange_epoch_wraparound(seq):
         Ta = alt.register_frame(x, None, guess)
         assert np.array_equal(Tr, Ta), k
         assert ref.stats[-1]["iterations"] == alt.stats[-1]["iterations"]
+
+
+def test_long_run_grows_the_trajectory_buffers():
+    """more sweeps than the initial trajectory capacity (4096): the buffers are re-allocated in the middle of a resident
+    run, with the EKF stream still reading rows of the old ones - nothing may change"""
+    n = 4200
+    sq = synth.make_sequence(seed=77, n_scans=n, H=16, W=64)
+    n_imu = sq.imu_range_for_scan(n - 1)[1]
+
+    def run(m):
+        r = core.SeqRunner(m, sq.H * sq.W, sq.imu_range_for_scan(m - 1)[1], max_range=70.0, min_range=1.0,
+                           use_imu_prediction=True, with_ekf=True, scan_cols=sq.W)
+        _upload(sq, r, m)
+        r.run()
+        return r.results()
+
+    full, head = run(n), run(64)
+    assert len(full["kiss_poses"]) == n and np.isfinite(full["res_poses"]).all()
+    assert np.array_equal(full["kiss_poses"][:64], head["kiss_poses"])
+    assert np.array_equal(full["res_poses"][:64], head["res_poses"])
+    assert n_imu > 0 and full["res_t"][-1] > full["res_t"][0]
