@@ -16,6 +16,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before anything initialises HIP: see ptudes-lab_amd/_lib.py
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # cpu_baseline's OpenMP pass: idle threads must not burn the cgroup quota
 
 import numpy as np  # noqa: E402
@@ -113,6 +114,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--seqs-per-gpu", type=int, default=1)
+    ap.add_argument("--seed-base", type=int, default=1000, help="sequence s of SURVEY.md 8(d) uses seed seed_base + s")
+    ap.add_argument("--distinct-seeds", action="store_true",
+                    help="rank r takes sequences seed_base + r, + world + r, ... (SURVEY.md 8(e)) instead of every rank "
+                         "registering its own copy of sequences seed_base .. seed_base + S - 1")
     ap.add_argument("--rows", type=int, default=128)
     ap.add_argument("--cols", type=int, default=1024)
     ap.add_argument("--max-range", type=float, default=70.0)
@@ -134,11 +139,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    ctl = None
     if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # launched by torch.distributed.run
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL carries the one collective of the path, the trajectory gather after the run.  Its communicator is brought
+        # up there and not before: a live RCCL communicator in the process stretches the cross-stream hand-overs of the
+        # scan pipeline from 63 to 110 us per scan (2700 -> 2400 scans/s, measured with one rank).  Barriers and the
+        # max-over-ranks clock go through a host-side gloo group.
+        dist.init_process_group(backend="nccl")
+        ctl = dist.new_group(backend="gloo")
 
     import ptudes_lab_amd  # noqa: F401
     from ptudes_lab_amd import core, synth
@@ -155,7 +166,11 @@ def main():
     if args.map_table: icp_over["map_table_capacity"] = args.map_table
     seqs = []
     for j in range(S):
-        seed = 1000 + rank + world * j  # sequence ids s with s % world == rank
+        # Weak scaling = the same work on every GPU: by default each rank registers its own copy of the same sequence(s)
+        # (own map, own poses, own filter, nothing shared).  The sequences of SURVEY.md 8(d) differ by +-20 % in GN
+        # iterations per scan, so with --distinct-seeds (ids s with s % world == rank, 8(e)) the max-over-ranks clock
+        # measures the slowest sequence, not the scaling.
+        seed = args.seed_base + (rank + world * j if args.distinct_seeds else j)
         seqs.append(synth.make_sequence(seed=seed, n_scans=n_total, H=args.rows, W=args.cols, min_range=args.min_range,
                                         max_range=args.max_range))
     n_imu = seqs[0].imu_range_for_scan(n_total - 1)[1]
@@ -183,7 +198,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctl)
 
     def sync():
         if torch is not None:
@@ -204,7 +219,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         from ptudes_lab_amd import parallel
-        dt = parallel.max_over_ranks(dt, dist, device="cuda")
+        dt = parallel.max_over_ranks(dt, dist, device="cpu", group=ctl)
 
     # per-rank accounting
     outs = [runner.results(j) for j in range(S)]
@@ -240,6 +255,10 @@ def main():
         avg_gn_s = (gn_ms / 1e3) / max(gn_n, 1)
         avg_gn_bytes = gn_bytes / max(gn_n, 1)  # one launch carries the GN loops of all S sequences
         achieved = avg_gn_bytes / avg_gn_s if avg_gn_s > 0 else 0.0
+        if args.distinct_seeds:
+            seeds_txt = f"{args.seed_base}..{args.seed_base + world * S - 1} (rank r: s % {world} == r)"
+        else:
+            seeds_txt = f"{args.seed_base}..{args.seed_base + S - 1}" + (", a private copy on every rank (equal work per GPU)" if world > 1 else "")
         line = {
             "metric": f"lidar scans/sec (ICP+EKF) on {args.rows}x{args.cols} sweeps",
             "value": K * S * world / dt, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -249,7 +268,7 @@ def main():
                                    f"ICP + IMU-EKF ({'--use-imu-prediction' if use_imu else 'constant-velocity guess'}), "
                                    f"min/max range {args.min_range}/{args.max_range} m, voxel {(args.voxel_size or args.max_range / 100):.2f} m"
                                    + (f" [{args.workload_name}]" if args.workload_name else ""),
-                       "sequences_per_gpu": S, "sequence_seeds": f"{1000}..{1000 + world * S - 1}",
+                       "sequences_per_gpu": S, "sequence_seeds": seeds_txt,
                        "scans_per_sequence": n_total, "parallelism": f"{world} independent sequence shard(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(), "kernel": "k_gn_loop" if S == 1 else "kb_gn_loop",
@@ -278,7 +297,7 @@ def main():
             line["gathered_trajectories"] = {"sequences": len(gathered), "rows_each": sorted({len(v) for v in gathered.values()})}
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=ctl)
         dist.destroy_process_group()
 
 

@@ -132,6 +132,12 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
                 "g.build()' or make -C ptudes-lab_amd/csrc).  There is no CPU fallback.")
+        # A handle drives three HIP streams (registration, map update, filter) that hand over to each other once per
+        # scan.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): as
+        # soon as other streams exist in the process (torch's, an RCCL communicator's) ours share a queue and every
+        # hand-over serialises behind the neighbour's commands: 63 -> 110 us per scan, measured.  The variable is read
+        # when the runtime initialises, so this only helps if nothing touched the GPU yet.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             f = getattr(L, name)  # AttributeError if the library does not export a declared symbol

@@ -38,10 +38,10 @@ def gather_trajectories(rows, counts, dist, device=None):
     return out
 
 
-def max_over_ranks(value: float, dist, device="cpu") -> float:
+def max_over_ranks(value: float, dist, device="cpu", group=None) -> float:
     import torch
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
 
