@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GN_EVENT_EVERY = 8
+GATHER_TIMEOUT_S = 120
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -130,13 +131,14 @@ def main():
     ap.add_argument("--map-blocks", type=int, default=0, help="voxel-block pool capacity")
     ap.add_argument("--map-table", type=int, default=0, help="map hash-table slots (power of two)")
     ap.add_argument("--workload-name", type=str, default="")
+    ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.device < 0 else args.device
     dist = None
     torch = None
     ctl = None
@@ -236,13 +238,30 @@ def main():
     n_timed = sum(len(o["stats"]) - W for o in outs)
     assert n_timed == K * S, (n_timed, K, S)
 
-    # final trajectory gather: the only collective (T x 8 NC-GT rows per sequence, RCCL all-gather)
-    gathered = None
+    # final trajectory gather: the only collective (T x 8 NC-GT rows per sequence, RCCL all-gather).  It runs after the
+    # timed region and brings the RCCL communicator up; a failure or a stall there is reported in the line, not fatal.
+    gathered, gather_err = None, None
     if dist is not None:
+        import threading
         from ptudes_lab_amd import parallel
-        rows = torch.zeros((S, n_total, 8), dtype=torch.float64, device="cuda")
-        counts = [runner.copy_traj(j, rows[j].data_ptr(), n_total) for j in range(S)]
-        gathered = parallel.gather_trajectories(rows, counts, dist)
+        box = {}
+
+        def _gather():
+            try:
+                torch.cuda.set_device(local_rank)
+                rows = torch.zeros((S, n_total, 8), dtype=torch.float64, device="cuda")
+                counts = [runner.copy_traj(j, rows[j].data_ptr(), n_total) for j in range(S)]
+                box["out"] = parallel.gather_trajectories(rows, counts, dist)
+            except Exception as e:  # noqa: BLE001
+                box["err"] = repr(e)
+
+        th = threading.Thread(target=_gather, daemon=True)
+        th.start()
+        th.join(timeout=GATHER_TIMEOUT_S)
+        gathered = box.get("out")
+        gather_err = "no answer after %d s" % GATHER_TIMEOUT_S if th.is_alive() else box.get("err")
+        if parallel.max_over_ranks(0.0 if gather_err is None else 1.0, dist, device="cpu", group=ctl) > 0 and gather_err is None:
+            gather_err = "failed on another rank"  # every rank takes the same exit below
 
     if rank == 0:
         from ptudes_lab_amd.ins.data import calc_ate
@@ -295,8 +314,13 @@ def main():
             line["cpu_baseline"] = None
         if gathered is not None:
             line["gathered_trajectories"] = {"sequences": len(gathered), "rows_each": sorted({len(v) for v in gathered.values()})}
+        elif gather_err is not None:
+            line["gathered_trajectories"] = {"error": gather_err}
         print(json.dumps(line), flush=True)
     if dist is not None:
+        if gather_err is not None:  # a communicator in an unknown state: leave without the collective shutdown
+            sys.stdout.flush()
+            os._exit(0)
         dist.barrier(group=ctl)
         dist.destroy_process_group()
 
