@@ -1,13 +1,15 @@
 """`ekf-bench` commands: drop-in for the pose path of reference src/ptudes/cli/ekf_bench.py.
 
   sim     EKF with simulated IMU (reference :107-179) - the filter's known-answer harness
+  nc      Newer College bag IMU + ground-truth pose corrections (reference :183-323)
   ouster  IMU + scans -> KissICP poses -> EKF smoothing, KITTI / NC-GT pose files out (reference :381-666)
   cmp     compare trajectories in Newer College format (reference :686-760)
 
 Same option names, printed lines and output files.  Differences, all because ouster-sdk / rosbags are not
 installable offline: `ouster` reads .pcap/.bag only when ouster-sdk is importable and otherwise (or with
 --synthetic SEED) runs on a synthetic 128x1024 sequence; plotting options (-p) are not provided (the
-OpenGL / matplotlib viewers are outside the path).  `nc` (bag IMU + GT updates) needs rosbags and is not provided.
+OpenGL / matplotlib viewers are outside the path).  `nc` reads the bag with the package's own ROS1 reader (bag.py)
+instead of rosbags.
 """
 import os
 from datetime import datetime
@@ -25,6 +27,7 @@ from ..utils import (filter_nc_gt_by_close_ts, filter_nc_gt_by_cmp, read_newer_c
                      save_poses_kitti_format, save_poses_nc_gt_format)
 
 DOWN = np.array([0, 0, -1])
+UP = np.array([0, 0, 1])
 
 
 @click.group(name="ekf-bench")
@@ -88,6 +91,82 @@ def ptudes_ekf_sim(duration: float, corr_t: float, freq: float, acc_noise_std: f
     ate_rot, ate_trans = ekf_traj_ate(ekf_gt, ekf)
     print(f"ATE_rot:   {ate_rot:.04f} deg")
     print(f"ATE trans: {ate_trans:.04f} m")
+
+
+@click.command(name="nc")
+@click.argument("file", required=True, type=click.Path(exists=True))
+@click.option("-m", "--meta", required=False, type=click.Path(exists=True, dir_okay=False, readable=True),
+              help="Metadata for BAG, required if automatic metadata resolution fails")
+@click.option("-g", "--gt-file", required=True, type=click.Path(exists=True, dir_okay=False, readable=True),
+              help="Ground truth file with poses to compare and correct poses")
+@click.option("-t", "--duration", type=float, default=0.0,
+              help="Time duration of the data read/processed :(seconds, default 2.0)")
+@click.option("--start-ts", type=float, default=0.0,
+              help="Start time (relative to the beginning of the data) (seconds, default 0.0)")
+@click.option("-p", "--plot", required=False, type=str, help="Plotting option [graphs, point_viz] (not provided here)")
+@click.option("--xy-plot", is_flag=True, help="Draw X and Y dimenstions on XY plane, instead of separate")
+@click.option("-i", "--imu-topic", required=False, default="/os_node/imu_packets", type=str,
+              help="Imu topic name to use (msg/Imu or imu_packets)")
+def ptudes_ekf_nc(file: str, meta: Optional[str] = None, gt_file: Optional[str] = None, duration: float = 2.0,
+                  start_ts: float = 0.0, plot: Optional[str] = None, xy_plot: bool = False,
+                  imu_topic: Optional[str] = None) -> None:
+    """EKF with Newer College Dataset IMUs topics.
+
+    Ground truth (--gt-file) is used for pose correction.
+    """
+    from .. import bag  # IMUBagSource looked up at call time, as the reference imports it inside the command (:235)
+
+    init_grav = GRAV * UP
+    # the Ouster IMU and the alphasense IMU have different nav frames (reference :236-239)
+    if imu_topic in ["/os_cloud_node/imu", "/os_node/imu_packets"]:
+        init_grav = GRAV * DOWN
+    print("init_grav = ", init_grav)
+    print("Reading NC dataset:")
+    print(f"  file: {file}")
+    print(f"  topic: {imu_topic}")
+    print(f"  gt file: {gt_file}")
+    imu_source = bag.IMUBagSource(file, imu_topic=imu_topic)
+    if not gt_file:
+        print("need gt now")
+        return
+    gts = read_newer_college_gt(gt_file)
+    pose_corr_idx = 0
+    gt_pose0 = np.linalg.inv(gts[pose_corr_idx][1])
+    print("Running EKF ... \n")
+    ekf = ESEKF(init_grav=init_grav, _logging=bool(plot))
+    gt_poses, res_poses = [], []
+    gt0_initialized = False
+    ts, first_ts = 0, -1
+    for imu in imu_source:
+        ts = imu.ts
+        if first_ts < 0:
+            first_ts = ts
+        if ts - first_ts < start_ts:  # skipping till the beginning (--start-ts)
+            continue
+        if not gt0_initialized:
+            while pose_corr_idx < len(gts) and ts >= gts[pose_corr_idx][0]:
+                pose_corr_idx += 1
+            gt_pose0 = np.linalg.inv(gts[pose_corr_idx][1])
+            gt0_initialized = True
+        ekf.processImu(imu)
+        if ts >= gts[pose_corr_idx][0]:
+            pose_corr = gt_pose0 @ gts[pose_corr_idx][1]
+            ekf.processPose(pose_corr)
+            gt_poses.append(pose_corr)
+            res_poses.append(ekf.nav.pose_mat())
+            # past the last GT row the index stays, and every further IMU is followed by a correction with that row
+            if pose_corr_idx + 1 < len(gts):
+                pose_corr_idx += 1
+        if duration > 0 and ts - first_ts - start_ts > duration:
+            break
+    print(f"scanned duration: {ts - first_ts - start_ts:0.04} s")
+    print(f"updates num: {len(res_poses)}\n")
+    if res_poses:
+        ate_rot, ate_trans = calc_ate(res_poses, gt_poses)
+        print(f"ATE_rot:   {ate_rot:.04f} deg")
+        print(f"ATE trans: {ate_trans:.04f} m")
+    if plot:
+        print(f"WARNING: plot param '{plot}' doesn't supported")
 
 
 def _synthetic_source(seed: int, n_scans: int):
@@ -234,5 +313,6 @@ def ptudes_ekf_cmp(gt_file: str, gt_file_cmp: List[str]) -> None:
 
 
 ptudes_ekf_bench.add_command(ptudes_ekf_sim)
+ptudes_ekf_bench.add_command(ptudes_ekf_nc)
 ptudes_ekf_bench.add_command(ptudes_ekf_ouster)
 ptudes_ekf_bench.add_command(ptudes_ekf_cmp)

@@ -124,7 +124,7 @@ def case_ekf_steps(variant):
             upd_cov.append(np.zeros((6, 6)) if cov is None else cov)
     np.savez_compressed(
         os.path.join(HERE, f"ekf_steps_{variant}.npz"),
-        imu_ts=ts, imu_lacc=lacc, imu_avel=avel, nav_after_imu=navs,
+        imu_ts=ts, imu_ts_ns=ts_ns, imu_lacc=lacc, imu_avel=avel, nav_after_imu=navs,
         upd_idx=np.array(upd_idx), upd_pose=np.array(upd_pose),
         upd_cov=np.array(upd_cov), has_cov=np.array(variant == "cov"),
         nav_after_upd=np.array(navs_post), cov_pre=np.array(covs_pre),
@@ -415,6 +415,72 @@ def case_packet_feed():
         json.dump({"packets": enc, "events": out}, f)
 
 
+def case_ekf_nc(variant):
+    """`ptudes ekf-bench nc` (cli/ekf_bench.py:220-323): IMU stream from a bag + GT poses used as pose corrections.
+    rosbags is absent, so `ptudes.bag.IMUBagSource` is replaced by a source yielding the reference's own `IMU` objects
+    from a seeded stream; the GT file is written with the reference's NC-GT writer.  Records the stream, the GT file
+    text, what the command printed and the filter pose after every correction.  One option set per process (App. C1)."""
+    import numpy as np
+    import ptudes.cli.ekf_bench as eb
+    import ptudes.bag as pbag
+    from ptudes.ins.data import IMU
+    from ptudes.utils import save_poses_nc_gt_format
+    from scipy.spatial.transform import Rotation as R
+    from click.testing import CliRunner
+
+    rng = np.random.default_rng(20240)
+    n = 400
+    t0 = 1583836591.0
+    # stamps on the nanosecond grid, turned into seconds the way the reference does for sensor_msgs/Imu (bag.py:139)
+    ts_ns = np.int64(t0) * 10**9 + 10_000_000 * np.arange(n, dtype=np.int64) + rng.integers(-200_000, 200_000, n)
+    ts = np.array([int(v) // 10**9 + (int(v) % 10**9) * 1e-9 for v in ts_ns])
+    grav = 9.782940329221166
+    lacc = np.array([0.0, 0.0, grav]) + rng.normal(0, 0.3, (n, 3)) + 0.4 * np.sin(np.arange(n)[:, None] * 0.05 + np.array([0, 1, 2]))
+    avel = rng.normal(0, 0.05, (n, 3)) + 0.1 * np.cos(np.arange(n)[:, None] * 0.03 + np.array([0.5, 1.5, 2.5]))
+    # GT at ~10 Hz, starting before the IMU stream and ending before its end
+    m = 36
+    gt_t = t0 - 0.25 + 0.1 * np.arange(m) + rng.uniform(-3e-3, 3e-3, m)
+    gt_poses = []
+    for k in range(m):
+        T = np.eye(4)
+        T[:3, :3] = R.from_rotvec([0.01 * k, -0.004 * k, 0.02 * k]).as_matrix()
+        T[:3, 3] = [0.05 * k, 0.02 * k * np.sin(0.3 * k), 0.01 * k]
+        gt_poses.append(T)
+    gt_path = os.path.join(HERE, "ekf_nc_gt.csv")
+    save_poses_nc_gt_format(gt_path, t=list(gt_t), poses=gt_poses, header="ekf-bench nc golden")
+
+    class Src:
+        def __init__(self, data_path, imu_topic=None):
+            self.imu_topic = imu_topic
+
+        def __iter__(self):
+            for i in range(n):
+                yield IMU(lacc[i].copy(), avel[i].copy(), float(ts[i]))
+
+    pbag.IMUBagSource = Src
+    poses_log = []
+    orig = eb.ESEKF
+
+    class Rec(orig):
+        def processPose(self, *a, **k):
+            super().processPose(*a, **k)
+            poses_log[-1].append((self.ts, self.nav.pose_mat().copy()))
+
+    eb.ESEKF = Rec
+    bag_path = os.path.join(HERE, "ekf_nc_gt.csv")  # any existing path satisfies click.Path(exists=True); never opened
+    runs = {"default": ["-g", gt_path], "start": ["-g", gt_path, "--start-ts", "0.7", "-t", "1.5"],
+            "alphasense": ["-g", gt_path, "-i", "/alphasense/imu", "-t", "2.0"]}
+    args = runs[variant]
+    poses_log.append([])
+    res = CliRunner().invoke(eb.ptudes_ekf_nc, [bag_path] + args)
+    assert res.exit_code == 0, (res.output, res.exception)
+    np.savez_compressed(os.path.join(HERE, f"ekf_nc_{variant}.npz"), imu_ts=ts, imu_ts_ns=ts_ns, imu_lacc=lacc, imu_avel=avel, gt_t=gt_t,
+                        gt_poses=np.array(gt_poses), upd_t=np.array([p[0] for p in poses_log[-1]]),
+                        upd_pose=np.array([p[1] for p in poses_log[-1]]))
+    with open(os.path.join(HERE, f"ekf_nc_{variant}.json"), "w") as f:
+        json.dump({"args": args[2:], "stdout": res.output.replace(gt_path, "<GT>").replace(bag_path, "<BAG>")}, f, indent=1)
+
+
 CASES = {
     "ekf_steps_default": lambda: case_ekf_steps("default"),
     "ekf_steps_init": lambda: case_ekf_steps("init"),
@@ -427,6 +493,9 @@ CASES = {
     "imu_nav": case_imu_nav,
     "stream_stats": case_stream_stats,
     "packet_feed": case_packet_feed,
+    "ekf_nc_default": lambda: case_ekf_nc("default"),
+    "ekf_nc_start": lambda: case_ekf_nc("start"),
+    "ekf_nc_alphasense": lambda: case_ekf_nc("alphasense"),
 }
 
 if __name__ == "__main__":
