@@ -32,14 +32,23 @@ def read_metadata_json(meta_path: str):
 
 
 def read_packet_source(file_path: str, meta=None):
-    """Ouster raw packet source of a .pcap (reference utils.py:171-187).  ROS bags need the reference's rosbags-based
-    reader (bag.py), which this build does not provide."""
+    """Open PCAP or BAG based Ouster raw packet source (reference utils.py:171-187): a .pcap through ouster-sdk, a .bag
+    or a directory of .bag files (sorted by name) through `bag.OusterRawBagSource`.  Both need ouster-sdk for the
+    packet types; like the reference, anything else yields None."""
+    import glob
     from pathlib import Path
-    from ouster import pcap  # guarded
     file = Path(file_path)
-    if file.is_file() and file.suffix == ".pcap":
-        return pcap.Pcap(file_path, meta)
-    raise ValueError(f"'{file_path}': only .pcap packet files are supported by this build (no rosbags reader)")
+    if file.is_file():
+        if file.suffix == ".pcap":
+            from ouster import pcap  # guarded
+            return pcap.Pcap(file_path, meta)
+        elif file.suffix == ".bag":
+            from .bag import OusterRawBagSource
+            return OusterRawBagSource(file, meta)
+    elif file.is_dir():
+        from .bag import OusterRawBagSource
+        bags_paths = sorted([Path(p) for p in glob.glob(str(Path(file) / "*.bag"))])
+        return OusterRawBagSource(bags_paths, meta)
 
 
 def vee(vec: np.ndarray) -> np.ndarray:
