@@ -917,11 +917,9 @@ __device__ __forceinline__ double gn_ll_join(unsigned half) {
 template <int PC, bool MC>
 __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     __shared__ double red[GN_MAX_GROUPS][32];
-    __shared__ double red2[4][32];
     __shared__ double tot[32];
     __shared__ double Esh[12];
     __shared__ double Tsh[12];
-    __shared__ double stage[32];
     __shared__ double scur[GN_MAX_GROUPS][4];
     __shared__ double redL[64][32];  // a leader's member rows (G <= 512)
     __shared__ int flag_done;

@@ -447,7 +447,7 @@ extern "C" int ptl_icp_map_points(ptl_icp* h, double* xyz_out, int64_t max_point
     HIPCHK(hipStreamSynchronize(h->stream));
     const int64_t n = cnt < max_points ? cnt : max_points;
     if (n > 0) HIPCHK(hipMemcpy(xyz_out, d_out, (size_t)n * 3 * 8, hipMemcpyDeviceToHost));
-    hipFree(d_out);
+    (void)hipFree(d_out);
     if (n_written) *n_written = n;
     return PTL_OK;
 }
@@ -776,13 +776,13 @@ static int ekf_create_impl(const ptl_ekf_cfg* cfg, hipStream_t shared, ptl_ekf**
     h->st = nullptr; h->d_buf = nullptr; h->buf_rows = 1024;
     if (h->own_stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return set_err(PTL_ERR_HIP, "stream"); }
     if (dalloc(&h->st, 1) != hipSuccess || dalloc(&h->d_buf, (size_t)h->buf_rows * 7 + 64) != hipSuccess) {
-        if (h->st) hipFree(h->st);
+        if (h->st) (void)hipFree(h->st);
         delete h;
         return set_err(PTL_ERR_HIP, "device allocation failed");
     }
     int rc = ekf_reset(h);
     if (rc == PTL_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = set_err(PTL_ERR_HIP, "sync");
-    if (rc) { hipFree(h->st); hipFree(h->d_buf); delete h; return rc; }
+    if (rc) { (void)hipFree(h->st); (void)hipFree(h->d_buf); delete h; return rc; }
     *out = h;
     return PTL_OK;
 }
@@ -790,8 +790,8 @@ extern "C" int ptl_ekf_create(const ptl_ekf_cfg* cfg, ptl_ekf** out) { return ek
 extern "C" int ptl_ekf_destroy(ptl_ekf* h) {
     if (!h) return PTL_OK;
     (void)hipSetDevice(h->cfg.device_id);
-    hipFree(h->st); hipFree(h->d_buf);
-    if (h->own_stream) hipStreamDestroy(h->stream);
+    (void)hipFree(h->st); (void)hipFree(h->d_buf);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PTL_OK;
 }
@@ -883,15 +883,15 @@ extern "C" int ptl_seq_destroy(ptl_seq* s) {
     (void)hipSetDevice(s->cfg.icp.device_id);
     if (s->icp) icp_free(s->icp);
     if (s->ekf) ptl_ekf_destroy(s->ekf);
-    if (s->d_scans) hipFree(s->d_scans);
-    if (s->d_imu) hipFree(s->d_imu);
-    if (s->d_res_poses) hipFree(s->d_res_poses);
-    if (s->d_res_t) hipFree(s->d_res_t);
-    if (s->d_rows) hipFree(s->d_rows);
-    if (s->ev_guess) hipEventDestroy(s->ev_guess);
-    if (s->ev_gn) hipEventDestroy(s->ev_gn);
-    if (s->ekf_stream) hipStreamDestroy(s->ekf_stream);
-    if (s->stream) hipStreamDestroy(s->stream);
+    if (s->d_scans) (void)hipFree(s->d_scans);
+    if (s->d_imu) (void)hipFree(s->d_imu);
+    if (s->d_res_poses) (void)hipFree(s->d_res_poses);
+    if (s->d_res_t) (void)hipFree(s->d_res_t);
+    if (s->d_rows) (void)hipFree(s->d_rows);
+    if (s->ev_guess) (void)hipEventDestroy(s->ev_guess);
+    if (s->ev_gn) (void)hipEventDestroy(s->ev_gn);
+    if (s->ekf_stream) (void)hipStreamDestroy(s->ekf_stream);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return PTL_OK;
 }

@@ -35,6 +35,7 @@ def test_stream_stats_tracker_vs_reference_golden(golden_dir, name, beams):
     assert repr(st) == open(os.path.join(golden_dir, f"stream_stats_{name}.txt")).read()
 
 
+@pytest.mark.filterwarnings("ignore:invalid value encountered")  # the reference's pooled-variance formula divides 0 by 0 for a single point
 def test_range_stats_edge_cases():
     st = StreamStatsTracker()
     with pytest.raises(ValueError):
