@@ -519,6 +519,19 @@ __device__ __forceinline__ int map_find(const CT& c, unsigned long long key) {
     return -1;
 }
 
+// The correspondence gate of Registration.cpp is `norm < max_correspondence_distance`, i.e. sqrt(d2) < M on the squared
+// distance the search returns.  sqrt is correctly rounded and monotone, so the distances that pass are exactly those
+// below T = min { x : sqrt(x) >= M }: the gate becomes one comparison per point and iteration instead of an fp64
+// square root, with the same outcome for every input.  T is M * M up to a few ulp; it is found once per launch.
+__device__ __forceinline__ double sqrt_gate(double M) {
+    if (!(M > 0.0) || !(M < 1.0e150)) return (M > 0.0) ? M : 0.0;  // +inf: everything passes; <= 0 or NaN: nothing does
+    double T = M * M;
+    for (int k = 0; k < 64 && sqrt(__longlong_as_double(__double_as_longlong(T) - 1)) >= M; ++k)
+        T = __longlong_as_double(__double_as_longlong(T) - 1);
+    for (int k = 0; k < 64 && sqrt(T) < M; ++k) T = __longlong_as_double(__double_as_longlong(T) + 1);
+    return T;
+}
+
 // (int)(x / vs) - the voxel index of VoxelHashMap / VoxelDownsample (C truncation) - without the fp64 division in the
 // common case: q = x * (1 / vs) differs from the correctly rounded quotient by a few ulp, so both truncate alike
 // unless an integer lies within 1e-9 (|q| + 1) of q; only then is the real division evaluated.
@@ -580,32 +593,41 @@ __device__ __forceinline__ int nn_probe32(const CT& c, int kx, int ky, int kz, i
     const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
     return map_find(c, pack_key(kx + di, ky + dj, kz + dk));
 }
-// The scan proper, given the probe results.  With MARGIN it also returns, squared and with 1e-6 relative slack, how
-// far the point may move before the answer has to be searched again: if it moves by delta, the neighbour found is
-// at most d_best + delta away and every other candidate at least d_other - delta, so while 2 delta < d_other - d_best
-// the neighbour is unchanged and strictly closest (no tie rule applies).  d_other bounds ALL other candidates of the
-// 27 voxels: those examined and the voxels dropped by their box distance - provided the point stays in its voxel
-// (same candidate set), which the caller checks.
-template <int PC, bool MARGIN, class CT>
+// The scan proper, given the probe results.  First round: the point's own voxel together with `lastv`, the voxel
+// (lane index 0..26) that held the winner the last time this point was searched - between two Gauss-Newton iterations
+// the point moves by a fraction of a voxel, so the nearest neighbour is nearly always in one of the two and the bound
+// they give drops every other voxel: one memory round trip on the dependent chain instead of two or three.  The
+// result does not depend on the order voxels are looked at: candidates compare by (distance, visiting order), and a
+// voxel is dropped only when its box lies strictly farther than a distance already found.
+template <int PC, class CT>
 __device__ __forceinline__ bool nn_scan32(const CT& c, V3 s, int kx, int ky, int kz, int pb, int lane32, int gbase,
-                                          V3& best, double& best_d2, double& margin2) {
+                                          V3& best, double& best_d2, int& lastv) {
     const int P = (PC > 0) ? PC : c.P;  // compile-time for the default 20: y / z become immediate offsets of x
     const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
     const int cnt0 = (pb < 0) ? 0 : (int)((unsigned)pb >> 24);
     double bd = 1.7976931348623157e308;
-    double sec = 1.7976931348623157e308;  // MARGIN: lower bound (squared) on this lane's candidates other than its best
     unsigned border = 0xFFFFFFFFu;  // visiting order of a candidate: voxel lane * 32 + slot
     V3 bp = v3(0, 0, 0);
-    bool keep = lane32 != 13 && cnt0 > 0;
+    const int lv = (lastv != 13) ? lastv : -1;  // uniform over the group; -1: none
+    bool keep = lane32 != 13 && lane32 != lv && cnt0 > 0;
     const int pbc = __shfl(pb, gbase + 13);
-    if (pbc >= 0) {  // uniform over the group (a stored voxel holds at least one point)
-        if (lane32 < (int)((unsigned)pbc >> 24)) {
-            const double* X = blk_x(c, pbc & BLK_ID_MASK);
-            const double qx = X[lane32], qy = X[P + lane32], qz = X[2 * P + lane32];
-            const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+    const int pbl = (lv >= 0) ? __shfl(pb, gbase + lv) : -1;
+    if (pbc >= 0 || pbl >= 0) {  // uniform over the group (a stored voxel holds at least one point)
+        const bool ac = pbc >= 0 && lane32 < (int)((unsigned)pbc >> 24), al = pbl >= 0 && lane32 < (int)((unsigned)pbl >> 24);
+        double cx = 0.0, cy = 0.0, cz = 0.0, lx = 0.0, ly = 0.0, lz = 0.0;
+        if (ac) { const double* X = blk_x(c, pbc & BLK_ID_MASK); cx = X[lane32]; cy = X[P + lane32]; cz = X[2 * P + lane32]; }
+        if (al) { const double* X = blk_x(c, pbl & BLK_ID_MASK); lx = X[lane32]; ly = X[P + lane32]; lz = X[2 * P + lane32]; }
+        if (ac) {
+            const double dx = cx - s.x, dy = cy - s.y, dz = cz - s.z;
             bd = dx * dx + dy * dy + dz * dz;
             border = 13u * 32u + (unsigned)lane32;
-            bp = v3(qx, qy, qz);
+            bp = v3(cx, cy, cz);
+        }
+        if (al) {
+            const double dx = lx - s.x, dy = ly - s.y, dz = lz - s.z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            const unsigned id = (unsigned)(lv * 32 + lane32);
+            if (d2 < bd || (d2 == bd && id < border)) { bd = d2; border = id; bp = v3(lx, ly, lz); }
         }
         // distance from the point to this lane's voxel box.  Under truncation toward zero index 0 spans (-vs, vs),
         // v > 0 spans [v vs, (v+1) vs), v < 0 spans ((v-1) vs, v vs]; 1 nm of slack covers the rounding of x / vs
@@ -621,10 +643,7 @@ __device__ __forceinline__ bool nn_scan32(const CT& c, V3 s, int kx, int ky, int
             gap2 += g * g;
         }
         const double m = group_min32(bd);
-        if (keep && gap2 > m) {  // a dropped voxel: every point in it is at least this far
-            keep = false;
-            if (MARGIN) sec = gap2;
-        }
+        if (keep && gap2 > m) keep = false;  // a dropped voxel: every point in it is at least this far
     }
     unsigned todo = (unsigned)(__ballot(keep) >> gbase);  // this group's surviving voxels, visited in ascending order
     while (todo) {
@@ -642,55 +661,46 @@ __device__ __forceinline__ bool nn_scan32(const CT& c, V3 s, int kx, int ky, int
             const double dx = q0x - s.x, dy = q0y - s.y, dz = q0z - s.z;
             const double d2 = dx * dx + dy * dy + dz * dz;
             const unsigned id = (unsigned)(v0 * 32 + lane32);
-            if (d2 < bd || (d2 == bd && id < border)) {
-                if (MARGIN) sec = fmin(sec, bd);
-                bd = d2; border = id; bp = v3(q0x, q0y, q0z);
-            } else if (MARGIN) sec = fmin(sec, d2);
+            if (d2 < bd || (d2 == bd && id < border)) { bd = d2; border = id; bp = v3(q0x, q0y, q0z); }
         }
         if (a1) {
             const double dx = q1x - s.x, dy = q1y - s.y, dz = q1z - s.z;
             const double d2 = dx * dx + dy * dy + dz * dz;
             const unsigned id = (unsigned)(v1 * 32 + lane32);
-            if (d2 < bd || (d2 == bd && id < border)) {
-                if (MARGIN) sec = fmin(sec, bd);
-                bd = d2; border = id; bp = v3(q1x, q1y, q1z);
-            } else if (MARGIN) sec = fmin(sec, d2);
+            if (d2 < bd || (d2 == bd && id < border)) { bd = d2; border = id; bp = v3(q1x, q1y, q1z); }
         }
     }
-    // lexicographic (d2, visiting order) minimum over the 32 lanes: the distance, then the order among the lanes
-    // that hold it, then the winner lane hands out its point
+    // lexicographic (d2, visiting order) minimum over the 32 lanes: the distance, then - only if two candidates are
+    // exactly equally far - the order among the lanes that hold it; the winner lane hands out its point
     const double m = group_min32(bd);
-    const unsigned bo = group_min32((bd == m) ? border : 0xFFFFFFFFu);
-    const bool found = bo != 0xFFFFFFFFu;
-    const bool winner = found && bd == m && border == bo;
-    const unsigned win = (unsigned)(__ballot(winner) >> gbase);
+    const bool found = m < 1.7976931348623157e308;  // some lane holds a candidate
+    unsigned win = (unsigned)(__ballot(bd == m) >> gbase);
+    if (found && (win & (win - 1u))) {
+        const unsigned bo = group_min32((bd == m) ? border : 0xFFFFFFFFu);
+        win = (unsigned)(__ballot(bd == m && border == bo) >> gbase);
+    }
     const int wl = gbase + (win ? __ffs(win) - 1 : 0);
     best = v3(__shfl(bp.x, wl), __shfl(bp.y, wl), __shfl(bp.z, wl));
     best_d2 = m;
-    if (MARGIN) {
-        double o2 = winner ? sec : fmin(sec, bd);  // the winner's own best is the answer itself
-        for (int o = 16; o > 0; o >>= 1) o2 = fmin(o2, __shfl_xor(o2, o));
-        margin2 = 0.0;
-        if (found) {
-            const double gapd = sqrt(o2) - sqrt(m);
-            if (gapd > 1e-6) margin2 = gapd * gapd * (1.0 - 1e-6);
-        }
-    }
+    lastv = found ? (int)((unsigned)__shfl((int)border, wl) >> 5) : -1;
     return found;
 }
-// probe (or reuse this lane's previous probe while the point has not left its voxel) + scan
+// probe (or reuse this lane's previous probe while the point has not left its voxel) + scan.  `lastv` (the winner's
+// voxel of the previous call, -1 = none) is meaningful only together with the cached probes: it is dropped when the
+// point changes voxel, and callers that cannot carry it per point pass -1.
 template <int PC, class CT>
 __device__ __forceinline__ bool nn_search32(const CT& c, V3 s, int lane32, int gbase, V3& best, double& best_d2,
-                                            int& ncand, unsigned long long& ck, int& cblk, bool use_cache) {
+                                            int& ncand, unsigned long long& ck, int& cblk, bool use_cache, int& lastv) {
     const double inv_vs = 1.0 / c.vs;   // loop-invariant
     const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
     const unsigned long long key = pack_key(kx, ky, kz);
-    const int pb = (use_cache && key == ck) ? cblk : nn_probe32(c, kx, ky, kz, lane32);
+    const bool hit = use_cache && key == ck;
+    const int pb = hit ? cblk : nn_probe32(c, kx, ky, kz, lane32);
+    if (!hit) lastv = -1;
     ck = key;
     cblk = pb;
     ncand += (pb < 0) ? 0 : (int)((unsigned)pb >> 24);
-    double unused;
-    return nn_scan32<PC, false>(c, s, kx, ky, kz, pb, lane32, gbase, best, best_d2, unused);
+    return nn_scan32<PC>(c, s, kx, ky, kz, pb, lane32, gbase, best, best_d2, lastv);
 }
 
 // column `idx` of the 3x7 matrix [ I | -hat(s) | r ]: the Jacobian J = [I | -hat(s)] of Registration.cpp
@@ -939,7 +949,8 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         }
         return;
     }
-    const double max_dist = st->gn_max_dist, kern = st->gn_kernel, k2 = kern * kern;
+    const double kern = st->gn_kernel, k2 = kern * kern;
+    const double gate2 = sqrt_gate(st->gn_max_dist);  // sqrt(d2) < max_dist  <=>  d2 < gate2
     const int max_iter = (mode == 1) ? 1 : c.max_iter;
     // which of the 27 sums this lane owns
     int ia = 0, ib = 0;
@@ -962,7 +973,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     // one point per 32-lane group for the whole loop => its probe results can be cached across iterations
     const bool single_pass = ((G & 7) == 0) ? (((n + 7) >> 3) <= (G >> 3) * NG) : (n <= G * NG);  // (also true when the leaders idle)
     unsigned long long ckey = EMPTY_KEY;
-    int cblk = -1;
+    int cblk = -1, lastv = -1;
     for (int it = 0; it < max_iter; ++it) {
         const long long c0 = GN_CLK();
         // T_icp <- e T_icp for the previous iteration's increment, off the serial tail: one lane of the second
@@ -1001,12 +1012,13 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
                 cblk = (it > 0) ? c.pc_pb[32 * (size_t)i + lane32] : -1;
                 key_before = ckey;
             }
-            const bool found = nn_search32<PC>(c, s, lane32, gbase, t, d2, ncand, ckey, cblk, (single_pass || MC) && it > 0);
+            if (!single_pass) lastv = -1;  // (several points per group: not carried per point)
+            const bool found = nn_search32<PC>(c, s, lane32, gbase, t, d2, ncand, ckey, cblk, (single_pass || MC) && it > 0, lastv);
             if (MC && !single_pass && ckey != key_before) {
                 c.pc_pb[32 * (size_t)i + lane32] = cblk;
                 if (lane32 == 0) c.pc_key[i] = ckey;
             }
-            if (found && sqrt(d2) < max_dist) {  // uniform over the group
+            if (found && d2 < gate2) {  // uniform over the group
                 const V3 r = v3(s.x - t.x, s.y - t.y, s.z - t.z);
                 const double den = kern + (r.x * r.x + r.y * r.y + r.z * r.z);
                 const double w = k2 / (den * den);
@@ -1532,7 +1544,8 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
                 default: c = b.q[7]; break;
             }
             const int n = c.st->n_src;
-            const double max_dist = c.st->gn_max_dist, kern = c.st->gn_kernel, k2 = kern * kern;
+            const double kern = c.st->gn_kernel, k2 = kern * kern;
+            const double gate2 = sqrt_gate(c.st->gn_max_dist);
             double acc = 0.0;
             int ncand = 0;
             Rt E;
@@ -1547,8 +1560,9 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const Se
                 if (lane32 == 0) { c.src_cur[3 * (size_t)i] = sp.x; c.src_cur[3 * (size_t)i + 1] = sp.y; c.src_cur[3 * (size_t)i + 2] = sp.z; }
                 V3 t;
                 double d2;
-                const bool found = nn_search32<PC>(c, sp, lane32, gbase, t, d2, ncand, ckey, cblk, false);
-                if (found && sqrt(d2) < max_dist) {
+                int lastv = -1;
+                const bool found = nn_search32<PC>(c, sp, lane32, gbase, t, d2, ncand, ckey, cblk, false, lastv);
+                if (found && d2 < gate2) {
                     const V3 r = v3(sp.x - t.x, sp.y - t.y, sp.z - t.z);
                     const double den = kern + (r.x * r.x + r.y * r.y + r.z * r.z);
                     const double w = k2 / (den * den);
