@@ -1007,16 +1007,23 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             // during the loop, so a row stays valid while the point keeps its voxel) - a coalesced read instead of 27
             // dependent random reads of the hash table per point and iteration
             unsigned long long key_before = EMPTY_KEY;
+            int lastv_before = -1;
+            if (!single_pass) lastv = -1;  // several points per group: carried per point in the probe row, if there is one
             if (MC && !single_pass) {
                 ckey = (it > 0) ? c.pc_key[i] : EMPTY_KEY;
                 cblk = (it > 0) ? c.pc_pb[32 * (size_t)i + lane32] : -1;
+                if (it > 0) lastv = c.pc_pb[32 * (size_t)i + 27];  // entry 27 of the row (no voxel) holds the winner's voxel
+                if (lane32 == 27) cblk = -1;
                 key_before = ckey;
+                lastv_before = lastv;
             }
-            if (!single_pass) lastv = -1;  // (several points per group: not carried per point)
             const bool found = nn_search32<PC>(c, s, lane32, gbase, t, d2, ncand, ckey, cblk, (single_pass || MC) && it > 0, lastv);
-            if (MC && !single_pass && ckey != key_before) {
-                c.pc_pb[32 * (size_t)i + lane32] = cblk;
-                if (lane32 == 0) c.pc_key[i] = ckey;
+            if (MC && !single_pass) {
+                if (ckey != key_before) {
+                    c.pc_pb[32 * (size_t)i + lane32] = cblk;
+                    if (lane32 == 0) c.pc_key[i] = ckey;
+                }
+                if (lane32 == 27 && (lastv != lastv_before || ckey != key_before)) c.pc_pb[32 * (size_t)i + 27] = lastv;
             }
             if (found && d2 < gate2) {  // uniform over the group
                 const V3 r = v3(s.x - t.x, s.y - t.y, s.z - t.z);
