@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/trace_x
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_x -o kt -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2> $R/gpurun_out/trace_x.err
+cd $R && python tools_gaps.py gpurun_out/trace_x
+find gpurun_out/trace_x -type f -size +30M -delete
