@@ -928,11 +928,12 @@ template <int PC, bool MC>
 __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     __shared__ double red[GN_MAX_GROUPS][32];
     __shared__ double tot[32];
-    __shared__ double Esh[12];
+    __shared__ double Esh2[2][12];  // the increment of iteration i lives in buffer i & 1 (the guess in buffer 1): the solver
+                                    // of iteration i + 1 writes the other one, so nobody has to wait before it may
     __shared__ double Tsh[12];
     __shared__ double scur[GN_MAX_GROUPS][4];
     __shared__ double redL[64][32];  // a leader's member rows (G <= 512)
-    __shared__ int flag_done;
+    __shared__ int flag_done2[2];   // likewise
     DevState* st = c.st;
     const int tid = threadIdx.x, lane32 = tid & 31, grp = tid >> 5, gbase = (tid & 63) & 32;
     const int NG = blockDim.x >> 5;
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     }
     if (tid < 12) {
         Rt g = (mode != 1) ? rt_from16(guess_src(c)) : rt_identity();
-        Esh[tid] = (tid < 9) ? g.R[tid] : g.t[tid - 9];
+        Esh2[1][tid] = (tid < 9) ? g.R[tid] : g.t[tid - 9];
         Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
     }
     __syncthreads();
@@ -978,6 +979,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         const long long c0 = GN_CLK();
         // T_icp <- e T_icp for the previous iteration's increment, off the serial tail: one lane of the second
         // wavefront does it while everybody searches (Esh is not rewritten before the next solve)
+        const double* Esh = Esh2[(it + 1) & 1];  // what the previous iteration (or the prologue) left
         if (tid == 64 && it > 0) gn_compose(Esh, Tsh);
         double acc = 0.0;
         int ncand = 0;
@@ -1149,20 +1151,19 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             if (mine && even) tot[tid >> 1] = t;
             if (!ok && tid == 0) atomicOr(&st->err_flags, ERR_GN_TIMEOUT);
         }
-        __syncthreads();
-        const long long c3 = GN_CLK();
-
-        const long long c4 = GN_CLK();
-        if (tid < 64) {  // one wavefront; every lane ends up with the same dx, lane 0 publishes
-            double dx[6];
+        long long c3 = 0, c4 = 0;
+        if (tid < 64) {  // the wavefront that collected the totals solves: its own LDS writes are ordered before its reads,
+            c3 = c4 = GN_CLK();  // so no workgroup barrier stands between the last arrival and the factorisation
+            __builtin_amdgcn_wave_barrier();
+            double dx[6];        // every lane ends up with the same dx, lane 0 publishes
             solve6_ldlt_wave(tot, tid, dx);
           if (tid == 0) {
             const Rt e = se3_exp_gn(dx);
-            for (int k = 0; k < 9; ++k) Esh[k] = e.R[k];
-            for (int k = 0; k < 3; ++k) Esh[9 + k] = e.t[k];
+            for (int k = 0; k < 9; ++k) Esh2[it & 1][k] = e.R[k];
+            for (int k = 0; k < 3; ++k) Esh2[it & 1][9 + k] = e.t[k];
             double nn = 0.0;
             for (int k = 0; k < 6; ++k) nn += dx[k] * dx[k];
-            flag_done = (sqrt(nn) < c.conv) ? 1 : 0;
+            flag_done2[it & 1] = (sqrt(nn) < c.conv) ? 1 : 0;
           }
         }
         __syncthreads();
@@ -1171,12 +1172,11 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         ph_wait += c1b - c1;
         if (tid == 0) cand_total_sh += (long long)tot[28];
         iters = it + 1;
-        const int done = flag_done;
+        const int done = flag_done2[it & 1];
         if (mode == 1 && wg == 0 && tid < 29) st->dbg_sums[tid] = tot[tid];
-        __syncthreads();
         if (done) break;
     }
-    if (tid == 64 && iters > 0) gn_compose(Esh, Tsh);  // the last increment
+    if (tid == 64 && iters > 0) gn_compose(Esh2[(iters - 1) & 1], Tsh);  // the last increment
     __syncthreads();
     if (tid == 0 && c.wg_clk) { c.wg_clk[wg] += ph[0] + ph_wait; c.wg_clk[G + wg] += ph[0]; }  // diagnostic: search phase per workgroup
     if (wg == 0 && tid == 0) {
