@@ -968,7 +968,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     }
     __syncthreads();
     __shared__ long long cand_total_sh;  // (kept out of the registers: only workgroup 0 reads it, after the loop)
-    if (tid == 0) cand_total_sh = 0;
+    if (tid == (int)blockDim.x - 1) cand_total_sh = 0;
     int iters = 0;
     long long ph[5] = {0, 0, 0, 0, 0}, ph_wait = 0, ph_x1 = 0, ph_x2 = 0;
     // one point per 32-lane group for the whole loop => its probe results can be cached across iterations
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         const long long c5 = GN_CLK();
         ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
         ph_wait += c1b - c1;
-        if (tid == 0) cand_total_sh += (long long)tot[28];
+        if (tid == (int)blockDim.x - 1) cand_total_sh += (long long)tot[28];  // (a lane of the last wavefront: off the serial path)
         iters = it + 1;
         const int done = flag_done2[it & 1];
         if (mode == 1 && wg == 0 && tid < 29) st->dbg_sums[tid] = tot[tid];
