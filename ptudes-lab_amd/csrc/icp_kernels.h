@@ -952,6 +952,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     }
     const double kern = st->gn_kernel, k2 = kern * kern;
     const double gate2 = sqrt_gate(st->gn_max_dist);  // sqrt(d2) < max_dist  <=>  d2 < gate2
+    const double conv2 = sqrt_gate(c.conv);           // likewise for the convergence test on |dx|
     const int max_iter = (mode == 1) ? 1 : c.max_iter;
     // which of the 27 sums this lane owns
     int ia = 0, ib = 0;
@@ -1163,7 +1164,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             for (int k = 0; k < 3; ++k) Esh2[it & 1][9 + k] = e.t[k];
             double nn = 0.0;
             for (int k = 0; k < 6; ++k) nn += dx[k] * dx[k];
-            flag_done2[it & 1] = (sqrt(nn) < c.conv) ? 1 : 0;
+            flag_done2[it & 1] = (nn < conv2) ? 1 : 0;  // sqrt(nn) < conv, without the square root on the serial path
           }
         }
         __syncthreads();
