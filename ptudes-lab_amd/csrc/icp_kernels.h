@@ -963,8 +963,11 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         if (lane32 >= 21) { ia = lane32 - 21; ib = 6; }
     }
     if (tid < 12) {
-        Rt g = (mode != 1) ? rt_from16(guess_src(c)) : rt_identity();
-        Esh2[1][tid] = (tid < 9) ? g.R[tid] : g.t[tid - 9];
+        // element tid of [R | t] of the guess, read straight from the 4x4 (indexing a local copy by tid would put it, and
+        // with it the whole kernel, on scratch memory)
+        double gv = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
+        if (mode != 1) { const double* g16 = guess_src(c); gv = (tid < 9) ? g16[4 * (tid / 3) + (tid % 3)] : g16[4 * (tid - 9) + 3]; }
+        Esh2[1][tid] = gv;
         Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
     }
     __syncthreads();
