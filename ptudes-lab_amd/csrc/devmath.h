@@ -88,20 +88,24 @@ PTL_HD void quat_to_R(const double q[4], double R[9]) {
     R[3] = 2.0 * (x * y + z * w); R[4] = -xx + yy - zz + ww; R[5] = 2.0 * (y * z - x * w);
     R[6] = 2.0 * (x * z - y * w); R[7] = 2.0 * (y * z + x * w); R[8] = -xx - yy + zz + ww;
 }
+// scipy's Rotation.from_matrix(...).as_quat(): the largest of the diagonal entries and the trace picks the formula.
+// Written out per case with constant indices (the compact form with i, j, k = c, c+1, c+2 mod 3 indexes R and q by
+// run-time values, which puts both on scratch memory - in the EKF's per-sample mechanisation); same sums, same order.
 PTL_HD void R_to_quat(const double R[9], double q[4]) {
     const double tr = R[0] + R[4] + R[8];
-    double d[4] = {R[0], R[4], R[8], tr};
     int c = 0;
-    for (int i = 1; i < 4; ++i)
-        if (d[i] > d[c]) c = i;
+    double best = R[0];
+    if (R[4] > best) { c = 1; best = R[4]; }
+    if (R[8] > best) { c = 2; best = R[8]; }
+    if (tr > best) c = 3;
     if (c == 3) {
         q[0] = R[7] - R[5]; q[1] = R[2] - R[6]; q[2] = R[3] - R[1]; q[3] = 1.0 + tr;
+    } else if (c == 0) {
+        q[0] = 1.0 - tr + 2.0 * R[0]; q[1] = R[3] + R[1]; q[2] = R[6] + R[2]; q[3] = R[7] - R[5];
+    } else if (c == 1) {
+        q[1] = 1.0 - tr + 2.0 * R[4]; q[2] = R[7] + R[5]; q[0] = R[1] + R[3]; q[3] = R[2] - R[6];
     } else {
-        const int i = c, j = (c + 1) % 3, k = (c + 2) % 3;
-        q[i] = 1.0 - tr + 2.0 * R[4 * i];
-        q[j] = R[3 * j + i] + R[3 * i + j];
-        q[k] = R[3 * k + i] + R[3 * i + k];
-        q[3] = R[3 * k + j] - R[3 * j + k];
+        q[2] = 1.0 - tr + 2.0 * R[8]; q[0] = R[2] + R[6]; q[1] = R[5] + R[7]; q[3] = R[3] - R[1];
     }
     const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
