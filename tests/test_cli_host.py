@@ -69,3 +69,30 @@ def test_library_exports_every_declared_symbol():
             core.Icp(70.0, 1.0)
         with pytest.raises(RuntimeError):
             core.Ekf()
+
+
+def test_squared_gate_is_equivalent_to_the_square_root_test():
+    """The GN kernel replaces `sqrt(d2) < M` (correspondence gate, convergence test) by `d2 < T` with
+    T = min{x : sqrt(x) >= M} (icp_kernels.h sqrt_gate): the construction, restated with numpy, agrees with the square
+    root for every double around the threshold - sqrt is correctly rounded and monotone."""
+    rng = np.random.default_rng(5)
+
+    def gate(M):
+        T = np.float64(M) * np.float64(M)
+        while np.sqrt(np.nextafter(T, 0.0)) >= M:
+            T = np.nextafter(T, 0.0)
+        while np.sqrt(T) < M:
+            T = np.nextafter(T, np.inf)
+        return T
+
+    for M in list(rng.uniform(1e-6, 300.0, 200)) + [1e-4, 6.0, 3 * 2.0, 0.1, 2.1 * 3]:
+        M = np.float64(M)
+        T = gate(M)
+        x = T
+        for _ in range(40):  # 40 doubles below T ...
+            x = np.nextafter(x, 0.0)
+            assert np.sqrt(x) < M and x < T
+        x = T
+        for _ in range(40):  # ... and T and 39 above
+            assert not (np.sqrt(x) < M) and not (x < T)
+            x = np.nextafter(x, np.inf)
