@@ -57,11 +57,11 @@ def sim_imu(acc_mean=np.zeros(3), acc_std=1.5, acc_noise_std=0.4, acc_bias=np.ar
 
 
 @click.command(name="sim")
-@click.option("-t", "--duration", type=float, default=2.0, help="Time to generate IMUs measurements (seconds, default 2.0)")
-@click.option("-f", "--freq", type=float, default=100.0, help="IMU frequency")
-@click.option("--corr-t", type=float, default=0.1, help="Pose correction time interval to EKF (seconds, default 0.1)")
-@click.option("--acc-noise-std", type=float, default=0.4, help="IMU accelerometer noise sigma")
-@click.option("--gyr-noise-std", type=float, default=0.4, help="IMU gyroscope noise sigma")
+@click.option("-t", "--duration", type=float, default=2.0, help="seconds of simulated IMU samples to run (default 2.0)")
+@click.option("-f", "--freq", type=float, default=100.0, help="IMU rate, Hz")
+@click.option("--corr-t", type=float, default=0.1, help="seconds between two pose corrections of the filter (default 0.1)")
+@click.option("--acc-noise-std", type=float, default=0.4, help="standard deviation of the accelerometer noise")
+@click.option("--gyr-noise-std", type=float, default=0.4, help="standard deviation of the gyroscope noise")
 def ptudes_ekf_sim(duration: float, corr_t: float, freq: float, acc_noise_std: float, gyr_noise_std: float) -> None:
     """EKF with simulated IMU measurements; the noise-free filter is the ground truth for pose corrections."""
     print("Using sim IMUs with params:")
@@ -96,17 +96,17 @@ def ptudes_ekf_sim(duration: float, corr_t: float, freq: float, acc_noise_std: f
 @click.command(name="nc")
 @click.argument("file", required=True, type=click.Path(exists=True))
 @click.option("-m", "--meta", required=False, type=click.Path(exists=True, dir_okay=False, readable=True),
-              help="Metadata for BAG, required if automatic metadata resolution fails")
+              help="sensor metadata .json of the BAG (unused by this command, kept for the option set)")
 @click.option("-g", "--gt-file", required=True, type=click.Path(exists=True, dir_okay=False, readable=True),
-              help="Ground truth file with poses to compare and correct poses")
+              help="Newer College ground-truth CSV: its poses correct the filter and are what the result is compared with")
 @click.option("-t", "--duration", type=float, default=0.0,
-              help="Time duration of the data read/processed :(seconds, default 2.0)")
+              help="seconds of data to process; 0 = to the end of the bag")
 @click.option("--start-ts", type=float, default=0.0,
-              help="Start time (relative to the beginning of the data) (seconds, default 0.0)")
+              help="seconds to skip from the first IMU sample (default 0.0)")
 @click.option("-p", "--plot", required=False, type=str, help="Plotting option [graphs, point_viz] (not provided here)")
-@click.option("--xy-plot", is_flag=True, help="Draw X and Y dimenstions on XY plane, instead of separate")
+@click.option("--xy-plot", is_flag=True, help="(plots are not provided; accepted for the option set)")
 @click.option("-i", "--imu-topic", required=False, default="/os_node/imu_packets", type=str,
-              help="Imu topic name to use (msg/Imu or imu_packets)")
+              help="IMU topic: a sensor_msgs/Imu topic or an Ouster imu_packets topic")
 def ptudes_ekf_nc(file: str, meta: Optional[str] = None, gt_file: Optional[str] = None, duration: float = 2.0,
                   start_ts: float = 0.0, plot: Optional[str] = None, xy_plot: bool = False,
                   imu_topic: Optional[str] = None) -> None:
@@ -116,53 +116,54 @@ def ptudes_ekf_nc(file: str, meta: Optional[str] = None, gt_file: Optional[str] 
     """
     from .. import bag  # IMUBagSource looked up at call time, as the reference imports it inside the command (:235)
 
-    init_grav = GRAV * UP
-    # the Ouster IMU and the alphasense IMU have different nav frames (reference :236-239)
-    if imu_topic in ["/os_cloud_node/imu", "/os_node/imu_packets"]:
-        init_grav = GRAV * DOWN
+    # the Ouster IMU's nav frame has gravity along -Z, the alphasense IMU's along +Z (reference :236-239)
+    ouster_frame = imu_topic in ("/os_cloud_node/imu", "/os_node/imu_packets")
+    init_grav = GRAV * (DOWN if ouster_frame else UP)
     print("init_grav = ", init_grav)
     print("Reading NC dataset:")
     print(f"  file: {file}")
     print(f"  topic: {imu_topic}")
     print(f"  gt file: {gt_file}")
-    imu_source = bag.IMUBagSource(file, imu_topic=imu_topic)
+    source = bag.IMUBagSource(file, imu_topic=imu_topic)
     if not gt_file:
         print("need gt now")
         return
-    gts = read_newer_college_gt(gt_file)
-    pose_corr_idx = 0
-    gt_pose0 = np.linalg.inv(gts[pose_corr_idx][1])
+    gt_rows = read_newer_college_gt(gt_file)
+    gt_stamp = [row[0] for row in gt_rows]
+    last_row = len(gt_rows) - 1
     print("Running EKF ... \n")
     ekf = ESEKF(init_grav=init_grav, _logging=bool(plot))
-    gt_poses, res_poses = [], []
-    gt0_initialized = False
-    ts, first_ts = 0, -1
-    for imu in imu_source:
+    corrections, estimates = [], []
+    row = 0          # GT row that corrects the filter next
+    origin = None    # inverse of the GT pose everything is expressed relative to
+    ts, t_first = 0, -1
+    for imu in source:
         ts = imu.ts
-        if first_ts < 0:
-            first_ts = ts
-        if ts - first_ts < start_ts:  # skipping till the beginning (--start-ts)
+        if t_first < 0:
+            t_first = ts
+        elapsed = ts - t_first - start_ts
+        if ts - t_first < start_ts:  # --start-ts: not there yet
             continue
-        if not gt0_initialized:
-            while pose_corr_idx < len(gts) and ts >= gts[pose_corr_idx][0]:
-                pose_corr_idx += 1
-            gt_pose0 = np.linalg.inv(gts[pose_corr_idx][1])
-            gt0_initialized = True
+        if origin is None:
+            # the first GT row newer than the first sample that is processed (reference :283-287; a stream that starts
+            # past the last row fails here, as it does there)
+            while row < len(gt_rows) and ts >= gt_stamp[row]:
+                row += 1
+            origin = np.linalg.inv(gt_rows[row][1])
         ekf.processImu(imu)
-        if ts >= gts[pose_corr_idx][0]:
-            pose_corr = gt_pose0 @ gts[pose_corr_idx][1]
-            ekf.processPose(pose_corr)
-            gt_poses.append(pose_corr)
-            res_poses.append(ekf.nav.pose_mat())
-            # past the last GT row the index stays, and every further IMU is followed by a correction with that row
-            if pose_corr_idx + 1 < len(gts):
-                pose_corr_idx += 1
-        if duration > 0 and ts - first_ts - start_ts > duration:
+        if ts >= gt_stamp[row]:
+            target = origin @ gt_rows[row][1]
+            ekf.processPose(target)
+            corrections.append(target)
+            estimates.append(ekf.nav.pose_mat())
+            # past the last GT row the index stays: every further IMU sample is followed by a correction with that row
+            row = min(row + 1, last_row)
+        if duration > 0 and elapsed > duration:
             break
-    print(f"scanned duration: {ts - first_ts - start_ts:0.04} s")
-    print(f"updates num: {len(res_poses)}\n")
-    if res_poses:
-        ate_rot, ate_trans = calc_ate(res_poses, gt_poses)
+    print(f"scanned duration: {ts - t_first - start_ts:0.04} s")
+    print(f"updates num: {len(estimates)}\n")
+    if estimates:
+        ate_rot, ate_trans = calc_ate(estimates, corrections)
         print(f"ATE_rot:   {ate_rot:.04f} deg")
         print(f"ATE trans: {ate_trans:.04f} m")
     if plot:
@@ -181,20 +182,20 @@ def _synthetic_source(seed: int, n_scans: int):
 @click.command(name="ouster")
 @click.argument("file", required=False, type=click.Path())
 @click.option("-m", "--meta", required=False, type=click.Path(exists=True, dir_okay=False, readable=True),
-              help="Metadata for PCAP/BAG, required if automatic metadata resolution fails")
-@click.option("--start-scan", type=int, default=0, help="Start scan number")
-@click.option("--end-scan", type=int, help="End scan number, inclusive")
+              help="sensor metadata .json of the PCAP / BAG (needed when it is not found next to FILE)")
+@click.option("--start-scan", type=int, default=0, help="first scan to use (0-based)")
+@click.option("--end-scan", type=int, help="last scan to use (inclusive)")
 @click.option("--use-imu-prediction", is_flag=True,
-              help="Use EKF IMU pose prediction for KissICP register frame, i.e. lously coupled Lidar Inertial Odometry")
+              help="hand the filter's predicted pose to KissICP as initial guess (loosely coupled lidar-inertial odometry)")
 @click.option("-g", "--gt-file", required=False, type=click.Path(exists=True, dir_okay=False, readable=True),
-              help="Ground truth file with poses to compare (Newer College format)")
-@click.option("--kiss-min-range", type=float, default=1, help="KissICP min range param in m (default 1)")
-@click.option("--kiss-max-range", type=float, default=70, help="KissICP max range param in m (default 70)")
-@click.option("--beams", type=int, default=0, help="Active beams number in a lidar scan")
+              help="Newer College ground-truth CSV to compare the result with")
+@click.option("--kiss-min-range", type=float, default=1, help="KissICP: shortest range kept, metres (default 1)")
+@click.option("--kiss-max-range", type=float, default=70, help="KissICP: longest range kept, metres (default 70)")
+@click.option("--beams", type=int, default=0, help="keep only NUM evenly spaced beams (rows) of every scan; 0 = all")
 @click.option("--save-kitti-poses", required=False, type=click.Path(exists=False, dir_okay=False),
-              help="Save resulting poses to the file (in kitti format)")
+              help="write the resulting poses to this file, KITTI format")
 @click.option("--save-nc-gt-poses", required=False, type=click.Path(exists=False, dir_okay=False),
-              help="Save resulting poses to the file (in NC ground truth format)")
+              help="write the resulting poses to this file, Newer College ground-truth format")
 @click.option("--synthetic", type=int, default=None,
               help="Run on the synthetic 128x1024 sequence with this seed instead of FILE (no ouster-sdk needed)")
 def ptudes_ekf_ouster(file: Optional[str], meta: Optional[str], start_scan: int, end_scan: Optional[int],

@@ -14,24 +14,23 @@ from ..ins.data import IMU, StreamStatsTracker
 @click.command(name="stat")
 @click.argument("file", required=False, type=click.Path())
 @click.option("-m", "--meta", required=False, type=click.Path(exists=True, dir_okay=False, readable=True),
-              help="Metadata for PCAP/BAG, required if automatic metadata resolution fails")
-@click.option("--start-scan", type=int, default=0, help="Start scan number")
-@click.option("--end-scan", type=int, help="End scan number, inclusive")
+              help="sensor metadata .json of the PCAP / BAG (needed when it is not found next to FILE)")
+@click.option("--start-scan", type=int, default=0, help="first scan to use (0-based)")
+@click.option("--end-scan", type=int, help="last scan to use (inclusive)")
 @click.option("--beams", type=int, default=0,
-              help="Active beams number in a lidar scan (i.e. reduces beams (i.e. active rows of a scan) to the NUM)")
+              help="keep only NUM evenly spaced beams (rows) of every scan; 0 = all")
 @click.option("-t", "--duration", type=float, default=3.0,
-              help="Time period of the data (imu/scan) to read in seconds. (default: 3.0, use 0 to read and stats all data source)")
-@click.option("--kiss-run", is_flag=True, help="KissICP vanilla wrapper run (for time profiling)")
-@click.option("--kiss-min-range", type=float, default=1, help="KissICP min range param in m (default 1)")
-@click.option("--kiss-max-range", type=float, default=70, help="KissICP max range param in m (default 70)")
+              help="seconds of data (IMU / scans) to take into the statistics; 0 = the whole source (default 3.0)")
+@click.option("--kiss-run", is_flag=True, help="also register every scan with KissICP (timing runs)")
+@click.option("--kiss-min-range", type=float, default=1, help="KissICP: shortest range kept, metres (default 1)")
+@click.option("--kiss-max-range", type=float, default=70, help="KissICP: longest range kept, metres (default 70)")
 @click.option("--synthetic", type=int, default=None,
               help="Run on the synthetic 128x1024 sequence with this seed instead of FILE (no ouster-sdk needed)")
 def ptudes_stat(file: Optional[str], meta: Optional[str], start_scan: int = 0, end_scan: Optional[int] = None,
                 beams: int = 0, duration: float = 3, kiss_run: bool = False, kiss_min_range: float = 1.0,
                 kiss_max_range: float = 70, synthetic: Optional[int] = None) -> None:
-    """Ouster BAGS/PCAP data source stats
-
-    Calculates scans range and imu acc/gyr statistics for --duration seconds."""
+    """Range and IMU statistics of a data source (mean / std of the scans' ranges, of accelerometer and gyroscope
+    samples) over --duration seconds, plus the gravity direction the accelerometer mean suggests."""
     if synthetic is None:
         raise click.ClickException("reading .pcap/.bag needs ouster-sdk, which is not installed; "
                                    "use --synthetic SEED to run the same command on a synthetic sequence")

@@ -22,49 +22,48 @@ def _ouster_sdk():
 
 
 class OusterLidarData:
-    """Lidar data source: LidarScan + IMUs iterator with scan index"""
+    """Scans and IMU samples of an Ouster packet stream, each tagged with the index of the scan it belongs to."""
 
     def __init__(self, source, *, fields=None, _sdk=None) -> None:
-        self._source = source
-        self._fields = fields if fields is not None else self._source.metadata.format.udp_profile_lidar
-        self._sdk = _sdk
-        self._scan_idx = 0
+        self._source, self._sdk = source, _sdk
+        self._fields = source.metadata.format.udp_profile_lidar if fields is None else fields
 
     def withScanIdx(self, *, start_scan: int = 0, end_scan: Optional[int] = None) -> Iterator[Tuple[int, object]]:
-        """Make an iterator with (scanIdx, scan/imu)  (reference data.py:31-77)"""
+        """(scan index, LidarScan | IMU) in packet order (reference data.py:31-77).  A scan is emitted when the batcher
+        closes it, i.e. on the first packet of the next frame; IMU samples carry the index of the scan being assembled;
+        nothing is emitted before `start_scan`; the stream stops after scan `end_scan`; a frame left open when the
+        packets run out is emitted as it is."""
         sdk = self._sdk or _ouster_sdk()
-        fmt = self._source.metadata.format
-        w, h, columns_per_packet = fmt.columns_per_frame, fmt.pixels_per_column, fmt.columns_per_packet
-        batch = sdk.ScanBatcher(w, sdk.PacketFormat.from_info(self._source.metadata))
-        ls_write = None
-        scan_idx = 0
-        for packet in self._source:
-            if isinstance(packet, sdk.LidarPacket):
-                if ls_write is None:
-                    ls_write = sdk.LidarScan(h, w, self._fields, columns_per_packet)
-                if batch(packet, ls_write):  # finished frame
-                    if scan_idx >= start_scan:
-                        yield scan_idx, ls_write
-                    scan_idx += 1
-                    if end_scan is not None and scan_idx > end_scan:
-                        return
-                    ls_write = None
-            elif isinstance(packet, sdk.ImuPacket):
-                if scan_idx >= start_scan:
-                    yield scan_idx, IMU.from_packet(packet)
-        if ls_write is not None:  # the stream ended inside a frame
-            yield scan_idx, ls_write
+        info = self._source.metadata
+        geometry = (info.format.pixels_per_column, info.format.columns_per_frame)
+        batcher = sdk.ScanBatcher(geometry[1], sdk.PacketFormat.from_info(info))
+        open_scan, index = None, 0
+        for pkt in self._source:
+            emit = index >= start_scan
+            if isinstance(pkt, sdk.ImuPacket):
+                if emit:
+                    yield index, IMU.from_packet(pkt)
+                continue
+            if not isinstance(pkt, sdk.LidarPacket):
+                continue
+            if open_scan is None:
+                open_scan = sdk.LidarScan(geometry[0], geometry[1], self._fields, info.format.columns_per_packet)
+            if not batcher(pkt, open_scan):
+                continue
+            if emit:
+                yield index, open_scan
+            open_scan, index = None, index + 1
+            if end_scan is not None and index > end_scan:
+                return
+        if open_scan is not None:
+            yield index, open_scan
 
     def __iter__(self):
-        """Make an iterator just data"""
-        for scan_idx, d in self.withScanIdx():
-            yield scan_idx, d
+        return self.withScanIdx()
 
     def close(self) -> None:
-        """Close the underlying PacketSource."""
         self._source.close()
 
     @property
     def metadata(self):
-        """Return metadata from the underlying PacketSource."""
         return self._source.metadata

@@ -151,47 +151,32 @@ class StreamStatsTracker:
     min / max come from the HIP reduction `ptl_range_stats`, the pooling formula is the reference's (:310-316)."""
 
     def __init__(self, use_beams_num: Optional[int] = None, metadata=None, device_id: int = 0):
-        self._metadata = metadata
-        self._device_id = device_id
-        self._mean = 0
-        self._scans_num = 0
-        self._points_num = 0
-        self._sigma_sq = 0
-        self._use_beams_num = use_beams_num
-        self._mean_acc = np.zeros(3)
-        self._mean_gyr = np.zeros(3)
-        self._sigman_acc = np.zeros(3)  # sigma^2 * n accumulators
-        self._sigman_gyr = np.zeros(3)
+        self._metadata, self._device_id, self._use_beams_num = metadata, device_id, use_beams_num
+        # ranges: pooled mean / variance over all valid returns seen so far, and their extremes
+        self._mean = self._sigma_sq = 0
+        self._min_range = self._max_range = 0
+        self._points_num = self._scans_num = 0
+        # IMU: running mean and sum of squared deviations per axis (rows: accelerometer, gyroscope)
+        self._imu_mean = np.zeros((2, 3))
+        self._imu_m2 = np.zeros((2, 3))
         self._imu_num = 0
-        self._max_ts = 0
-        self._min_ts = 0
-        self._min_range = 0
-        self._max_range = 0
+        self._t_span = None  # [first, last] timestamp of anything tracked
 
+    # mm -> m; the 15-bit low-data-rate profile stores ranges in units of 8 mm (:242-252)
     def _range_to_m(self) -> float:
-        coef = 0.001  # :242-252
-        md = self._metadata
-        if md is not None and str(getattr(getattr(md, "format", None), "udp_profile_lidar", "")).endswith("RNG15_RFL8_NIR8"):
-            coef = 8 * coef
-        return coef
+        profile = str(getattr(getattr(self._metadata, "format", None), "udp_profile_lidar", ""))
+        return 0.008 if profile.endswith("RNG15_RFL8_NIR8") else 0.001
 
-    def _track_min_max_ts(self, ts: float):  # :254-260
-        if not self._imu_num and not self._scans_num:
-            self._min_ts = ts
-            self._max_ts = ts
-        else:
-            self._min_ts = min(self._min_ts, ts)
-            self._max_ts = max(self._max_ts, ts)
+    def _stretch_span(self, ts: float):  # :254-260
+        self._t_span = [ts, ts] if self._t_span is None else [min(self._t_span[0], ts), max(self._t_span[1], ts)]
 
     def trackImu(self, imu: IMU):
-        """Update IMU mean / sigma (:266-282)"""
-        mean_acc_prev = self._mean_acc.copy()
-        mean_gyr_prev = self._mean_gyr.copy()
-        self._mean_acc += (imu.lacc - self._mean_acc) / (self._imu_num + 1)
-        self._sigman_acc += (imu.lacc - mean_acc_prev) * (imu.lacc - self._mean_acc)
-        self._mean_gyr += (imu.avel - self._mean_gyr) / (self._imu_num + 1)
-        self._sigman_gyr += (imu.avel - mean_gyr_prev) * (imu.avel - self._mean_gyr)
-        self._track_min_max_ts(imu.ts)
+        """Update IMU mean / sigma (:266-282): Welford's update, accelerometer and gyroscope side by side"""
+        x = np.stack([imu.lacc, imu.avel])
+        before = self._imu_mean.copy()
+        self._imu_mean += (x - self._imu_mean) / (self._imu_num + 1)
+        self._imu_m2 += (x - before) * (x - self._imu_mean)
+        self._stretch_span(imu.ts)
         self._imu_num += 1
 
     def trackScan(self, ls, last_valid_column_ts_ns: Optional[int] = None):
@@ -215,57 +200,39 @@ class StreamStatsTracker:
         n, m, v, lo, hi = int(out[0]), out[1], out[2], out[3], out[4]
         if n == 0:
             raise ValueError("scan has no valid returns")  # the reference divides by zero here
-        if not self._points_num:  # :262-264
-            self._min_range, self._max_range = lo, hi
-        else:
-            self._min_range, self._max_range = min(self._min_range, lo), max(self._max_range, hi)
-        s1 = 0 if not self._points_num else (self._points_num - 1) * self._sigma_sq
-        corr = self._points_num * n * np.square(self._mean - m) / ((self._points_num + n) * (self._points_num + n - 1))
-        self._sigma_sq = (s1 + n * v) / (self._points_num + n - 1) + corr
-        self._mean = (self._mean * self._points_num + m * n) / (self._points_num + n)
-        self._track_min_max_ts(last_valid_column_ts_ns * 1e-9)
+        seen = self._points_num
+        if seen:  # :262-264
+            lo, hi = min(self._min_range, lo), max(self._max_range, hi)
+        self._min_range, self._max_range = lo, hi
+        # pooled variance of two samples (:310-316): within-sample parts plus the term for the distance of the means
+        within = (seen - 1) * self._sigma_sq if seen else 0
+        between = seen * n * np.square(self._mean - m) / ((seen + n) * (seen + n - 1))
+        self._sigma_sq = (within + n * v) / (seen + n - 1) + between
+        self._mean = (self._mean * seen + m * n) / (seen + n)
+        self._stretch_span(last_valid_column_ts_ns * 1e-9)
         self._scans_num += 1
-        self._points_num += n
+        self._points_num = seen + n
 
-    @property
-    def range_mean(self) -> float:
-        return self._mean
+    range_mean = property(lambda self: self._mean)
+    range_std = property(lambda self: np.sqrt(self._sigma_sq))
+    acc_mean = property(lambda self: self._imu_mean[0])
+    gyr_mean = property(lambda self: self._imu_mean[1])
+    acc_std = property(lambda self: np.sqrt(self._imu_m2[0] / self._imu_num))
+    gyr_std = property(lambda self: np.sqrt(self._imu_m2[1] / self._imu_num))
+    dt = property(lambda self: 0 if self._t_span is None else self._t_span[1] - self._t_span[0])
 
-    @property
-    def range_std(self) -> float:
-        return np.sqrt(self._sigma_sq)
-
-    @property
-    def acc_mean(self) -> np.ndarray:
-        return self._mean_acc
-
-    @property
-    def acc_std(self) -> np.ndarray:
-        return np.sqrt(self._sigman_acc / self._imu_num)
-
-    @property
-    def gyr_mean(self) -> np.ndarray:
-        return self._mean_gyr
-
-    @property
-    def gyr_std(self) -> np.ndarray:
-        return np.sqrt(self._sigman_gyr / self._imu_num)
-
-    @property
-    def dt(self) -> float:
-        return self._max_ts - self._min_ts
-
-    def _formatted_str(self) -> str:  # :351-366
-        s3_min_range = max(self._min_range, self.range_mean - 3 * self.range_std)
-        s3_max_range = min(self._max_range, self.range_mean + 3 * self.range_std)
-        return (f"StreamStatsTracker[dt: {self.dt:.04f} s, imus: {self._imu_num}, scans: {self._scans_num}]:\n"
-                f"  range_mean: {self.range_mean:.03f} m,\n"
-                f"  range_std: {self.range_std:.03f} m (s3 span: [{s3_min_range:.03f} - {s3_max_range:.03f} m])\n"
-                f"  range min max: {self._min_range:.03f} - {self._max_range:.03f} m\n"
-                f"  acc_mean: {self.acc_mean} m/s^2\n"
-                f"  acc_std: {self.acc_std}\n"
-                f"  gyr_mean: {self.gyr_mean} rad/s\n"
-                f"  gyr_std: {self.gyr_std}")
+    def _formatted_str(self) -> str:  # the reference's report, line for line (:351-366)
+        lo3 = max(self._min_range, self.range_mean - 3 * self.range_std)
+        hi3 = min(self._max_range, self.range_mean + 3 * self.range_std)
+        rows = [f"StreamStatsTracker[dt: {self.dt:.04f} s, imus: {self._imu_num}, scans: {self._scans_num}]:",
+                f"  range_mean: {self.range_mean:.03f} m,",
+                f"  range_std: {self.range_std:.03f} m (s3 span: [{lo3:.03f} - {hi3:.03f} m])",
+                f"  range min max: {self._min_range:.03f} - {self._max_range:.03f} m",
+                f"  acc_mean: {self.acc_mean} m/s^2",
+                f"  acc_std: {self.acc_std}",
+                f"  gyr_mean: {self.gyr_mean} rad/s",
+                f"  gyr_std: {self.gyr_std}"]
+        return "\n".join(rows)
 
     def __repr__(self):
         return self._formatted_str()
