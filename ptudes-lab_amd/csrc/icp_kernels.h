@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
                 }
                 if (__all(bad == 0u)) break;
                 if (++spins > GN_LL_SPINS) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(1);
+                /* no sleep: nothing else runs in this workgroup while its first wavefront waits for the totals */
             }
             double t = 0.0;
 #pragma unroll
