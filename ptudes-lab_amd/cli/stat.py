@@ -8,7 +8,7 @@ from typing import Optional
 import click
 import numpy as np
 
-from ..ins.data import IMU, StreamStatsTracker
+from ..ins.data import StreamStatsTracker
 
 
 @click.command(name="stat")
