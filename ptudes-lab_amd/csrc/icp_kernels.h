@@ -411,20 +411,38 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c) {
 __device__ __forceinline__ void d_vds2(const Ctx& c) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool w1 = false;
+    unsigned long long key = EMPTY_KEY;
     if (i < c.n_in) {
         const int s1 = c.slot1[i];
         w1 = (s1 >= 0) && (c.vmin1[s1] == (unsigned)i);
-        int slot = -1;
         if (w1) {
             V3 p = v3(c.pts[3 * (size_t)i], c.pts[3 * (size_t)i + 1], c.pts[3 * (size_t)i + 2]);
-            unsigned long long key; int kx, ky, kz;
+            int kx, ky, kz;
             vox_key(p, c.vds2, key, kx, ky, kz);
+        }
+    }
+    // As in pass 1, runs: consecutive pass-1 winners of a wavefront mostly share the coarser voxel.  Only the first winner
+    // of each run of equal keys - the lowest index of the run, the only one of them that can win - claims and bids; the
+    // others take the slot from it.
+    {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long winners = __ballot(w1);
+        const unsigned long long before = winners & ((1ull << lane) - 1ull);          // winners in lower lanes
+        const int prev_lane = before ? 63 - __clzll((long long)before) : lane;
+        const unsigned long long prev_key = __shfl(key, prev_lane);
+        const bool head = w1 && (!before || prev_key != key);
+        int slot = -1;
+        if (head) {
             slot = vds_claim(c.vkey2, c.vmask, key);
             if (slot < 0) atomicOr(&c.st->err_flags, ERR_VDS_TABLE);
             else if (c.vmin2[slot] > (unsigned)i)
                 atomicMin(&c.vmin2[slot], (unsigned)i);
         }
-        c.slot2[i] = slot;
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long below = heads & (~0ull >> (63 - lane));               // heads at or below this lane
+        const int my_head = below ? 63 - __clzll((long long)below) : lane;
+        const int hs = __shfl(slot, my_head);
+        if (i < c.n_in) c.slot2[i] = w1 ? hs : -1;
     }
     const int n1 = __syncthreads_count(w1 ? 1 : 0);
     if (threadIdx.x == 0) c.bcnt1[blockIdx.x] = n1;
