@@ -137,6 +137,10 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        # one process per GPU, started by the launcher (the driver's command line): this script does not spawn ranks itself
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N ranks with\n  python -m torch.distributed.run "
+                 f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {args.gpus} ...")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.device < 0 else args.device
     dist = None
