@@ -105,3 +105,36 @@ def test_raw_packet_source_with_stand_in_sdk(tmp_path):
     assert got == [("L" if k % 4 == 0 else "I", k, (10**9 + 1000 * k) / 10**9) for k in range(16) if k % 4 in (0, 1)]
     only = bag.OusterRawBagSource(str(p), info="META", lidar_topic="/os_node/lidar_packets", _sdk=Sdk)
     assert [x.buf[0] for x in only] == [0, 4, 8, 12] and only.metadata == "META"
+
+
+def test_several_bags_merge_by_time_and_unknown_compression_is_reported(tmp_path):
+    conns = [("/alphasense/imu", "sensor_msgs/Imu", IMU_MD5)]
+    ts, lacc, avel = _stream(30, seed=9)
+    # even samples in one file, odd ones in the other: the source yields them interleaved by bag time
+    for part in (0, 1):
+        msgs = [(0, int(ts[i]), bw.imu_msg(i, int(ts[i]), lacc[i], avel[i])) for i in range(part, len(ts), 2)]
+        bw.write_bag(tmp_path / f"p{part}.bag", conns, msgs, chunk_msgs=4, compression="bz2" if part else "none")
+    got = list(bag.IMUBagSource([str(tmp_path / "p1.bag"), str(tmp_path / "p0.bag")], imu_topic="/alphasense/imu"))
+    assert [g.lacc[0] for g in got] == [lacc[i][0] for i in range(len(ts))]
+    # a chunk compressed with something this reader does not know
+    data = (tmp_path / "p0.bag").read_bytes().replace(b"compression=none", b"compression=zstd")
+    (tmp_path / "odd.bag").write_bytes(data)
+    with pytest.raises(bag.BagError, match="unknown chunk compression"):
+        list(bag.IMUBagSource(str(tmp_path / "odd.bag")))
+
+
+def test_packet_sources_need_ouster_sdk_and_say_so(tmp_path):
+    from ptudes_lab_amd import utils as pu
+    p = tmp_path / "raw.bag"
+    bw.write_bag(p, [("/os_node/lidar_packets", "ouster_ros/PacketMsg", bag.OUSTER_PACKETMSG_MD5)],
+                 [(0, 10**9 + k, bw.packet_msg(b"ab")) for k in range(3)])
+    try:
+        import ouster.client  # noqa: F401
+        pytest.skip("ouster-sdk is installed here")
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError, match="ouster-sdk is not installed"):
+        pu.read_packet_source(str(p), meta=None)
+    with pytest.raises(RuntimeError, match="ouster-sdk is not installed"):
+        pu.read_packet_source(str(tmp_path), meta=None)  # a directory of bags
+    assert pu.read_packet_source(str(tmp_path / "missing.xyz")) is None  # like the reference: anything else yields None
