@@ -29,18 +29,6 @@ GATHER_TIMEOUT_S = 120
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def pmc_traffic():
-    """HBM bytes per k_gn_loop launch from the committed rocprofv3 PMC passes (profiles/), or None"""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
-    if not files:
-        return None
-    try:
-        return json.load(open(files[-1])).get("k_gn_loop_traffic_bytes_per_launch")
-    except Exception:
-        return None
-
-
 def icp_bytes(stats):
     """Algorithmic bytes of one Gauss-Newton launch (B_icp): per iteration the source is
     read once (12 B/pt), 27 hash slots are probed per point (16 B each) and every candidate map point is
@@ -57,7 +45,7 @@ def scan_bytes(s, n_raw):
     return b_pre + b_ds + icp_bytes(s) + b_map
 
 
-def _cpu_pass(seq, n_total, use_imu_prediction, budget_s):
+def _cpu_pass(seq, n_total, use_imu_prediction, budget_s, with_ekf=True):
     from oracle import cpu as orc
     icp = orc.ICP(max_range=seq.max_range, min_range=seq.min_range)
     ekf = orc.EKF()
@@ -68,21 +56,23 @@ def _cpu_pass(seq, n_total, use_imu_prediction, budget_s):
         x = seq.scan(k).astype(np.float64)  # rendering is not part of the timed work
         a, b = seq.imu_range_for_scan(k)
         t0 = time.perf_counter()
-        for i in range(a, b):
-            ekf.process_imu(seq.imu[i, 1:4], seq.imu[i, 4:7], seq.imu[i, 0])
+        if with_ekf:
+            for i in range(a, b):
+                ekf.process_imu(seq.imu[i, 1:4], seq.imu[i, 4:7], seq.imu[i, 0])
         guess = ekf.pose_mat() if use_imu_prediction else None
         pose = icp.register_frame(x, t01, guess)
-        ekf.process_pose(pose)
+        if with_ekf:
+            ekf.process_pose(pose)
         spent += time.perf_counter() - t0
         kiss.append(pose)
-        res.append(ekf.pose_mat())
+        res.append(ekf.pose_mat() if with_ekf else pose)
         done += 1
         if spent >= budget_s:
             break
     return done, spent, np.array(kiss), np.array(res)
 
 
-def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0):
+def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0, with_ekf=True):
     """The CPU oracle (kind "port": our C restatement of the reference path) timed on this host on the first
     sweeps of the same sequence: one sequential pass (~1/3 of the budget; also the parity check of the GPU
     trajectory) and one pass with the loops kiss-icp runs under TBB spread over every usable core (oracle.h
@@ -91,11 +81,11 @@ def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0):
     from ptudes_lab_amd.synth import usable_cores
     cores = usable_cores()
     orc.set_threads(1)
-    d1, s1, kiss, res = _cpu_pass(seq, n_total, use_imu_prediction, budget_s / 3.0)
+    d1, s1, kiss, res = _cpu_pass(seq, n_total, use_imu_prediction, budget_s / 3.0, with_ekf)
     v1, vm, dm, sm = d1 / s1, 0.0, 0, 0.0
     if cores > 1:
         orc.set_threads(cores)
-        dm, sm, kiss_m, res_m = _cpu_pass(seq, n_total, use_imu_prediction, budget_s * 2.0 / 3.0)
+        dm, sm, kiss_m, res_m = _cpu_pass(seq, n_total, use_imu_prediction, budget_s * 2.0 / 3.0, with_ekf)
         orc.set_threads(1)
         vm = dm / sm
         if dm > d1:
@@ -109,6 +99,91 @@ def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0):
                        f"{os.cpu_count()} logical cores, {cores} usable under the cgroup quota"), kiss, res
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, worker=None, timeout_s=3600.0, out=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and relay rank 0's JSON
+    line.  Runs before anything in this process has imported torch or touched HIP (a process that has initialised the GPU
+    must not be replaced or forked); the children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT exactly as
+    `python -m torch.distributed.run` would set them.  A rank that dies takes the others down (exact PIDs) instead of
+    leaving them in a barrier.  Returns the worst exit code.  `worker` replaces [python, bench.py] (CPU test stub)."""
+    import subprocess
+    import threading
+    out = out or sys.stdout
+    cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=True))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    t_end = time.monotonic() + timeout_s
+    rcs = [None] * n
+    failed = False
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0):
+                    failed = True
+        if (failed or time.monotonic() > t_end) and any(rc is None for rc in rcs):
+            time.sleep(5.0 if failed else 0.0)  # the others usually notice by themselves (gloo peer reset)
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    p.kill()
+                    rcs[r] = p.wait() or 9
+                else:
+                    rcs[r] = p.returncode
+            if not failed:
+                print(f"bench.py: ranks still running after {timeout_s:.0f} s, killed", file=sys.stderr)
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    for ln in lines:  # stdout carries the result line(s) only; anything else a library printed there goes to stderr
+        (out if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+    out.flush()
+    worst = 0
+    for rc in rcs:
+        if rc:
+            worst = rc if rc > 0 else 128 - rc
+    if worst:
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+    return worst
+
+
+def pmc_traffic_for(workload_key):
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC pass (profiles/) whose recorded workload
+    is THIS run's workload, or None: a counter value belongs to the run it was collected on."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload_key") == workload_key and d.get("traffic_bytes_per_launch") is not None:
+            best = (d["traffic_bytes_per_launch"], os.path.basename(f))
+    return best
+
+
+def workload_key(args, S):
+    """what a PMC pass has to have been collected on to speak for this run"""
+    return (f"{args.rows}x{args.cols}_r{args.min_range:g}-{args.max_range:g}_v{(args.voxel_size or args.max_range / 100):g}_"
+            f"seed{args.seed_base}_S{S}_W{args.warmup}_K{args.steps}_{'cv' if args.const_velocity else 'imu'}"
+            f"{'' if not args.icp_only else '_icponly'}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,53 +191,72 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--seqs-per-gpu", type=int, default=1)
     ap.add_argument("--seed-base", type=int, default=1000, help="sequence s of SURVEY.md 8(d) uses seed seed_base + s")
-    ap.add_argument("--distinct-seeds", action="store_true",
-                    help="rank r takes sequences seed_base + r, + world + r, ... (SURVEY.md 8(e)) instead of every rank "
-                         "registering its own copy of sequences seed_base .. seed_base + S - 1")
+    ap.add_argument("--equal-work", action="store_true",
+                    help="every rank registers its own copy of sequences seed_base .. seed_base + S - 1 (equal work per GPU) "
+                         "instead of the SURVEY.md 8(e) sharding: rank r owns the sequences s with s %% world == r")
+    ap.add_argument("--distinct-seeds", action="store_true", help="(the default now; kept for old command lines)")
     ap.add_argument("--rows", type=int, default=128)
     ap.add_argument("--cols", type=int, default=1024)
     ap.add_argument("--max-range", type=float, default=70.0)
     ap.add_argument("--min-range", type=float, default=1.0)
     ap.add_argument("--const-velocity", action="store_true",
                     help="use the constant-velocity guess instead of --use-imu-prediction (reference default)")
+    ap.add_argument("--icp-only", action="store_true", help="no IMU / EKF at all (BASELINE config 2): constant-velocity guess")
     ap.add_argument("--gn-wgs", type=int, default=0, help="workgroups of the persistent GN kernel (0 = library default)")
     ap.add_argument("--gn-threads", type=int, default=0)
     ap.add_argument("--voxel-size", type=float, default=0.0, help="override the map voxel size (default max_range/100)")
     ap.add_argument("--map-blocks", type=int, default=0, help="voxel-block pool capacity")
     ap.add_argument("--map-table", type=int, default=0, help="map hash-table slots (power of two)")
     ap.add_argument("--workload-name", type=str, default="")
-    ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default LOCAL_RANK)")
+    ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default LOCAL_RANK %% visible devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--dump-traj", type=str, default="", help="rank 0 writes the gathered (T, 8) NC-GT rows of every sequence to this .npz")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's plain `python bench.py --gpus N`: this process becomes the launcher (it has not touched torch or HIP)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        # one process per GPU, started by the launcher (the driver's command line): this script does not spawn ranks itself
-        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N ranks with\n  python -m torch.distributed.run "
-                 f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {args.gpus} ...")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched under a launcher with a different rank count)")
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.device < 0 else args.device
+    # stdout is for the one JSON line: native libraries (gloo, RCCL, the HIP runtime) print their own notes to fd 1, so
+    # from here on fd 1 is stderr and the line goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    import ptudes_lab_amd  # noqa: F401
+    from ptudes_lab_amd import _lib, core, synth
+    n_dev = _lib.lib().ptl_device_count()  # (hipGetDeviceCount: does not initialise a device)
+    if n_dev < 1:
+        sys.exit("bench.py: no HIP device - the HIP path is the only path")
+    local_rank = (int(os.environ.get("LOCAL_RANK", "0")) % n_dev) if args.device < 0 else args.device
+    shared_device = world > n_dev  # several ranks on one GPU (1-GPU box): RCCL refuses duplicate devices, the gather goes over gloo
     dist = None
     torch = None
     ctl = None
-    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # launched by torch.distributed.run
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # a rank of a multi-process run
+        import datetime
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         # RCCL carries the one collective of the path, the trajectory gather after the run.  Its communicator is brought
         # up there and not before: a live RCCL communicator in the process stretches the cross-stream hand-overs of the
         # scan pipeline from 63 to 110 us per scan (2700 -> 2400 scans/s, measured with one rank).  Barriers and the
         # max-over-ranks clock go through a host-side gloo group.
-        dist.init_process_group(backend="nccl")
-        ctl = dist.new_group(backend="gloo")
-
-    import ptudes_lab_amd  # noqa: F401
-    from ptudes_lab_amd import core, synth
+        if shared_device:
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+            ctl = dist.group.WORLD
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", timeout=datetime.timedelta(seconds=600))
+            ctl = dist.new_group(backend="gloo")
 
     K, W, S = args.steps, args.warmup, args.seqs_per_gpu
     n_total = W + K
-    use_imu = not args.const_velocity
+    with_ekf = not args.icp_only
+    use_imu = with_ekf and not args.const_velocity
     pps = args.rows * args.cols
     icp_over = dict(scan_cols=args.cols)
     if args.gn_wgs: icp_over["gn_workgroups"] = args.gn_wgs
@@ -170,22 +264,20 @@ def main():
     if args.voxel_size: icp_over["voxel_size"] = args.voxel_size
     if args.map_blocks: icp_over["map_block_capacity"] = args.map_blocks
     if args.map_table: icp_over["map_table_capacity"] = args.map_table
-    seqs = []
-    for j in range(S):
-        # Weak scaling = the same work on every GPU: by default each rank registers its own copy of the same sequence(s)
-        # (own map, own poses, own filter, nothing shared).  The sequences of SURVEY.md 8(d) differ by +-20 % in GN
-        # iterations per scan, so with --distinct-seeds (ids s with s % world == rank, 8(e)) the max-over-ranks clock
-        # measures the slowest sequence, not the scaling.
-        seed = args.seed_base + (rank + world * j if args.distinct_seeds else j)
-        seqs.append(synth.make_sequence(seed=seed, n_scans=n_total, H=args.rows, W=args.cols, min_range=args.min_range,
-                                        max_range=args.max_range))
-    n_imu = seqs[0].imu_range_for_scan(n_total - 1)[1]
+    # rank r owns the sequences s with s % world == r, sequence s has seed seed_base + s - independent
+    # sequences, nothing shared, no data-path collective.  They differ by up to 40 % in GN iterations per scan, so the
+    # max-over-ranks clock of such a run is the slowest sequence's; --equal-work gives every rank a private copy of the
+    # same sequence(s) instead (the pure scaling measurement).
+    seq_ids = [j if args.equal_work else rank + world * j for j in range(S)]
+    seqs = [synth.make_sequence(seed=args.seed_base + s, n_scans=n_total, H=args.rows, W=args.cols, min_range=args.min_range,
+                                max_range=args.max_range) for s in seq_ids]
+    n_imu = seqs[0].imu_range_for_scan(n_total - 1)[1] if with_ekf else 0
     # S == 1: the single-sequence runner (its Gauss-Newton kernel caches hash probes across iterations);
     # S > 1: all sequences of this rank advance in lockstep in one batched runner (one launch per stage for all)
     class _One:
         def __init__(self):
             self.r = core.SeqRunner(n_total, pps, n_imu, max_range=args.max_range, min_range=args.min_range,
-                                    use_imu_prediction=use_imu, with_ekf=True, device_id=local_rank, **icp_over)
+                                    use_imu_prediction=use_imu, with_ekf=with_ekf, device_id=local_rank, **icp_over)
         def upload_scan(self, j, k, x): self.r.upload_scan(k, x)
         def upload_imu(self, j, rows, ends): self.r.upload_imu(rows, ends)
         def run(self, n): self.r.run(n)
@@ -196,18 +288,19 @@ def main():
         def copy_traj(self, j, ptr, n): return self.r.copy_traj(ptr, n)
     runner = _One() if S == 1 else core.BatchRunner(S, n_total, pps, n_imu, max_range=args.max_range,
                                                     min_range=args.min_range, use_imu_prediction=use_imu,
-                                                    with_ekf=True, device_id=local_rank, **icp_over)
+                                                    with_ekf=with_ekf, device_id=local_rank, **icp_over)
     for j, sq in enumerate(seqs):
         for k in range(n_total):
             runner.upload_scan(j, k, sq.scan(k))
-        runner.upload_imu(j, sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n_total)])
+        runner.upload_imu(j, sq.imu[:n_imu] if with_ekf else np.zeros((0, 7)),
+                          [sq.imu_range_for_scan(k)[1] if with_ekf else 0 for k in range(n_total)])
 
     def barrier():
         if dist is not None:
             dist.barrier(group=ctl)
 
     def sync():
-        if torch is not None:
+        if torch is not None and not shared_device:
             torch.cuda.synchronize()
         core.device_sync(local_rank)
 
@@ -221,11 +314,17 @@ def main():
     t0 = time.perf_counter()
     runner.enqueue(K)
     runner.wait()
-    sync(); barrier()
+    sync()
+    dt_own = time.perf_counter() - t0  # this rank's own K steps
+    barrier()
     dt = time.perf_counter() - t0
+    per_rank = [K * S / dt_own]
     if dist is not None:
         from ptudes_lab_amd import parallel
         dt = parallel.max_over_ranks(dt, dist, device="cpu", group=ctl)
+        box = [None] * world
+        dist.all_gather_object(box, K * S / dt_own, group=ctl)
+        per_rank = [float(v) for v in box]
 
     # per-rank accounting
     outs = [runner.results(j) for j in range(S)]
@@ -242,20 +341,30 @@ def main():
     n_timed = sum(len(o["stats"]) - W for o in outs)
     assert n_timed == K * S, (n_timed, K, S)
 
-    # final trajectory gather: the only collective (T x 8 NC-GT rows per sequence, RCCL all-gather).  It runs after the
-    # timed region and brings the RCCL communicator up; a failure or a stall there is reported in the line, not fatal.
+    # final trajectory gather: the only collective (T x 8 NC-GT rows per sequence, RCCL all-gather; gloo when several
+    # ranks share one GPU, which RCCL refuses).  It runs after the timed region and brings the RCCL communicator up; a
+    # failure or a stall there is reported in the line AND in the exit code.
     gathered, gather_err = None, None
-    if dist is not None:
+    if dist is not None and with_ekf:
         import threading
         from ptudes_lab_amd import parallel
         box = {}
 
         def _gather():
             try:
-                torch.cuda.set_device(local_rank)
-                rows = torch.zeros((S, n_total, 8), dtype=torch.float64, device="cuda")
-                counts = [runner.copy_traj(j, rows[j].data_ptr(), n_total) for j in range(S)]
-                box["out"] = parallel.gather_trajectories(rows, counts, dist)
+                if shared_device:
+                    rows = torch.zeros((S, n_total, 8), dtype=torch.float64)
+                    counts = []
+                    for j in range(S):
+                        o = outs[j]
+                        counts.append(len(o["res_t"]))
+                        rows[j, : counts[-1]] = torch.from_numpy(parallel.poses_to_rows(o["res_t"], o["res_poses"]))
+                    box["out"] = parallel.gather_trajectories(rows, counts, dist)
+                else:
+                    torch.cuda.set_device(local_rank)
+                    rows = torch.zeros((S, n_total, 8), dtype=torch.float64, device="cuda")
+                    counts = [runner.copy_traj(j, rows[j].data_ptr(), n_total) for j in range(S)]
+                    box["out"] = parallel.gather_trajectories(rows, counts, dist)
             except Exception as e:  # noqa: BLE001
                 box["err"] = repr(e)
 
@@ -270,33 +379,45 @@ def main():
     if rank == 0:
         from ptudes_lab_amd.ins.data import calc_ate
         o, sq = outs[0], seqs[0]
+        est = o["res_poses"] if with_ekf else o["kiss_poses"]
         gt = sq.gt_poses(0.5)
         g0i = np.linalg.inv(gt[0])
         gt_rel = np.array([g0i @ g for g in gt])
-        ate_r, ate_t = calc_ate(list(o["res_poses"]), list(gt_rel[: len(o["res_poses"])]))
-        rmse_gt = float(np.sqrt(np.mean(np.sum((o["res_poses"][:, :3, 3] - gt_rel[: len(o["res_poses"]), :3, 3]) ** 2, 1))))
+        ate_r, ate_t = calc_ate(list(est), list(gt_rel[: len(est)]))
+        rmse_gt = float(np.sqrt(np.mean(np.sum((est[:, :3, 3] - gt_rel[: len(est), :3, 3]) ** 2, 1))))
         avg_gn_s = (gn_ms / 1e3) / max(gn_n, 1)
         avg_gn_bytes = gn_bytes / max(gn_n, 1)  # one launch carries the GN loops of all S sequences
         achieved = avg_gn_bytes / avg_gn_s if avg_gn_s > 0 else 0.0
-        if args.distinct_seeds:
-            seeds_txt = f"{args.seed_base}..{args.seed_base + world * S - 1} (rank r: s % {world} == r)"
-        else:
+        if args.equal_work:
             seeds_txt = f"{args.seed_base}..{args.seed_base + S - 1}" + (", a private copy on every rank (equal work per GPU)" if world > 1 else "")
+        else:
+            seeds_txt = f"{args.seed_base}..{args.seed_base + world * S - 1}" + (f" (rank r owns s % {world} == r)" if world > 1 else "")
+        mode_txt = "ICP only, constant-velocity guess" if not with_ekf else \
+            f"ICP + IMU-EKF ({'--use-imu-prediction' if use_imu else 'constant-velocity guess'})"
+        wkey = workload_key(args, S)
+        pmc = pmc_traffic_for(wkey) if world == 1 else None
         line = {
             "metric": f"lidar scans/sec (ICP+EKF) on {args.rows}x{args.cols} sweeps",
             "value": K * S * world / dt, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.rows}x{args.cols} sweeps, random-walk SE(3) GT, "
-                                   f"ICP + IMU-EKF ({'--use-imu-prediction' if use_imu else 'constant-velocity guess'}), "
+            "config": {"workload": f"synthetic {args.rows}x{args.cols} sweeps, random-walk SE(3) GT, {mode_txt}, "
                                    f"min/max range {args.min_range}/{args.max_range} m, voxel {(args.voxel_size or args.max_range / 100):.2f} m"
                                    + (f" [{args.workload_name}]" if args.workload_name else ""),
+                       "workload_key": wkey,
                        "sequences_per_gpu": S, "sequence_seeds": seeds_txt,
                        "scans_per_sequence": n_total, "parallelism": f"{world} independent sequence shard(s), no data-path collective"},
+            "per_rank_scans_per_s": {"values": per_rank, "min": min(per_rank), "mean": float(np.mean(per_rank)), "max": max(per_rank),
+                                     "note": "each rank's own K steps / its own wall time; `value` uses the max-over-ranks clock"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(), "kernel": "k_gn_loop" if S == 1 else "kb_gn_loop",
+                         "frac": achieved / HBM_PEAK, "traffic": pmc[0] if pmc else None,
+                         "traffic_source": pmc[1] if pmc else None,
+                         "measured_frac": (pmc[0] / avg_gn_s / HBM_PEAK) if (pmc and avg_gn_s > 0) else None,
+                         "kernel": "k_gn_loop" if S == 1 else "kx_gn_loop",
                          "avg_launch_us": 1e6 * avg_gn_s, "algorithmic_bytes_per_launch": avg_gn_bytes,
-                         "launches": gn_n, "timed_launches": f"every {ev_every}th of {K} (HIP events)"},
+                         "launches": gn_n, "timed_launches": f"every {ev_every}th of {K} (HIP events)",
+                         "note": "frac = ALGORITHMIC bytes (SURVEY 8(d): 27 probes x 16 B + every candidate x 12 B + the source, per "
+                                 "iteration) / launch time / peak; measured_frac = PMC HBM bytes of the same workload / launch time / peak"},
             "whole_scan": {"algorithmic_bytes_per_scan": b_scan / max(n_timed, 1),
                            "achieved_GBps": (b_scan * world / dt) / 1e9 if world == 1 else None,
                            "gn_share_of_wall": (avg_gn_s * K) / dt,
@@ -308,23 +429,28 @@ def main():
                          "rmse_vs_gt_m": rmse_gt},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, kiss_cpu, res_cpu = cpu_baseline(sq, n_total, use_imu, args.cpu_budget)
+            cb, kiss_cpu, res_cpu = cpu_baseline(sq, n_total, use_imu, args.cpu_budget, with_ekf=with_ekf)
             m = len(res_cpu)
             line["cpu_baseline"] = cb
-            d = np.linalg.norm(o["res_poses"][:m, :3, 3] - res_cpu[:, :3, 3], axis=1)
+            d = np.linalg.norm(est[:m, :3, 3] - res_cpu[:, :3, 3], axis=1)
             line["parity_vs_oracle"] = {"scans": m, "max_dpos_m": float(d.max()), "rmse_dpos_m": float(np.sqrt(np.mean(d ** 2)))}
             line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
         else:
             line["cpu_baseline"] = None
         if gathered is not None:
-            line["gathered_trajectories"] = {"sequences": len(gathered), "rows_each": sorted({len(v) for v in gathered.values()})}
+            line["gathered_trajectories"] = {"sequences": len(gathered), "rows_each": sorted({len(v) for v in gathered.values()}),
+                                             "backend": "gloo (ranks share a GPU; RCCL refuses duplicate devices)" if shared_device else "nccl (RCCL)"}
+            if args.dump_traj:
+                np.savez(args.dump_traj, **{f"rank{r}_seq{j}": v for (r, j), v in gathered.items()},
+                         seeds=np.array([[r, j, args.seed_base + (j if args.equal_work else r + world * j)] for (r, j) in gathered]))
         elif gather_err is not None:
             line["gathered_trajectories"] = {"error": gather_err}
-        print(json.dumps(line), flush=True)
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
-        if gather_err is not None:  # a communicator in an unknown state: leave without the collective shutdown
+        if gather_err is not None:  # a communicator in an unknown state: leave without the collective shutdown, and say so
             sys.stdout.flush()
-            os._exit(0)
+            sys.stderr.flush()
+            os._exit(3)
         dist.barrier(group=ctl)
         dist.destroy_process_group()
 

@@ -51,12 +51,9 @@ struct ScanStats {  // mirrors ptl_icp_stats
 struct DevState {
     // per-scan counters
     int n_in, n_valid, n_down, n_src;
-    // GN loop: grid barrier words, each on its own 128-byte line
-    unsigned bar_grp[8 * 32];
-    unsigned bar_gen[8 * 32];
-    unsigned bar_top;
     unsigned gn_epoch;  // bumped before every single-sequence GN launch: part of the flag of its published words
-    int gn_iters, gn_ncorr, gn_pad;
+    int gn_iters, gn_ncorr;
+    int gn_abort;       // set by the first Gauss-Newton workgroup whose exchange poll ran out: everybody leaves the loop
     long long gn_cand;
     double gn_max_dist, gn_kernel;
     double T_icp[16];
@@ -236,10 +233,8 @@ __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
     st->prev_n_in = st->n_in;
     st->n_in = c.n_in;
     st->n_valid = 0; st->n_down = 0; st->n_src = 0;
-    for (int g = 0; g < 8; ++g) { st->bar_grp[g * 32] = 0; st->bar_gen[g * 32] = 0; }
-    st->bar_top = 0;
     st->gn_epoch = (st->gn_epoch + 1u) & 0x3FFFFFu;
-    st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0;
+    st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0; st->gn_abort = 0;
     st->do_deskew = (c.deskew && n_poses >= 2) ? 1 : 0;
     s_nposes = n_poses;
     __threadfence_block();
@@ -820,28 +815,6 @@ __device__ __forceinline__ PointWalk point_walk(int n, int G, int wg, int NG, in
     return w;
 }
 
-// Two-level arrival / one-word-per-group release grid barrier on monotonic counters (zeroed by K0).
-// Groups are wg & 7 (what the dispatcher places on one XCD today; correctness does not depend on it).
-// Every payload word is exchanged with agent-scope 8-byte atomics, so no fences are needed.
-__device__ __forceinline__ void grid_barrier(DevState* st, int G, int wg, int it) {
-    const int grp = wg & 7;
-    const int ngroups = G < 8 ? G : 8;
-    const unsigned ng = (unsigned)((G - grp + 7) / 8);
-    const unsigned gen = (unsigned)(it + 1);
-    const unsigned a = __hip_atomic_fetch_add(&st->bar_grp[grp * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a + 1u == ng * gen) {
-        const unsigned t = __hip_atomic_fetch_add(&st->bar_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t + 1u == (unsigned)ngroups * gen)
-            for (int g = 0; g < ngroups; ++g)
-                __hip_atomic_store(&st->bar_gen[g * 32], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    unsigned spins = 0;
-    while (__hip_atomic_load(&st->bar_gen[grp * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1u << 25)) { atomicOr(&st->err_flags, ERR_GN_TIMEOUT); break; }
-    }
-}
-
 // kiss.py:116-130 after the ICP: new pose, innovation (err_dt / err_drot), threshold model deviation, stats
 // row.  full != 0 => a real scan (trajectory + stats row, closes with finish_pending); 0 => ptl_icp_align.
 __device__ __forceinline__ const double* guess_src(const Ctx& c) { return c.ext_guess ? c.ext_guess : c.st->guess; }
@@ -890,26 +863,28 @@ __device__ __forceinline__ unsigned long long gn_ll_word(const double* vals, int
     const unsigned half = (w & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
     return (unsigned long long)half | ((unsigned long long)flag << 32);
 }
-// spin until the word carries `flag`; returns its data half (sets *ok = false on a timeout)
-__device__ __forceinline__ unsigned gn_ll_wait(const unsigned long long* p, unsigned flag, bool* ok) {
-    unsigned spins = 0;
-    for (;;) {
-        const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(v >> 32) == flag) return (unsigned)v;
-        if (++spins > GN_LL_SPINS) { *ok = false; return 0u; }
-        __builtin_amdgcn_s_sleep(1);
-    }
+// A poll that runs out of spins (a workgroup that is not resident, a co-tenant holding CUs) must not be repeated
+// max_iter times by every workgroup: whoever runs out first raises ERR_GN_TIMEOUT and sets st->gn_abort; every
+// spinning wavefront looks at that word every 1024 polls and gives up too, and a workgroup that gave up leaves the loop
+// at the end of the iteration.  The host sees the error flag at its next wait.
+__device__ __forceinline__ bool gn_abort_seen(const int* abort_word) {
+    return __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
-// the same for two words of one row at once (both loads in flight together)
+__device__ __forceinline__ void gn_raise_abort(DevState* st) {
+    atomicOr(&st->err_flags, ERR_GN_TIMEOUT);
+    __hip_atomic_store(&st->gn_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// spin until both words of one row carry `flag` (both loads in flight together); *ok = false on a timeout / abort
 __device__ __forceinline__ void gn_ll_wait2(const unsigned long long* p0, const unsigned long long* p1, bool second,
-                                            unsigned flag, unsigned* h0, unsigned* h1, bool* ok) {
+                                            unsigned flag, unsigned* h0, unsigned* h1, bool* ok, const int* abort_word) {
     unsigned spins = 0;
     for (;;) {
         const unsigned long long a = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long b = second ? __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                             : ((unsigned long long)flag << 32);
         if ((unsigned)(a >> 32) == flag && (unsigned)(b >> 32) == flag) { *h0 = (unsigned)a; *h1 = (unsigned)b; return; }
-        if (++spins > GN_LL_SPINS) { *ok = false; *h0 = 0u; *h1 = 0u; return; }
+        ++spins;
+        if (spins > GN_LL_SPINS || ((spins & 1023u) == 0u && gn_abort_seen(abort_word))) { *ok = false; *h0 = 0u; *h1 = 0u; return; }
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -942,8 +917,15 @@ __device__ __forceinline__ double gn_ll_join(unsigned half) {
 // MC (compile time): keep the probe results of every source point in memory when a group serves several points per
 // iteration (dense scans: N_s > workgroups x groups).  The host picks the variant from the previous scan's N_s (a hint
 // copied back asynchronously; both variants are correct for any N_s), so the single-pass code carries none of it.
-template <int PC, bool MC>
-__global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
+// XL (compile time): how the workgroups' rows meet.  false: the two-hop exchange above (rows -> 8 group leaders -> group
+// sums to every consumer slot), for one sequence spread over the whole chip.  true: ONE hop - every workgroup polls all G
+// rows of its sequence itself and forms the same sums (members of a group in member order, then the groups in group
+// order: bit-identical to the two-hop result for the same G); meant for G <= 64 workgroups that sit on one XCD (the
+// batched kernel kx_gn_loop: sequence s <-> the workgroups with blockIdx & 7 == s), where a store becomes visible to
+// its neighbours after one memory-side round trip instead of two hops across the chip.
+// G / wg: number and index of the workgroups that cooperate on THIS sequence (the grid, or one XCD's share of it).
+template <int PC, bool MC, bool XL>
+__device__ __forceinline__ void gn_loop_body(const Ctx& c, int mode, const int G, const int wg) {
     __shared__ double red[GN_MAX_GROUPS][32];
     __shared__ double tot[32];
     __shared__ double Esh2[2][12];  // the increment of iteration i lives in buffer i & 1 (the guess in buffer 1): the solver
@@ -955,7 +937,6 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     DevState* st = c.st;
     const int tid = threadIdx.x, lane32 = tid & 31, grp = tid >> 5, gbase = (tid & 63) & 32;
     const int NG = blockDim.x >> 5;
-    const int G = gridDim.x, wg = blockIdx.x;
     const int n = st->n_src;
     const unsigned epoch = st->gn_epoch;
     if (wg == 0 && tid == 0 && mode == 0) flush_map_stats(c, st);  // the previous scan's map update precedes this launch
@@ -1100,78 +1081,114 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
                                (unsigned long long)half | ((unsigned long long)flag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const long long c2 = GN_CLK();
-        if (wg < ngroups) {  // leader of group wg: members wg, wg + 8, ... ; every wavefront takes two of their rows
-            const int nmem = (G - wg + 7) / 8;
-            for (int j = grp; j < nmem; j += NG) {
-                const unsigned long long* row = c.gn_rows_ll + ((size_t)par * G + (wg + 8 * j)) * GN_LL_WORDS;
+        if (XL) {
+            // one hop: every 32-lane group polls one row of the sequence (all its workgroups, this one included); the
+            // first 29 lanes then add them in the two-hop association and hand the totals to the solve
+            for (int j = grp; j < G; j += NG) {
+                const unsigned long long* row = c.gn_rows_ll + ((size_t)par * G + j) * GN_LL_WORDS;
                 unsigned h0, h1;
-                gn_ll_wait2(row + lane32, row + lane32 + 32, lane32 + 32 < 58, flag, &h0, &h1, &ok);
+                gn_ll_wait2(row + lane32, row + lane32 + 32, lane32 + 32 < 58, flag, &h0, &h1, &ok, &st->gn_abort);
                 const double v0 = gn_ll_join(h0), v1 = gn_ll_join(h1);
                 if ((lane32 & 1) == 0) {
                     redL[j][lane32 >> 1] = v0;
                     if (16 + (lane32 >> 1) < 29) redL[j][16 + (lane32 >> 1)] = v1;
                 }
             }
-            if (!ok) atomicOr(&st->err_flags, ERR_GN_TIMEOUT);
-            __syncthreads();
+            if (!ok) gn_raise_abort(st);
+            ok = __syncthreads_or(ok ? 0 : 1) == 0;
             ph_x1 += GN_CLK() - c2;
-            if (tid < 29) {  // sum in member order; each summing lane publishes both halves of its entry, one copy per consumer slot
-                double s = 0.0;
-                if (nmem == 32) {  // 256 workgroups: all reads in flight, then the same additions in member order
+            if (tid < 29) {
+                double t = 0.0;
+                if (G == 32) {  // all reads in flight, then the additions in (group, member) order
                     double r[32];
 #pragma unroll
                     for (int j = 0; j < 32; ++j) r[j] = redL[j][tid];
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) s += r[j];
+                    for (int g = 0; g < 8; ++g) t += (((0.0 + r[g]) + r[g + 8]) + r[g + 16]) + r[g + 24];
                 } else {
-                    for (int j = 0; j < nmem; ++j) s += redL[j][tid];
+                    for (int g = 0; g < ngroups; ++g) {
+                        double sg = 0.0;
+                        for (int j = g; j < G; j += 8) sg += redL[j][tid];
+                        t += sg;
+                    }
                 }
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(s), fl = (unsigned long long)flag << 32;
-                const unsigned long long lo = (bits & 0xFFFFFFFFull) | fl, hi = (bits >> 32) | fl;
-#pragma unroll
-                for (int r = 0; r < GN_XSUM_COPIES; ++r) {
-                    unsigned long long* dst = c.gn_xsum_ll + (((size_t)par * 8 + r) * 8 + wg) * GN_LL_WORDS + 2 * tid;
-                    __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                tot[tid] = t;
             }
-        }
-        // The group sums are collected by ONE wavefront (lane l <-> word l of a row; lanes 2e, 2e + 1 hold the halves of
-        // entry e): nothing between the arrival of the last word and the solve needs LDS traffic but the 29 totals.
-        if (tid < 64) {
-            const bool mine = tid < 58, even = (tid & 1) == 0;
-            ok = true;
             ph_x2 += GN_CLK() - c2;
-            // everybody: the group sums addressed to this workgroup's slot, added in group order
-            unsigned h[8];
-            unsigned spins = 0;
-            for (;;) {
-                unsigned long long vv[8];
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    vv[g] = (unsigned long long)flag << 32;
-                    if (mine && g < ngroups)
-                        vv[g] = __hip_atomic_load(c.gn_xsum_ll + (((size_t)par * 8 + (wg & (GN_XSUM_COPIES - 1))) * 8 + g) * GN_LL_WORDS + tid,
-                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (wg < ngroups) {  // leader of group wg: members wg, wg + 8, ... ; every wavefront takes two of their rows
+                const int nmem = (G - wg + 7) / 8;
+                for (int j = grp; j < nmem; j += NG) {
+                    const unsigned long long* row = c.gn_rows_ll + ((size_t)par * G + (wg + 8 * j)) * GN_LL_WORDS;
+                    unsigned h0, h1;
+                    gn_ll_wait2(row + lane32, row + lane32 + 32, lane32 + 32 < 58, flag, &h0, &h1, &ok, &st->gn_abort);
+                    const double v0 = gn_ll_join(h0), v1 = gn_ll_join(h1);
+                    if ((lane32 & 1) == 0) {
+                        redL[j][lane32 >> 1] = v0;
+                        if (16 + (lane32 >> 1) < 29) redL[j][16 + (lane32 >> 1)] = v1;
+                    }
                 }
-                unsigned bad = 0u;
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    bad |= (unsigned)(vv[g] >> 32) ^ flag;
-                    h[g] = (unsigned)vv[g];
+                if (!ok) gn_raise_abort(st);
+                __syncthreads();
+                ph_x1 += GN_CLK() - c2;
+                if (tid < 29) {  // sum in member order; each summing lane publishes both halves of its entry, one copy per consumer slot
+                    double s = 0.0;
+                    if (nmem == 32) {  // 256 workgroups: all reads in flight, then the same additions in member order
+                        double r[32];
+    #pragma unroll
+                        for (int j = 0; j < 32; ++j) r[j] = redL[j][tid];
+    #pragma unroll
+                        for (int j = 0; j < 32; ++j) s += r[j];
+                    } else {
+                        for (int j = 0; j < nmem; ++j) s += redL[j][tid];
+                    }
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(s), fl = (unsigned long long)flag << 32;
+                    const unsigned long long lo = (bits & 0xFFFFFFFFull) | fl, hi = (bits >> 32) | fl;
+    #pragma unroll
+                    for (int r = 0; r < GN_XSUM_COPIES; ++r) {
+                        unsigned long long* dst = c.gn_xsum_ll + (((size_t)par * 8 + r) * 8 + wg) * GN_LL_WORDS + 2 * tid;
+                        __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
-                if (__all(bad == 0u)) break;
-                if (++spins > GN_LL_SPINS) { ok = false; break; }
-                /* no sleep: nothing else runs in this workgroup while its first wavefront waits for the totals */
             }
-            double t = 0.0;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const double v = gn_ll_join(h[g]);
-                if (g < ngroups) t += v;
+            // The group sums are collected by ONE wavefront (lane l <-> word l of a row; lanes 2e, 2e + 1 hold the halves of
+            // entry e): nothing between the arrival of the last word and the solve needs LDS traffic but the 29 totals.
+            if (tid < 64) {
+                const bool mine = tid < 58, even = (tid & 1) == 0;
+                ok = true;
+                ph_x2 += GN_CLK() - c2;
+                // everybody: the group sums addressed to this workgroup's slot, added in group order
+                unsigned h[8];
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned long long vv[8];
+    #pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        vv[g] = (unsigned long long)flag << 32;
+                        if (mine && g < ngroups)
+                            vv[g] = __hip_atomic_load(c.gn_xsum_ll + (((size_t)par * 8 + (wg & (GN_XSUM_COPIES - 1))) * 8 + g) * GN_LL_WORDS + tid,
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    unsigned bad = 0u;
+    #pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        bad |= (unsigned)(vv[g] >> 32) ^ flag;
+                        h[g] = (unsigned)vv[g];
+                    }
+                    if (__all(bad == 0u)) break;
+                    if (++spins > GN_LL_SPINS) { ok = false; break; }
+                    /* no sleep: nothing else runs in this workgroup while its first wavefront waits for the totals */
+                }
+                double t = 0.0;
+    #pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const double v = gn_ll_join(h[g]);
+                    if (g < ngroups) t += v;
+                }
+                if (mine && even) tot[tid >> 1] = t;
+                if (!ok && tid == 0) gn_raise_abort(st);
             }
-            if (mine && even) tot[tid >> 1] = t;
-            if (!ok && tid == 0) atomicOr(&st->err_flags, ERR_GN_TIMEOUT);
         }
         long long c3 = 0, c4 = 0;
         if (tid < 64) {  // the wavefront that collected the totals solves: its own LDS writes are ordered before its reads,
@@ -1185,7 +1202,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
             for (int k = 0; k < 3; ++k) Esh2[it & 1][9 + k] = e.t[k];
             double nn = 0.0;
             for (int k = 0; k < 6; ++k) nn += dx[k] * dx[k];
-            flag_done2[it & 1] = (nn < conv2) ? 1 : 0;  // sqrt(nn) < conv, without the square root on the serial path
+            flag_done2[it & 1] = (nn < conv2 || !ok) ? 1 : 0;  // sqrt(nn) < conv, without the square root on the serial path; !ok: the exchange gave up (time-out / abort)
           }
         }
         __syncthreads();
@@ -1214,6 +1231,11 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
         st->gn_phase_clk[6] += ph_x1; st->gn_phase_clk[7] += ph_x2;  // part of phase 1 spent waiting for the workgroup's other wavefronts
         if (mode != 1) gn_post(c, st, false, mode == 0);
     }
+}
+// one sequence over the whole grid
+template <int PC, bool MC>
+__global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
+    gn_loop_body<PC, MC, false>(c, mode, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ K7-K9
@@ -1497,213 +1519,17 @@ __global__ __launch_bounds__(256) void kb_map_rebuild(const SeqCtx* a, int scan_
 }
 
 // ------------------------------------------------------------------------------------------------ batched K5
-// The Gauss-Newton loops of S scans (one per sequence) in ONE persistent launch: every iteration runs the
-// nearest-neighbour + accumulation pass of every still-active sequence back to back, then ONE workgroup
-// reduction, ONE grid barrier, S small grid reductions and S 6x6 solves (thread 64*s solves sequence s).
-// Point -> workgroup assignment, reduction trees and arithmetic per sequence are exactly those of k_gn_loop, so
-// each sequence's result is bit-identical to running it alone with the same (G, threads); only the
-// synchronisation is shared.
+// The Gauss-Newton loops of up to 8 scans (one per sequence) in ONE persistent launch, one sequence per XCD: sequence s
+// is owned by the workgroups with blockIdx & 7 == s (what the dispatcher places on XCD s today; speed only - every
+// exchanged word travels with agent-scope atomics).  Its map blocks, probe rows and source points stay in that XCD's L2,
+// its workgroups meet through the one-hop exchange of gn_loop_body<XL = true> - nothing crosses the chip - and it leaves
+// the loop on its own convergence.  Per sequence the point -> workgroup assignment, the reduction trees and the
+// arithmetic are those of k_gn_loop launched alone with gridDim / 8 workgroups: bit-identical results.
 #define GN_MAX_SEQ 8
-struct GnSeq {  // what the inner loop needs of one sequence, small enough to travel as a kernel argument
-    const double* src0;
-    double* src_cur;
-    const TabEnt* tab;
-    const unsigned char* blocks;
-    DevState* st;
-    unsigned tmask;
-    int bstride, P, pad;
-    double vs, conv;
-};
-struct GnBatch {
-    GnSeq q[GN_MAX_SEQ];
-    int S, max_iter;
-};
 template <int PC>
-__global__ __launch_bounds__(GN_MAX_THREADS) void kb_gn_loop(GnBatch b, const SeqCtx* a, double* partials) {
-    __shared__ double red[GN_MAX_SEQ][GN_MAX_GROUPS / 2][32];
-    __shared__ double red2[4][32];
-    __shared__ double redg[4][8][32];
-    __shared__ double tot[GN_MAX_SEQ][32];
-    __shared__ double Esh[GN_MAX_SEQ][12];
-    __shared__ double Tsh[GN_MAX_SEQ][12];
-    __shared__ int done_sh[GN_MAX_SEQ];
-    __shared__ int iters_sh[GN_MAX_SEQ];
-    __shared__ long long cand_sh[GN_MAX_SEQ];
-    __shared__ int ncorr_sh[GN_MAX_SEQ];
-    const int tid = threadIdx.x, lane32 = tid & 31, grp = tid >> 5, gbase = (tid & 63) & 32;
-    const int NG = blockDim.x >> 5;
-    const int G = gridDim.x, wg = blockIdx.x, S = b.S;
-    DevState* st0 = b.q[0].st;  // barrier words of sequence 0 serve the whole launch
-    int ia = 0, ib = 0;
-    {
-        int o = 0;
-        for (int p = 0; p < 6; ++p)
-            for (int q = p; q < 6; ++q) { if (o == lane32) { ia = p; ib = q; } ++o; }
-        if (lane32 >= 21) { ia = lane32 - 21; ib = 6; }
-    }
-    if (tid < S * 12) {
-        const int s = tid / 12, k = tid % 12;
-        const double* g = guess_src(a[s].c);
-        Esh[s][k] = (k < 9) ? g[4 * (k / 3) + (k % 3)] : g[4 * (k - 9) + 3];
-        Tsh[s][k] = (k < 9) ? ((k % 4 == 0) ? 1.0 : 0.0) : 0.0;
-    }
-    if (tid < S) {
-        done_sh[tid] = (b.q[tid].st->n_live == 0) ? 1 : 0;  // voxel_map.Empty() => return initial_guess
-        iters_sh[tid] = 0; cand_sh[tid] = 0; ncorr_sh[tid] = 0;
-    }
-    __syncthreads();
-    long long ph[5] = {0, 0, 0, 0, 0};
-    int n_it = 0;
-    for (int it = 0; it < b.max_iter; ++it) {
-        const long long c0 = GN_CLK();
-        bool all_done = true;
-        for (int s = 0; s < S; ++s) all_done = all_done && (done_sh[s] != 0);
-        if (all_done) break;
-        for (int s = 0; s < S; ++s) {
-            if (done_sh[s]) continue;  // uniform over the grid: every workgroup holds the same flags
-            GnSeq c;  // by value through constant kernel-argument offsets: stays in scalar registers for the pass
-            switch (s) {
-                case 0: c = b.q[0]; break;
-                case 1: c = b.q[1]; break;
-                case 2: c = b.q[2]; break;
-                case 3: c = b.q[3]; break;
-                case 4: c = b.q[4]; break;
-                case 5: c = b.q[5]; break;
-                case 6: c = b.q[6]; break;
-                default: c = b.q[7]; break;
-            }
-            const int n = c.st->n_src;
-            const double kern = c.st->gn_kernel, k2 = kern * kern;
-            const double gate2 = sqrt_gate(c.st->gn_max_dist);
-            double acc = 0.0;
-            int ncand = 0;
-            Rt E;
-            for (int k = 0; k < 9; ++k) E.R[k] = Esh[s][k];
-            for (int k = 0; k < 3; ++k) E.t[k] = Esh[s][9 + k];
-            unsigned long long ckey = EMPTY_KEY;
-            int cblk = -1;
-            const PointWalk pw = point_walk(n, G, wg, NG, grp);
-            for (int i = pw.first; i < pw.last; i += pw.step) {
-                const double* sp0 = (it == 0) ? c.src0 : c.src_cur;
-                const V3 sp = rt_apply(E, v3(sp0[3 * (size_t)i], sp0[3 * (size_t)i + 1], sp0[3 * (size_t)i + 2]));
-                if (lane32 == 0) { c.src_cur[3 * (size_t)i] = sp.x; c.src_cur[3 * (size_t)i + 1] = sp.y; c.src_cur[3 * (size_t)i + 2] = sp.z; }
-                V3 t;
-                double d2;
-                int lastv = -1;
-                const bool found = nn_search32<PC>(c, sp, lane32, gbase, t, d2, ncand, ckey, cblk, false, lastv);
-                if (found && d2 < gate2) {
-                    const V3 r = v3(sp.x - t.x, sp.y - t.y, sp.z - t.z);
-                    const double den = kern + (r.x * r.x + r.y * r.y + r.z * r.z);
-                    const double w = k2 / (den * den);
-                    if (lane32 < 27) acc += w * dot(jcol(ia, sp, r), jcol(ib, sp, r));
-                    else if (lane32 == 27) acc += 1.0;
-                }
-            }
-            const int ncand0 = group_sum32(ncand);
-            const double mine = (lane32 == 28) ? (double)ncand0 : acc;
-            const double pair = mine + __shfl_xor(mine, 32);
-            if ((tid & 63) < 32) red[s][tid >> 6][lane32] = pair;
-        }
-        __syncthreads();
-        const long long c1 = GN_CLK();
-        // workgroup reduction of every active sequence, same tree as k_gn_loop, then publish
-        for (int s = 0; s < S; ++s) {
-            if (done_sh[s]) continue;
-            if (tid < 128) {
-                const int col = tid & 31, seg = tid >> 5, NW = NG >> 1, per = (NW + 3) >> 2;
-                double v = 0.0;
-                for (int g = seg * per; g < (seg + 1) * per && g < NW; ++g) v += red[s][g][col];
-                red2[seg][col] = v;
-            }
-            __syncthreads();
-            if (tid < 29) {
-                const double v = ((red2[0][tid] + red2[1][tid]) + red2[2][tid]) + red2[3][tid];
-                double* part = partials + (((size_t)(it & 1) * G + wg) * GN_MAX_SEQ + s) * 32;
-                __hip_atomic_store(&part[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const long long c2 = GN_CLK();
-        if (tid == 0) grid_barrier(st0, G, wg, it);
-        __syncthreads();
-        const long long c3 = GN_CLK();
-        // grid reduction, up to four sequences per round with the single-sequence tree (8 strided parts, then 8 -> 1)
-        const int per_round = (int)(blockDim.x >> 8) < 4 ? (int)(blockDim.x >> 8) : 4;  // 256 threads per sequence
-        for (int s0 = 0; s0 < S; s0 += per_round) {
-            const int s = s0 + (tid >> 8);
-            if ((tid >> 8) < per_round && s < S && !done_sh[s]) {
-                const int t8 = tid & 255, col = t8 & 31, part8 = t8 >> 5;
-                double v = 0.0;
-                if (col < 29) {
-                    const double* base = partials + ((size_t)(it & 1) * G * GN_MAX_SEQ + s) * 32 + col;
-                    int w = part8;
-                    for (; w + 56 < G; w += 64) {
-                        double x[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            x[u] = __hip_atomic_load(&base[(size_t)(w + 8 * u) * GN_MAX_SEQ * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) v += x[u];
-                    }
-                    for (; w < G; w += 8)
-                        v += __hip_atomic_load(&base[(size_t)w * GN_MAX_SEQ * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                redg[tid >> 8][part8][col] = v;
-            }
-            __syncthreads();
-            if (tid < 128) {
-                const int sl = tid >> 5, col = tid & 31, s2 = s0 + sl;
-                if (sl < per_round && s2 < S && !done_sh[s2] && col < 29) {
-                    double v = 0.0;
-                    for (int g = 0; g < 8; ++g) v += redg[sl][g][col];
-                    tot[s2][col] = v;
-                }
-            }
-            __syncthreads();
-        }
-        const long long c4 = GN_CLK();
-        // one solving thread per sequence, in different wavefronts
-        if ((tid & 63) == 0 && (tid >> 6) < S && !done_sh[tid >> 6]) {
-            const int s = tid >> 6;
-            double dx[6];
-            solve6_ldlt(tot[s], dx);
-            Rt e = se3_exp_gn(dx);
-            Rt T;
-            for (int k = 0; k < 9; ++k) T.R[k] = Tsh[s][k];
-            for (int k = 0; k < 3; ++k) T.t[k] = Tsh[s][9 + k];
-            T = rt_mul(e, T);
-            for (int k = 0; k < 9; ++k) { Esh[s][k] = e.R[k]; Tsh[s][k] = T.R[k]; }
-            for (int k = 0; k < 3; ++k) { Esh[s][9 + k] = e.t[k]; Tsh[s][9 + k] = T.t[k]; }
-            double nn = 0.0;
-            for (int k = 0; k < 6; ++k) nn += dx[k] * dx[k];
-            cand_sh[s] += (long long)tot[s][28];
-            ncorr_sh[s] = (int)tot[s][27];
-            iters_sh[s] = it + 1;
-            if (sqrt(nn) < b.q[s].conv) done_sh[s] = 1;
-        }
-        __syncthreads();
-        const long long c5 = GN_CLK();
-        ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
-        ++n_it;
-    }
-    if (wg == 0 && tid == 0) {
-        for (int k = 0; k < 5; ++k) st0->gn_phase_clk[k] += ph[k];
-        st0->gn_phase_clk[5] += n_it;
-    }
-    if (wg == 0 && (tid & 63) == 0 && (tid >> 6) < S) {
-        const int s = tid >> 6;
-        const Ctx& c = a[s].c;
-        DevState* st = c.st;
-        const bool empty = st->n_live == 0;
-        Rt T;
-        for (int k = 0; k < 9; ++k) T.R[k] = Tsh[s][k];
-        for (int k = 0; k < 3; ++k) T.t[k] = Tsh[s][9 + k];
-        rt_to16(T, st->T_icp);
-        st->gn_iters = iters_sh[s];
-        st->gn_ncorr = ncorr_sh[s];
-        st->gn_cand = cand_sh[s];
-        gn_post(c, st, empty, 1);
-    }
+__global__ __launch_bounds__(GN_MAX_THREADS) void kx_gn_loop(const SeqCtx* a, int S, int scan_k) {
+    const int s = (int)(blockIdx.x & 7u);
+    if (s >= S) return;
+    const Ctx c = load_seq_ctx(a, s, scan_k);
+    gn_loop_body<PC, true, true>(c, 0, (int)(gridDim.x >> 3), (int)(blockIdx.x >> 3));
 }

@@ -156,7 +156,8 @@ static int icp_reset_device(ptl_icp* h) {
 
 static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, ptl_icp** out) {
     if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
-    if (cfg->max_points_per_voxel < 1 || cfg->max_points_per_voxel > 254) return set_err(PTL_ERR_ARG, "max_points_per_voxel must be in [1, 254]");
+    // the search maps one lane of a 32-lane group to one stored point of a voxel: more than 32 per voxel would be stored and never examined
+    if (cfg->max_points_per_voxel < 1 || cfg->max_points_per_voxel > 32) return set_err(PTL_ERR_ARG, "max_points_per_voxel must be in [1, 32]");
     if (cfg->map_block_capacity < 1 || cfg->map_block_capacity >= (1 << 24) - 1) return set_err(PTL_ERR_ARG, "map_block_capacity must be below 2^24 - 1");
     if (cfg->map_table_capacity & (cfg->map_table_capacity - 1)) return set_err(PTL_ERR_ARG, "map_table_capacity must be a power of two");
     if (cfg->max_points_per_scan < 1 || cfg->gn_workgroups < 1 || cfg->gn_workgroups > 512) return set_err(PTL_ERR_ARG, "bad capacity (gn_workgroups must be in [1, 512])");
@@ -164,6 +165,20 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     if (cfg->gn_threads < 256 || cfg->gn_threads > GN_MAX_THREADS || (cfg->gn_threads & 63)) return set_err(PTL_ERR_ARG, "gn_threads must be a multiple of 64 in [256, GN_MAX_THREADS]");
     if (ptl_device_count() <= cfg->device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->device_id);
     HIPCHK(hipSetDevice(cfg->device_id));
+    {
+        // The Gauss-Newton kernel is persistent: its workgroups exchange sums every iteration, so ALL of them have to be
+        // resident at once.  Check that against the occupancy the runtime reports for this kernel on this device
+        // (partitioned GPU, fewer CUs, larger gn_threads) instead of finding out through a poll time-out.
+        int per_cu = 0, cus = 0;
+        const int P20 = cfg->max_points_per_voxel == 20;
+        hipError_t e = P20 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop<20, true>, cfg->gn_threads, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop<0, true>, cfg->gn_threads, 0);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
+        if (e != hipSuccess) return set_err(PTL_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
+        if ((int64_t)per_cu * cus < cfg->gn_workgroups)
+            return set_err(PTL_ERR_STATE, "gn_workgroups = %d x %d threads cannot be co-resident on device %d (%d CUs x %d workgroups per CU): "
+                           "lower gn_workgroups", cfg->gn_workgroups, cfg->gn_threads, cfg->device_id, cus, per_cu);
+    }
     ptl_icp* h = new ptl_icp();
     h->cfg = *cfg;
     h->own_stream = shared_stream == nullptr;
@@ -506,9 +521,8 @@ __global__ void k_set_gn(Ctx c, int n_src, double max_dist, double kernel, const
     DevState* st = c.st;
     if (threadIdx.x == 0) {
         st->n_src = n_src; st->gn_max_dist = max_dist; st->gn_kernel = kernel;
-        for (int g = 0; g < 8; ++g) { st->bar_grp[g * 32] = 0; st->bar_gen[g * 32] = 0; }
-        st->bar_top = 0;
         st->gn_epoch = (st->gn_epoch + 1u) & 0x3FFFFFu;
+        st->gn_abort = 0;
         if (guess) for (int i = 0; i < 16; ++i) st->guess[i] = guess[i];
         __threadfence_block();
     }
@@ -1124,7 +1138,6 @@ struct ptl_batch {
     unsigned char is_range;
     ptl_lut* lut;
     SeqCtx* d_ctx;
-    double* d_partials;
     int64_t next_scan, n_out;
     int64_t imu_pos[GN_MAX_SEQ];
     bool ctx_dirty;
@@ -1146,7 +1159,6 @@ extern "C" int ptl_batch_destroy(ptl_batch* b) {
             if (p) (void)hipFree(p);
     }
     if (b->d_ctx) (void)hipFree(b->d_ctx);
-    if (b->d_partials) (void)hipFree(b->d_partials);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -1156,12 +1168,13 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
     if (n_sequences < 1 || n_sequences > GN_MAX_SEQ) return set_err(PTL_ERR_ARG, "n_sequences must be in [1, %d]", GN_MAX_SEQ);
     if (cfg->n_scans < 1 || cfg->points_per_scan < 1) return set_err(PTL_ERR_ARG, "empty sequence");
+    if ((cfg->icp.gn_workgroups & 7) || cfg->icp.gn_workgroups > 512) return set_err(PTL_ERR_ARG, "batched runs need gn_workgroups = 8 x (workgroups per sequence <= 64)");
     if (ptl_device_count() <= cfg->icp.device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->icp.device_id);
     HIPCHK(hipSetDevice(cfg->icp.device_id));
     ptl_batch* b = new ptl_batch();
     b->cfg = *cfg;
     b->S = n_sequences;
-    b->stream = nullptr; b->d_ctx = nullptr; b->d_partials = nullptr; b->lut = nullptr; b->is_range = 0;
+    b->stream = nullptr; b->d_ctx = nullptr; b->lut = nullptr; b->is_range = 0;
     b->next_scan = 0; b->n_out = 0; b->ctx_dirty = true; b->prof = false; b->ev_used = 0; b->gn_ms = 0; b->gn_launches = 0;
     for (int s = 0; s < GN_MAX_SEQ; ++s) {
         b->icp[s] = nullptr; b->ekf[s] = nullptr; b->d_scans[s] = nullptr; b->d_imu[s] = nullptr;
@@ -1186,9 +1199,7 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
             rc = set_err(PTL_ERR_HIP, "batch allocation failed");
         b->imu_end[s].assign((size_t)cfg->n_scans, 0);
     }
-    if (rc == PTL_OK && (dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess ||
-                         dalloc(&b->d_partials, (size_t)2 * ic.gn_workgroups * GN_MAX_SEQ * 32) != hipSuccess))
-        rc = set_err(PTL_ERR_HIP, "batch allocation failed");
+    if (rc == PTL_OK && dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess) rc = set_err(PTL_ERR_HIP, "batch allocation failed");
     if (rc) { ptl_batch_destroy(b); return rc; }
     *out = b;
     return PTL_OK;
@@ -1300,19 +1311,9 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
             e0 = b->ev[b->ev_used++]; e1 = b->ev[b->ev_used++];
             HIPCHK(hipEventRecord(e0, st));
         }
-        {
-            GnBatch gb;
-            memset(&gb, 0, sizeof gb);
-            gb.S = S; gb.max_iter = ic.max_iterations;
-            for (int s = 0; s < S; ++s) {
-                const Ctx& c = b->icp[s]->c;
-                gb.q[s].src0 = c.src0; gb.q[s].src_cur = c.src_cur; gb.q[s].tab = c.tab; gb.q[s].blocks = c.blocks;
-                gb.q[s].st = c.st; gb.q[s].tmask = c.tmask; gb.q[s].bstride = c.bstride; gb.q[s].P = c.P;
-                gb.q[s].vs = c.vs; gb.q[s].conv = c.conv;
-            }
-            if (ic.max_points_per_voxel == 20) kb_gn_loop<20><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(gb, b->d_ctx, b->d_partials);
-            else kb_gn_loop<0><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(gb, b->d_ctx, b->d_partials);
-        }
+        // one sequence per XCD: workgroups with blockIdx & 7 == s run sequence s's loop with gn_workgroups / 8 workgroups
+        if (ic.max_points_per_voxel == 20) kx_gn_loop<20><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
+        else kx_gn_loop<0><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
         if (b->prof) HIPCHK(hipEventRecord(e1, st));
         kb_map_insert_a<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
         kb_map_insert_b<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);

@@ -45,6 +45,19 @@ def max_over_ranks(value: float, dist, device="cpu", group=None) -> float:
     return float(t.item())
 
 
+def poses_to_rows(t, poses):
+    """(T,), (T, 4, 4) -> (T, 8) NC-GT rows [t, x, y, z, qx, qy, qz, qw] (host-side twin of the rows the filter kernel
+    writes on device; used when the gather has to go through host memory)"""
+    from scipy.spatial.transform import Rotation
+    poses = np.asarray(poses, dtype=np.float64).reshape(-1, 4, 4)
+    rows = np.zeros((len(poses), 8))
+    if len(poses):
+        rows[:, 0] = np.asarray(t, dtype=np.float64)
+        rows[:, 1:4] = poses[:, :3, 3]
+        rows[:, 4:8] = Rotation.from_matrix(poses[:, :3, :3]).as_quat()
+    return rows
+
+
 def rows_to_poses(rows: np.ndarray):
     """(T, 8) NC-GT rows -> (t (T,), poses (T, 4, 4))"""
     from scipy.spatial.transform import Rotation

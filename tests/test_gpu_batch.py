@@ -1,4 +1,6 @@
-"""Batched runner: S sequences in lockstep on one GPU == S independent device-resident runs, bit for bit."""
+"""Batched runner: S sequences on one GPU, one XCD each (kx_gn_loop: the workgroups with blockIdx & 7 == s run sequence s's
+Gauss-Newton loop with one-hop exchange inside the XCD) == S independent device-resident runs with gn_workgroups / 8
+workgroups each, bit for bit."""
 import numpy as np
 import pytest
 
@@ -8,15 +10,16 @@ from ptudes_lab_amd import core, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("use_imu", [True, False])
-def test_batch_equals_independent_runs(use_imu):
-    S, n = 3, 10
+@pytest.mark.parametrize("use_imu,S", [(True, 3), (False, 3), (True, 8)])
+def test_batch_equals_independent_runs(use_imu, S):
+    n = 10
     seqs = [synth.make_sequence(seed=1010 + s, n_scans=n) for s in range(S)]
     n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
     b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=use_imu, with_ekf=True)
     singles = []
     for s, sq in enumerate(seqs):
-        r = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=use_imu, with_ekf=True)
+        # one sequence of the batch runs on 256 / 8 = 32 workgroups: the independent run it must equal uses 32 too
+        r = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=use_imu, with_ekf=True, gn_workgroups=32)
         ends = [sq.imu_range_for_scan(k)[1] for k in range(n)]
         for k in range(n):
             x = sq.scan(k)
@@ -43,3 +46,28 @@ def test_batch_rejects_missing_imu():
     b = core.BatchRunner(2, 3, 1024, 4, with_ekf=True, max_points_per_scan=1024, scan_cols=64)
     with pytest.raises(ValueError):
         b.upload_imu(0, np.zeros((4, 7)), [2, 2, 4])  # no IMU between scans 0 and 1
+
+
+def test_batch_rejects_bad_workgroup_count():
+    with pytest.raises(ValueError):
+        core.BatchRunner(2, 3, 1024, 4, with_ekf=True, max_points_per_scan=1024, scan_cols=64, gn_workgroups=100)
+
+
+def test_points_per_voxel_above_32_is_rejected_and_32_matches_the_oracle():
+    """the search maps one lane of a 32-lane group to one stored point of a voxel: 33 is refused; at 32 a
+    voxel's 32nd point is found"""
+    from oracle import cpu as orc
+    with pytest.raises(ValueError):
+        core.Icp(70.0, 1.0, max_points_per_voxel=33)
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(0.0, 0.69, (400, 3)) + np.array([7.0, 7.0, 0.7])  # one voxel, far more than 32 candidates
+    src = pts[31] + np.array([1e-3, 0.0, 0.0])                          # nearest stored point is the 32nd
+    icp = core.Icp(70.0, 1.0, max_points_per_voxel=32)
+    icp.map_add(pts)
+    m = orc.Map(0.7, 70.0, 32)
+    m.add_points(pts)
+    assert icp.map_size() == (m.num_voxels, m.num_points) == (1, 32)
+    sums, nc, cand = icp.linear_system(src[None], 2.0, 0.5)
+    ref = m.linear_system(src[None], 2.0, 0.5)
+    assert nc == 1 and cand == 32
+    assert np.allclose(sums, ref[0], rtol=1e-12, atol=1e-15)

@@ -30,3 +30,40 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "scans/s" and cb["sample"]
     assert d["parity_vs_oracle"]["max_dpos_m"] < 1e-9
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_on_distinct_sequences(tmp_path):
+    """the driver's plain `python bench.py --gpus 2`: two fresh ranks (sequences 1000 and 1001), no launcher.
+    On a 1-GPU box both ranks share GPU 0 (64 Gauss-Newton workgroups each; the gather then goes over gloo because RCCL
+    refuses two ranks on one device).  Each gathered trajectory equals the single-process run of that sequence."""
+    import numpy as np
+    import ptudes_lab_amd  # noqa: F401
+    from ptudes_lab_amd import core, synth
+    dump = str(tmp_path / "traj.npz")
+    K, W = 10, 4
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(K), "--warmup", str(W),
+                          "--gn-wgs", "64", "--dump-traj", dump], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == K and d["cpu_baseline"] is None
+    assert d["gathered_trajectories"]["sequences"] == 2 and d["gathered_trajectories"]["rows_each"] == [K + W]
+    assert len(d["per_rank_scans_per_s"]["values"]) == 2
+    assert abs(d["value"] - 2 * K / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    got = np.load(dump)
+    n = K + W
+    for r in range(2):
+        sq = synth.make_sequence(seed=1000 + r, n_scans=n)
+        n_imu = sq.imu_range_for_scan(n - 1)[1]
+        run = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=True, with_ekf=True, gn_workgroups=64)
+        for k in range(n):
+            run.upload_scan(k, sq.scan(k))
+        run.upload_imu(sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
+        run.run()
+        o = run.results()
+        rows = got[f"rank{r}_seq0"]
+        assert rows.shape == (n, 8)
+        assert np.array_equal(rows[:, 0], o["res_t"]) and np.array_equal(rows[:, 1:4], o["res_poses"][:, :3, 3])
+    assert not np.array_equal(got["rank0_seq0"][:, 1:4], got["rank1_seq0"][:, 1:4])

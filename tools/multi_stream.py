@@ -1,8 +1,8 @@
 """several independent sequences on one GPU, one persistent-GN stream each (ptl_seq_enqueue / ptl_seq_wait):
-throughput against workgroups per sequence.   python tools_multi_stream.py S G [T]"""
+throughput against workgroups per sequence.   python tools/multi_stream.py S G [T]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ptudes_lab_amd  # noqa
 from ptudes_lab_amd import core, synth
 

@@ -1,7 +1,7 @@
 """per-call drop-in API rate: KissICPWrapper.register_frame + ESEKF.processImu / processPose driven from host arrays,
 one call per event as the reference's loop does (PCIe upload and a host round trip per call included)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ptudes_lab_amd  # noqa
 from ptudes_lab_amd.cli.ekf_bench import _synthetic_source
 from ptudes_lab_amd.sequence import run_events

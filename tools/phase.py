@@ -2,11 +2,11 @@
 
 Needs a library built with the clocks compiled in:  make -C ptudes-lab_amd/csrc clean && make -C ptudes-lab_amd/csrc PHASES=1
 (the default build leaves them out: they cost registers and serialise on s_memtime; all values then read 0).
-    python tools_phase.py [gn_workgroups gn_threads]
+    python tools/phase.py [gn_workgroups gn_threads]
 """
 import sys, ctypes as C, numpy as np
 import os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ptudes_lab_amd
 from ptudes_lab_amd import core, synth, _lib as L
 n=60

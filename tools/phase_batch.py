@@ -1,5 +1,5 @@
 import sys, ctypes as C, numpy as np
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ptudes_lab_amd
 from ptudes_lab_amd import core, synth, _lib as L
 S=int(sys.argv[1]); n=40

@@ -1,9 +1,9 @@
 """Which HIP runtime the product library ends up on when torch is in the process, and what that costs.
-usage: tools_torch_order.py MODE [bench args]   MODE: plain | torch_first | torch_cuda_first | lib_first"""
+usage: tools/torch_order.py MODE [bench args]   MODE: plain | torch_first | torch_cuda_first | lib_first"""
 import os, sys
 mode = sys.argv[1]
 sys.argv = ["bench.py"] + sys.argv[2:]
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if mode == "torch_first":
     import torch
 elif mode == "torch_cuda_first":
