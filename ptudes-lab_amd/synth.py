@@ -253,3 +253,91 @@ def make_sequence(seed=1000, n_scans=100, H=128, W=1024, *, min_range=1.0, max_r
                     boxes=boxes_w, cyls=cyls_w, min_range=min_range, max_range=max_range,
                     noise_std=noise_std, dropout=dropout, rough_amp=rough_amp, rough_len=rough_len, traj_dt=traj_dt, traj_R=Rm, traj_p=p_w, traj_vw=vw,
                     traj_wb=wb, imu=imu, imu_bias_acc=b_a, imu_bias_gyr=b_g)
+
+
+def make_path_sequence(seed=2000, n_scans=100, H=128, W=1024, *, step_m=0.5, static_sweeps=0, ramp_sweeps=0, yaw_rate=0.0,
+                       min_range=1.0, max_range=70.0, noise_std=0.0, dropout=0.0, scan_hz=10.0, t_base=1626432000.0,
+                       room_size=None, n_boxes=None, n_cyls=None, rough_amp=0.15, rough_len=1.5, imu_noise=(0.0, 0.0),
+                       clear_halfwidth=4.0, wobble_deg=0.0, wobble_hz=1.3, heave_m=0.0):
+    """A controlled sequence for tracking experiments (not SURVEY.md 8(d)'s random walk): the sensor drives along +x at
+    `step_m` metres per sweep (0.05 = walking pace, 1.0 = 10 m/s vehicle speed), optionally standing still for the first
+    `static_sweeps` sweeps (no un-deskewed motion baked into the first map), accelerating over `ramp_sweeps` sweeps
+    (smoothstep; 0 = the speed is there from t = 0), optionally yawing at `yaw_rate` rad/s and rocking like a sprung
+    vehicle: roll / pitch of `wobble_deg` amplitude at `wobble_hz` (and 0.77 of it), heave of `heave_m` - scaled by the
+    current speed fraction, so a standing vehicle stands still.  The scene is a hall long
+    enough for the drive (default: path length + 80 m by 60 m by 15 m) with the obstacle density of make_sequence and a
+    clear lane of +-`clear_halfwidth` m around the path.  Range noise and dropout default to none."""
+    rng = np.random.default_rng(seed)
+    scan_dt = 1.0 / scan_hz
+    path_len = step_m * max(n_scans + 1 - static_sweeps, 0)
+    if room_size is None:
+        room_size = (max(80.0, path_len + 80.0), 60.0, 15.0)
+    lx, ly, lz = room_size
+    area_ratio = (lx * ly) / (80.0 * 60.0)
+    n_boxes = int(round(40 * area_ratio)) if n_boxes is None else n_boxes
+    n_cyls = int(round(20 * area_ratio)) if n_cyls is None else n_cyls
+    height = 1.5
+    p0 = np.array([-lx / 2 + 40.0, 0.0, height])
+    boxes = np.zeros((n_boxes, 6))
+    for b in range(n_boxes):
+        h = rng.uniform(0.5, 6.0, 3) / 2
+        while True:
+            cy = rng.uniform(-ly / 2 + 3, ly / 2 - 3)
+            if abs(cy) - h[1] > clear_halfwidth:
+                break
+        boxes[b] = [rng.uniform(-lx / 2 + 3, lx / 2 - 3), cy, h[2], *h]
+    cyls = np.zeros((n_cyls, 4))
+    for c in range(n_cyls):
+        r = rng.uniform(0.5, 6.0) / 2
+        while True:
+            cy = rng.uniform(-ly / 2 + 3, ly / 2 - 3)
+            if abs(cy) - r > clear_halfwidth:
+                break
+        cyls[c] = [rng.uniform(-lx / 2 + 3, lx / 2 - 3), cy, r, rng.uniform(0.5, 6.0)]
+    traj_dt = 1e-3
+    n_steps = int(round((n_scans + 1) * scan_dt / traj_dt)) + 2
+    t = np.arange(n_steps) * traj_dt
+    v_full = step_m / scan_dt
+    t0 = static_sweeps * scan_dt
+    if ramp_sweeps > 0:
+        u = np.clip((t - t0) / (ramp_sweeps * scan_dt), 0.0, 1.0)
+        speed = v_full * u * u * (3 - 2 * u)
+    else:
+        speed = np.where(t >= t0, v_full, 0.0)
+    x = np.concatenate([[0.0], np.cumsum(0.5 * (speed[1:] + speed[:-1]) * traj_dt)])
+    p_w = np.zeros((n_steps, 3))
+    p_w[:, 0] = x
+    vw = np.zeros((n_steps, 3))
+    vw[:, 0] = speed
+    yaw = yaw_rate * np.maximum(t - t0, 0.0)
+    frac = speed / v_full if v_full > 0 else np.zeros_like(speed)
+    roll = np.radians(wobble_deg) * frac * np.sin(2 * np.pi * wobble_hz * t + 0.7)
+    pitch = np.radians(wobble_deg) * frac * np.sin(2 * np.pi * 0.77 * wobble_hz * t + 2.1)
+    rot = Rotation.from_euler("zyx", np.stack([yaw, pitch, roll], axis=1))
+    Rm = rot.as_matrix()
+    p_w[:, 2] = heave_m * frac * np.sin(2 * np.pi * 1.19 * wobble_hz * t)
+    vw = np.gradient(p_w, traj_dt, axis=0)
+    # body angular rate from consecutive attitudes
+    rel = (rot[:-1].inv() * rot[1:]).as_rotvec() / traj_dt
+    wb = np.concatenate([rel, rel[-1:]], axis=0)
+    room = np.array([-lx / 2, lx / 2, -ly / 2, ly / 2, 0.0, lz])
+    room[0:2] -= p0[0]
+    room[2:4] -= p0[1]
+    room[4:6] -= p0[2]
+    boxes[:, :3] -= p0
+    cyls[:, :2] -= p0[:2]
+    a_w = np.gradient(vw, traj_dt, axis=0)
+    g = np.array([0.0, 0.0, -GRAV])
+    b_a = np.array([0.05, -0.02, 0.03])
+    b_g = np.array([0.002, -0.001, 0.0015])
+    stride = int(round(0.01 / traj_dt))
+    idx = np.arange(0, int(round(n_scans * scan_dt / 0.01))) * stride
+    f_b = np.einsum("nji,nj->ni", Rm[idx], a_w[idx] - g)
+    imu = np.empty((len(idx), 7))
+    imu[:, 0] = t_base + idx * traj_dt
+    imu[:, 1:4] = f_b + b_a + rng.normal(0, 1.0, (len(idx), 3)) * imu_noise[0]
+    imu[:, 4:7] = wb[idx] + b_g + rng.normal(0, 1.0, (len(idx), 3)) * imu_noise[1]
+    return Sequence(H=H, W=W, n_scans=n_scans, seed=seed, scan_dt=scan_dt, t_base=t_base, room=room, boxes=boxes, cyls=cyls,
+                    min_range=min_range, max_range=max_range, noise_std=noise_std, dropout=dropout, rough_amp=rough_amp,
+                    rough_len=rough_len, traj_dt=traj_dt, traj_R=Rm, traj_p=p_w, traj_vw=vw, traj_wb=wb, imu=imu,
+                    imu_bias_acc=b_a, imu_bias_gyr=b_g)
