@@ -181,7 +181,7 @@ def workload_key(args, S):
     """what a PMC pass has to have been collected on to speak for this run"""
     return (f"{args.rows}x{args.cols}_r{args.min_range:g}-{args.max_range:g}_v{(args.voxel_size or args.max_range / 100):g}_"
             f"seed{args.seed_base}_S{S}_W{args.warmup}_K{args.steps}_{'cv' if args.const_velocity else 'imu'}"
-            f"{'' if not args.icp_only else '_icponly'}")
+            f"{'' if not args.icp_only else '_icponly'}{'' if not args.gn_lanes else '_L%d' % args.gn_lanes}")
 
 
 def main():
@@ -204,6 +204,7 @@ def main():
     ap.add_argument("--icp-only", action="store_true", help="no IMU / EKF at all (BASELINE config 2): constant-velocity guess")
     ap.add_argument("--gn-wgs", type=int, default=0, help="workgroups of the persistent GN kernel (0 = library default)")
     ap.add_argument("--gn-threads", type=int, default=0)
+    ap.add_argument("--gn-lanes", type=int, default=0, help="lanes per source point of the GN kernel: 32 | 8 (0 = the runner's default)")
     ap.add_argument("--voxel-size", type=float, default=0.0, help="override the map voxel size (default max_range/100)")
     ap.add_argument("--map-blocks", type=int, default=0, help="voxel-block pool capacity")
     ap.add_argument("--map-table", type=int, default=0, help="map hash-table slots (power of two)")
@@ -261,6 +262,7 @@ def main():
     icp_over = dict(scan_cols=args.cols)
     if args.gn_wgs: icp_over["gn_workgroups"] = args.gn_wgs
     if args.gn_threads: icp_over["gn_threads"] = args.gn_threads
+    if args.gn_lanes: icp_over["gn_lanes_per_point"] = args.gn_lanes
     if args.voxel_size: icp_over["voxel_size"] = args.voxel_size
     if args.map_blocks: icp_over["map_block_capacity"] = args.map_blocks
     if args.map_table: icp_over["map_table_capacity"] = args.map_table
@@ -413,7 +415,7 @@ def main():
                          "frac": achieved / HBM_PEAK, "traffic": pmc[0] if pmc else None,
                          "traffic_source": pmc[1] if pmc else None,
                          "measured_frac": (pmc[0] / avg_gn_s / HBM_PEAK) if (pmc and avg_gn_s > 0) else None,
-                         "kernel": "k_gn_loop" if S == 1 else "kx_gn_loop",
+                         "kernel": ("k_gn_loop8" if args.gn_lanes == 8 else "k_gn_loop") if S == 1 else ("kx_gn_loop" if args.gn_lanes == 32 else "kx_gn_loop8"),
                          "avg_launch_us": 1e6 * avg_gn_s, "algorithmic_bytes_per_launch": avg_gn_bytes,
                          "launches": gn_n, "timed_launches": f"every {ev_every}th of {K} (HIP events)",
                          "note": "frac = ALGORITHMIC bytes (SURVEY 8(d): 27 probes x 16 B + every candidate x 12 B + the source, per "

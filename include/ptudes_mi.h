@@ -67,6 +67,9 @@ typedef struct {
     int32_t gn_workgroups;        /* workgroups of the persistent Gauss-Newton kernel */
     int32_t rebuild_every;        /* rebuild the map hash table every this many scans (drops tombstones) */
     int32_t gn_threads;           /* threads per workgroup of that kernel (multiple of 64, 256..1024) */
+    int32_t gn_lanes_per_point;   /* 32: latency form (one point per 32 lanes, one sequence over the whole chip);
+                                   * 8: throughput form (8 points per wavefront, moment accumulation, one-hop exchange;
+                                   * needs gn_workgroups <= 64) - what the batched runner uses per sequence */
 } ptl_icp_cfg;
 
 /* per-scan counters; identical meaning to oracle/oracle.h orc_icp_stats (SURVEY.md 8(d) byte model) */
@@ -159,6 +162,8 @@ int ptl_icp_gn_phases(ptl_icp *h, int64_t out[8]);
 /* diagnostic: ticks each Gauss-Newton workgroup spent in the search phase since creation; out holds 2 * gn_workgroups
  * values (until the last / the first wavefront finished) */
 int ptl_icp_gn_wg_clocks(ptl_icp *h, int64_t *out, int32_t max_wgs);
+/* diagnostic: the device state's 32 debug sums (phase-clock builds park sub-step clocks there) */
+int ptl_icp_debug_sums(ptl_icp *h, double out[32]);
 /* test hook: set the 22-bit launch epoch of the Gauss-Newton exchange (exercises its wrap-around) */
 int ptl_icp_debug_set_epoch(ptl_icp *h, uint32_t epoch);
 
@@ -235,10 +240,12 @@ int ptl_seq_icp(ptl_seq *s, ptl_icp **icp);
 int ptl_seq_profile(ptl_seq *s, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
 
 /* ------------------------------------------------------------------------------------------------
- * Batched runner: up to 8 independent sequences on ONE GPU advanced in lockstep.  Every stage is one launch for
- * all sequences and their Gauss-Newton loops share one persistent launch (one grid barrier per iteration for all
- * of them); each sequence's results are bit-identical to running it alone.  cfg describes every sequence
- * (same n_scans / points_per_scan / n_imu); with_ekf requires >= 1 IMU sample between consecutive scans.
+ * Batched runner: up to 8 independent sequences on ONE GPU, one XCD each.  Every stage is one launch for all
+ * sequences; in the persistent Gauss-Newton launch the workgroups with blockIdx & 7 == s own sequence s (its map, probe
+ * rows and exchange stay in that XCD's L2; it leaves the loop on its own convergence).  Each sequence's results are
+ * bit-identical to running it alone with gn_workgroups / 8 workgroups and the same gn_lanes_per_point.  cfg describes
+ * every sequence (same n_scans / points_per_scan / n_imu; gn_workgroups = 8 x workgroups per sequence); with_ekf
+ * requires >= 1 IMU sample between consecutive scans.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ptl_batch ptl_batch;
 int ptl_batch_create(const ptl_seq_cfg *cfg, int32_t n_sequences, ptl_batch **out);
@@ -254,6 +261,7 @@ int ptl_batch_results(ptl_batch *b, int32_t seq, double *res_poses, double *res_
                       ptl_icp_stats *stats, int64_t max_n, int64_t *n_out);
 int ptl_batch_copy_traj(ptl_batch *b, int32_t seq, void *dst_device, int64_t max_rows, int64_t *rows);
 int ptl_batch_gn_phases(ptl_batch *b, int64_t out[8]); /* like ptl_icp_gn_phases, for the shared launch */
+int ptl_batch_icp(ptl_batch *b, int32_t seq, ptl_icp **icp); /* the ICP handle of one sequence (diagnostics, map export) */
 int ptl_batch_profile(ptl_batch *b, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
 
 #ifdef __cplusplus

@@ -23,7 +23,7 @@ class IcpCfg(C.Structure):
                 ("convergence", C.c_double), ("device_id", C.c_int32), ("scan_cols", C.c_int32),
                 ("max_points_per_scan", C.c_int64), ("map_block_capacity", C.c_int64),
                 ("map_table_capacity", C.c_int64), ("gn_workgroups", C.c_int32), ("rebuild_every", C.c_int32),
-                ("gn_threads", C.c_int32)]
+                ("gn_threads", C.c_int32), ("gn_lanes_per_point", C.c_int32)]
 
 
 class IcpStats(C.Structure):
@@ -68,6 +68,7 @@ PROTOTYPES = {
     "ptl_icp_gn_wg_clocks": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int32]),
     "ptl_range_stats": (C.c_int, [C.c_int, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, c_d_p]),
     "ptl_icp_debug_set_epoch": (C.c_int, [_vp, C.c_uint32]),
+    "ptl_icp_debug_sums": (C.c_int, [_vp, c_d_p]),
     "ptl_icp_deskew": (C.c_int, [_vp, c_d_p, c_d_p, C.c_int64, c_d_p]),
     "ptl_icp_map_add": (C.c_int, [_vp, c_d_p, C.c_int64, c_d_p, C.c_int]),
     "ptl_icp_linear_system": (C.c_int, [_vp, c_d_p, C.c_int64, C.c_double, C.c_double, c_d_p, c_i64_p, c_i64_p]),
@@ -118,6 +119,7 @@ PROTOTYPES = {
     "ptl_batch_results": (C.c_int, [_vp, C.c_int32, c_d_p, c_d_p, c_d_p, C.POINTER(IcpStats), C.c_int64, c_i64_p]),
     "ptl_batch_copy_traj": (C.c_int, [_vp, C.c_int32, _vp, C.c_int64, c_i64_p]),
     "ptl_batch_gn_phases": (C.c_int, [_vp, c_i64_p]),
+    "ptl_batch_icp": (C.c_int, [_vp, C.c_int32, _vpp]),
     "ptl_batch_profile": (C.c_int, [_vp, C.c_int, c_d_p, c_i64_p, C.c_int]),
 }
 

@@ -331,12 +331,16 @@ class SeqRunner:
 
 
 class BatchRunner:
-    """Up to 8 independent sequences on one GPU in lockstep (one launch per stage for all of them, one shared
-    persistent Gauss-Newton launch).  Per-sequence results are bit-identical to `SeqRunner`."""
+    """Up to 8 independent sequences on one GPU, one XCD each (one launch per stage for all of them; in the persistent
+    Gauss-Newton launch the workgroups with blockIdx & 7 == s own sequence s).  Per-sequence results are bit-identical to
+    `SeqRunner(..., gn_workgroups=G / 8, gn_lanes_per_point=<the batch's>)`."""
 
     def __init__(self, n_sequences, n_scans, points_per_scan, n_imu, *, max_range=70.0, min_range=1.0,
                  use_imu_prediction=False, with_ekf=True, device_id=0, ekf=None, **icp_over):
         cfg = L.SeqCfg()
+        icp_over.setdefault("gn_lanes_per_point", 8)  # a workgroup walks ~200 points per iteration here: the throughput form
+        if icp_over["gn_lanes_per_point"] == 8:
+            icp_over.setdefault("gn_threads", 512)
         cfg.icp = icp_cfg(max_range, min_range, device_id=device_id, **icp_over)
         cfg.ekf = ekf if ekf is not None else ekf_cfg(device_id=device_id)
         cfg.n_scans, cfg.points_per_scan, cfg.n_imu = n_scans, points_per_scan, n_imu

@@ -120,6 +120,7 @@ struct Ctx {
     const double* ext_guess;  // device 4x4 or null
     unsigned long long* pc_key;  // [n_max]      multi-pass probe cache: voxel key of source point i at its last probe
     int* pc_pb;                  // [n_max][32]  and the 27 probe results (block id | count << 24, -1 = absent)
+    double* pc_ans;              // [n_max][8]   8-lane kernel: exact answer cache (s0 | t | slack^2 | candidate count)
     unsigned long long* gn_rows_ll;  // [2][G][64]      per-workgroup sums as (32 data bits | 32 flag bits) words
     unsigned long long* gn_xsum_ll;  // [2][8][8][64]   per-group sums, one copy per consumer slot
     int overlap_pre;          // the next scan's K0-K4 run beside this scan's map update (own stream): see flush_map_stats
@@ -1238,6 +1239,545 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
     gn_loop_body<PC, MC, false>(c, mode, (int)gridDim.x, (int)blockIdx.x);
 }
 
+
+// ================================================================================================ K5, 8 lanes per point
+// Throughput form of the Gauss-Newton loop for workgroups that walk MANY source points per iteration (the batched
+// runner: one sequence per XCD, ~200 points per workgroup and iteration).  The 32-lanes-per-point search above is
+// VALU-issue-bound - every lane executes the whole search for a voxel that holds 7-8 points on average - so this one
+// gives a point 8 lanes (8 points per wavefront):
+//   * a voxel is scanned in chunks of 8 stored points (lane l <-> point base + l), group reductions are three DPP steps
+//     inside the VALU (quad permutes + half-row mirror), nothing goes through the LDS crossbar;
+//   * the 27 probe results of a point live in its 128-byte row in memory (lane l holds entries 4 l .. 4 l + 3; entry 27 =
+//     the voxel of the last winner, entry 28 = the candidate count of the 27 voxels), re-probed only when the point has
+//     changed voxel;
+//   * the exact pruning of nn_scan32 (own voxel + last winner's voxel first, box distance against the bound, survivors in
+//     turn) and its (distance, visiting order) minimum: the SAME correspondence for every point;
+//   * the linear system is accumulated as 16 moments sum w z_a z_b over z = (1, s, r, s x r) instead of 27 products picked
+//     per lane:  JTJ = [[ W I, -hat(Ws) ], [ ., tr(S) I - S ]] with W = sum w, Ws = sum w s, S = sum w s s^T, and
+//     JTr = [ sum w r ; sum w s x r ]  (J = [I | -hat(s)], Registration.cpp BuildLinearSystem); lane l of a group
+//     accumulates moments l and l + 8 with operands read from a 10-entry table its lane 0 wrote to LDS.
+// Same weights, same gate, same correspondences as the 32-lane kernel; the sums differ from it in association only
+// (agreement with the oracle at the 1e-9 relative level of the other kernels, poses far below the 1e-9 m bar).
+// Rows travel through the one-hop exchange (G <= 64 workgroups, all polled by everybody).
+__device__ __forceinline__ double group_min8(double v) {
+    v = fmin(v, dpp_f64<0xB1>(v));   // lane ^ 1
+    v = fmin(v, dpp_f64<0x4E>(v));   // lane ^ 2
+    return fmin(v, dpp_f64<0x141>(v));  // row_half_mirror: lane i <-> 7 - i of each 8 (every quad holds its minimum already)
+}
+__device__ __forceinline__ unsigned group_min8(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+    return min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int group_sum8(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    return v + __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+}
+// the value one lane of the group holds (everybody else passes 0.0): x + 0 = x exactly, so a sum is a broadcast
+__device__ __forceinline__ double group_bcast8(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    return v + dpp_f64<0x141>(v);
+}
+__device__ __forceinline__ int sel4(int e0, int e1, int e2, int e3, int q) { return q == 0 ? e0 : q == 1 ? e1 : q == 2 ? e2 : e3; }
+
+// Stored voxels against the point, lane l <-> stored points l, l + 8, l + 16 (P <= 24: every load of the call is in flight
+// before the first distance is formed - one memory round trip per call instead of one per chunk of 8).  sd = smallest
+// distance this lane has seen lose.  NV voxels per call (the first round takes the point's own voxel and the last
+// winner's together).
+template <int PC, int NV, class CT>
+__device__ __forceinline__ void scan_voxels8(const CT& c, const int (&pb)[NV], const int (&vx)[NV], V3 s, int lane8, double& bd, double& sd,
+                                             unsigned& border, V3& bp) {
+    const int P = (PC > 0) ? PC : c.P;
+    if (P <= 24) {
+        double q[NV][3][3];
+        bool act[NV][3];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int cnt = (pb[v] < 0) ? 0 : (int)((unsigned)pb[v] >> 24);
+            const double* X = blk_x(c, pb[v] & BLK_ID_MASK);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int idx = 8 * k + lane8;
+                act[v][k] = idx < cnt;
+                q[v][k][0] = act[v][k] ? X[idx] : 0.0;
+                q[v][k][1] = act[v][k] ? X[P + idx] : 0.0;
+                q[v][k][2] = act[v][k] ? X[2 * P + idx] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (act[v][k]) {
+                    const double dx = q[v][k][0] - s.x, dy = q[v][k][1] - s.y, dz = q[v][k][2] - s.z;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    const unsigned id = (unsigned)(vx[v] * 32 + 8 * k + lane8);
+                    if (d2 < bd || (d2 == bd && id < border)) { sd = fmin(sd, bd); bd = d2; border = id; bp = v3(q[v][k][0], q[v][k][1], q[v][k][2]); }
+                    else sd = fmin(sd, d2);
+                }
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int cnt = (pb[v] < 0) ? 0 : (int)((unsigned)pb[v] >> 24);
+            const double* X = blk_x(c, pb[v] & BLK_ID_MASK);
+            for (int base = 0; __any(base < cnt); base += 8) {
+                const int idx = base + lane8;
+                if (idx < cnt) {
+                    const double qx = X[idx], qy = X[P + idx], qz = X[2 * P + idx];
+                    const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    const unsigned id = (unsigned)(vx[v] * 32 + idx);
+                    if (d2 < bd || (d2 == bd && id < border)) { sd = fmin(sd, bd); bd = d2; border = id; bp = v3(qx, qy, qz); }
+                    else sd = fmin(sd, d2);
+                }
+            }
+        }
+    }
+}
+
+// packed upper triangle of JTJ (21) + JTr (6) from the 16 moments
+//   M: 0 W | 1..3 W s | 4 xx 5 xy 6 xz 7 yy 8 yz 9 zz | 10..12 sum w r | 13..15 sum w s x r
+__device__ __forceinline__ double sums_from_moments(int e, const double* M) {
+    switch (e) {
+        case 0: case 6: case 11: return M[0];           // (0,0) (1,1) (2,2)
+        case 4: return M[3];                            // (0,4) = +W sz
+        case 5: return -M[2];                           // (0,5) = -W sy
+        case 8: return -M[3];                           // (1,3)
+        case 10: return M[1];                           // (1,5) = +W sx
+        case 12: return M[2];                           // (2,3) = +W sy
+        case 13: return -M[1];                          // (2,4)
+        case 15: return M[7] + M[9];                    // (3,3) = yy + zz
+        case 16: return -M[5];                          // (3,4) = -xy
+        case 17: return -M[6];                          // (3,5) = -xz
+        case 18: return M[4] + M[9];                    // (4,4) = xx + zz
+        case 19: return -M[8];                          // (4,5) = -yz
+        case 20: return M[4] + M[7];                    // (5,5) = xx + yy
+        case 21: case 22: case 23: return M[10 + (e - 21)];
+        case 24: case 25: case 26: return M[13 + (e - 24)];
+        default: return 0.0;                            // (0,1) (0,2) (0,3) (1,2) (1,4) (2,5)
+    }
+}
+
+#define GN8_ROW_ENTRIES 18   /* 16 moments, pair count, candidate count */
+#ifndef GN8_MAX_THREADS
+#define GN8_MAX_THREADS 512  /* 8 wavefronts per workgroup: 256 VGPRs per lane, nothing spills (at 768 / 168 VGPRs the search spills ~50) */
+#endif
+// one correspondence into a lane's 16 moments (+ pair count): w z_a z_b over z = (1, s, r, s x r)
+__device__ __forceinline__ void gn8_accumulate(double (&M)[GN8_ROW_ENTRIES], V3 s, V3 t, double kern, double k2) {
+    const V3 rr = v3(s.x - t.x, s.y - t.y, s.z - t.z);
+    const double den = kern + (rr.x * rr.x + rr.y * rr.y + rr.z * rr.z);
+    const double w = k2 / (den * den);  // Registration.cpp: square(kernel) / square(kernel + residual2)
+    const double cx = s.y * rr.z - s.z * rr.y, cy = s.z * rr.x - s.x * rr.z, cz = s.x * rr.y - s.y * rr.x;
+    M[0] += w;
+    M[1] += w * s.x; M[2] += w * s.y; M[3] += w * s.z;
+    M[4] += w * (s.x * s.x); M[5] += w * (s.x * s.y); M[6] += w * (s.x * s.z);
+    M[7] += w * (s.y * s.y); M[8] += w * (s.y * s.z); M[9] += w * (s.z * s.z);
+    M[10] += w * rr.x; M[11] += w * rr.y; M[12] += w * rr.z;
+    M[13] += w * cx; M[14] += w * cy; M[15] += w * cz;
+    M[16] += 1.0;
+}
+template <int PC>
+__device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G, const int wg) {
+    __shared__ int missq[GN8_MAX_THREADS];            // points of this chunk whose answer row did not settle them, compacted
+    __shared__ int wsum[GN8_MAX_THREADS / 64];
+    __shared__ double part[GN8_ROW_ENTRIES][16];
+    __shared__ double redL8[64][GN8_ROW_ENTRIES];     // everybody's rows (G != 32)
+    __shared__ double mom[GN8_ROW_ENTRIES];
+    __shared__ double tot[32];
+    __shared__ double Esh2[2][12];
+    __shared__ double Tsh[12];
+    __shared__ int flag_done2[2];
+    __shared__ long long cand_total_sh;
+    DevState* st = c.st;
+    const int tid = threadIdx.x, lane8 = tid & 7, grp8 = tid >> 3, lane32 = tid & 31, grp32 = tid >> 5;
+    const int NT = blockDim.x, NG8 = blockDim.x >> 3, NG32 = blockDim.x >> 5, NW = blockDim.x >> 6;
+    const int n = st->n_src;
+    const unsigned epoch = st->gn_epoch;
+    if (wg == 0 && tid == 0 && mode == 0) flush_map_stats(c, st);
+    if (st->n_live == 0) {  // voxel_map.Empty() => return initial_guess
+        if (wg == 0 && tid == 0) {
+            Rt I = rt_identity();
+            rt_to16(I, st->T_icp);
+            st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0;
+            gn_post(c, st, true, mode == 0);
+        }
+        return;
+    }
+    const double kern = st->gn_kernel, k2 = kern * kern;
+    const double gate2 = sqrt_gate(st->gn_max_dist);
+    const double conv2 = sqrt_gate(c.conv);
+    const double inv_vs = 1.0 / c.vs;
+    if (tid < 12) {
+        const double* g16 = guess_src(c);
+        Esh2[1][tid] = (tid < 9) ? g16[4 * (tid / 3) + (tid % 3)] : g16[4 * (tid - 9) + 3];
+        Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
+    }
+    if (tid == NT - 1) cand_total_sh = 0;
+    __syncthreads();
+    // contiguous scan-order share of this workgroup (a band of beams: its voxels stay in the L1 / L2 it uses)
+    const int per_wg = (n + G - 1) / G;
+    const int first = wg * per_wg, last = (first + per_wg < n) ? first + per_wg : n;
+    // the direction (di, dj, dk) of this lane's four row entries, 2 bits per axis: 0 = -1, 1 = 0, 2 = +1
+    int dcode[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = 4 * lane8 + q;
+        dcode[q] = (e < 27) ? ((e / 9) | (((e / 3) % 3) << 2) | ((e % 3) << 4)) : -1;
+    }
+    int iters = 0;
+    long long ph_miss = 0, ph_a = 0, pb_t[5] = {0, 0, 0, 0, 0};
+    long long ph[5] = {0, 0, 0, 0, 0};  // (only with -DGN_PHASE_CLOCKS) point loop | wg reduce + publish | exchange | - | totals + solve
+    for (int it = 0; it < c.max_iter; ++it) {
+        const long long c0 = GN_CLK();
+        const double* Esh = Esh2[(it + 1) & 1];
+        if (tid == 64 && it > 0) gn_compose(Esh, Tsh);
+        double M[GN8_ROW_ENTRIES];
+#pragma unroll
+        for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
+        for (int cbase = first; cbase < last; cbase += NT) {
+            // ---- phase A, ONE LANE PER POINT (one pass, one memory round trip): apply the increment, look at the point's
+            // answer row.  The last full search of the point (at s0, same voxel => same 27-voxel candidate set) found t at
+            // distance d0 and every other candidate - scanned, or inside a dropped voxel's box - at >= D.  After a move by
+            // delta = |s - s0| the triangle inequality leaves t the strict winner while d0 + delta < D - delta, and then a
+            // full search would return exactly t: the pair goes straight into this lane's sums.  Row: s0 (3) | t (3) |
+            // ((D - d0) / 2)^2 with a safety factor, < 0 = no answer | candidate count of the 27 voxels.  The distance, the
+            // gate and the weight come from the current s either way - same values as after a search.
+            {
+                const int i = cbase + tid;
+                int miss = -1;
+                if (i < last) {
+                    Rt E;
+                    for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
+                    for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
+                    const double* sp0 = (it == 0) ? c.src0 : c.src_cur;
+                    const V3 s = rt_apply(E, v3(sp0[3 * (size_t)i], sp0[3 * (size_t)i + 1], sp0[3 * (size_t)i + 2]));
+                    c.src_cur[3 * (size_t)i] = s.x; c.src_cur[3 * (size_t)i + 1] = s.y; c.src_cur[3 * (size_t)i + 2] = s.z;
+                    miss = i;
+                    if (it > 0) {
+                        const unsigned long long old_key = c.pc_key[i];
+                        const double2* row = (const double2*)(c.pc_ans + 8 * (size_t)i);
+                        const double2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];  // s0.xy | s0.z t.x | t.yz | slack^2, count
+                        const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
+                        const double ex = s.x - r0.x, ey = s.y - r0.y, ez = s.z - r1.x;
+                        const double delta2 = ex * ex + ey * ey + ez * ez;
+                        if (old_key == pack_key(kx, ky, kz) && delta2 < r3.x) {  // (slack^2 < 0: never)
+                            const V3 t = v3(r1.y, r2.x, r2.y);
+                            const double dx = t.x - s.x, dy = t.y - s.y, dz = t.z - s.z;
+                            const double m = dx * dx + dy * dy + dz * dz;  // the expression the search evaluates for this candidate
+                            M[17] += r3.y;
+                            if (m < gate2) gn8_accumulate(M, s, t, kern, k2);
+                            miss = -1;
+                        }
+                    }
+                }
+                missq[tid] = miss;
+            }
+            __syncthreads();
+            // compaction of the noted points in point order (deterministic): wavefront scan, wavefront offsets
+            int nmiss;
+            {
+                const int mine1 = missq[tid], cnt = mine1 >= 0 ? 1 : 0;
+                int incl = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if ((tid & 63) >= o) incl += u; }
+                if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+                __syncthreads();
+                int woff = 0, total = 0;
+                for (int w = 0; w < NW; ++w) { const int v = wsum[w]; if (w < (tid >> 6)) woff += v; total += v; }
+                nmiss = total;
+#ifdef GN_PHASE_CLOCKS
+                ph_miss += total; ph_a += GN_CLK() - c0;
+#endif
+                if (cnt) missq[woff + incl - 1] = mine1;  // (a slot at or below the own one: everybody has read its slot)
+                __syncthreads();
+            }
+            // ---- phase B, 8 LANES PER POINT: the full search of the noted points, 8 of them per wavefront
+            for (int k = grp8; __any(k < nmiss); k += NG8) {
+              if (k < nmiss) {
+                const long long b0 = GN_CLK();
+                const int i = missq[k];
+                const V3 s = v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]);
+                const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
+                const unsigned long long key = pack_key(kx, ky, kz);
+                // the point's probe row: lane l holds entries 4 l .. 4 l + 3 (requested together with the key that validates it)
+                int4 r = *(const int4*)(c.pc_pb + 32 * (size_t)i + 4 * lane8);
+                const bool same_voxel = it > 0 && c.pc_key[i] == key;
+                if (!same_voxel) {  // uniform over the group: probe this lane's four neighbour voxels, rebuild the row
+                    int e[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ee = 4 * lane8 + q;
+                        e[q] = (ee < 27) ? map_find(c, pack_key(kx + ee / 9 - 1, ky + (ee / 3) % 3 - 1, kz + ee % 3 - 1)) : -1;
+                    }
+                    int cs = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cs += (e[q] < 0) ? 0 : (int)((unsigned)e[q] >> 24);
+                    cs = group_sum8(cs);
+                    if (lane8 == 6) e[3] = -1;  // entry 27: no last winner yet
+                    if (lane8 == 7) e[0] = cs;  // entry 28: candidates of the 27 voxels
+                    r = make_int4(e[0], e[1], e[2], e[3]);
+                    *(int4*)(c.pc_pb + 32 * (size_t)i + 4 * lane8) = r;
+                    if (lane8 == 0) c.pc_key[i] = key;
+                }
+                const long long b1 = GN_CLK();
+                const int gb = (tid & 63) & ~7;  // first lane of this group within the wavefront
+                const int lv_raw = __shfl(r.w, gb + 6);
+                const int ctot = __shfl(r.x, gb + 7);
+                const int lv = (lv_raw != 13) ? lv_raw : -1;
+                const int pbc = __shfl(r.y, gb + 3);  // entry 13: the point's own voxel
+                const int pbl = (lv >= 0) ? __shfl(sel4(r.x, r.y, r.z, r.w, lv & 3), gb + (lv >> 2)) : -1;
+                double bd = 1.7976931348623157e308, sd = 1.7976931348623157e308;
+                unsigned border = 0xFFFFFFFFu;
+                V3 bp = v3(0, 0, 0);
+                // squared distance from the point to the box of each of this lane's (stored) neighbour voxels: it depends on
+                // the point alone, so it is known before anything is loaded
+                double gap2[4];
+                {
+                    double g2m[3], g2p[3];
+                    const int kk[3] = {kx, ky, kz};
+                    const double xx[3] = {s.x, s.y, s.z};
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const int vm = kk[ax] - 1, vp = kk[ax] + 1;
+                        const int bim = (vm < 0) ? vm : vm + 1, bip = (vp > 0) ? vp : vp - 1;
+                        const double gm = fmax(-((double)bim * c.vs - xx[ax]) - 1e-9, 0.0), gp = fmax(((double)bip * c.vs - xx[ax]) - 1e-9, 0.0);
+                        g2m[ax] = gm * gm; g2p[ax] = gp * gp;
+                    }
+                    const int ent[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ee = 4 * lane8 + q;
+                        gap2[q] = 1.7976931348623157e308;  // not a candidate voxel: absent, the own one, the last winner's, no voxel
+                        if (dcode[q] < 0 || ee == 13 || ee == lv || ent[q] < 0) continue;
+                        const int cx = dcode[q] & 3, cy = (dcode[q] >> 2) & 3, cz = (dcode[q] >> 4) & 3;
+                        const double gx = cx == 0 ? g2m[0] : cx == 1 ? 0.0 : g2p[0];
+                        const double gy = cy == 0 ? g2m[1] : cy == 1 ? 0.0 : g2p[1];
+                        const double gz = cz == 0 ? g2m[2] : cz == 1 ? 0.0 : g2p[2];
+                        gap2[q] = (gx + gy) + gz;
+                    }
+                }
+                // first round: the own voxel, the last winner's and the two nearest other boxes - the voxels a better point
+                // could most likely sit in - with all their loads in flight together (a voxel scanned although its box turns
+                // out to lie beyond the best distance is harmless: it is one of the 27)
+                unsigned spec = 0xFFFFFFFFu;  // the entries taken speculatively: v_a | v_b << 8
+                {
+                    int vsel[2], psel[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        double gl = 1.7976931348623157e308;
+                        int ql = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (gap2[q] < gl) { gl = gap2[q]; ql = q; }
+                        const double gmin = group_min8(gl);
+                        const unsigned v = group_min8((gl == gmin && gmin < 1.0e300) ? (unsigned)(4 * lane8 + ql) : 0xFFu);
+                        vsel[u] = (v == 0xFFu) ? -1 : (int)v;
+                        psel[u] = (v == 0xFFu) ? -1 : __shfl(sel4(r.x, r.y, r.z, r.w, (int)(v & 3u)), gb + (int)((v >> 2) & 7u));
+                        if (v != 0xFFu && (int)(v >> 2) == lane8) {  // taken: no longer a candidate of the later rounds
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (q == (int)(v & 3u)) gap2[q] = 1.7976931348623157e308;
+                        }
+                    }
+                    spec = (unsigned)(vsel[0] & 0xFF) | ((unsigned)(vsel[1] & 0xFF) << 8);
+                    const int pb4[4] = {pbc, pbl, psel[0], psel[1]}, vx4[4] = {13, lv, vsel[0], vsel[1]};
+                    scan_voxels8<PC, 4>(c, pb4, vx4, s, lane8, bd, sd, border, bp);
+                }
+                const long long b2 = GN_CLK();
+                // the other voxels: dropped when their box lies farther than the best distance so far (exact, see nn_scan32)
+                unsigned mine = 0u;
+                double gdrop = 1.7976931348623157e308;  // smallest squared box distance among the voxels this lane dropped
+                {
+                    const double m0 = group_min8(bd);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (!(gap2[q] < 1.0e300)) continue;
+                        if (gap2[q] > m0) gdrop = fmin(gdrop, gap2[q]); else mine |= 1u << q;
+                    }
+                }
+                for (;;) {  // the surviving voxels, two at a time (their loads in flight together)
+                    unsigned cand = mine ? (unsigned)(4 * lane8 + __ffs(mine) - 1) : 0xFFu;
+                    const unsigned v0 = group_min8(cand);
+                    if (v0 == 0xFFu) break;  // uniform over the group
+                    if ((int)(v0 >> 2) == lane8) mine &= mine - 1u;
+                    cand = mine ? (unsigned)(4 * lane8 + __ffs(mine) - 1) : 0xFFu;
+                    const unsigned v1 = group_min8(cand);
+                    if (v1 != 0xFFu && (int)(v1 >> 2) == lane8) mine &= mine - 1u;
+                    const int p0 = __shfl(sel4(r.x, r.y, r.z, r.w, (int)(v0 & 3u)), gb + (int)(v0 >> 2));
+                    const int p1 = (v1 != 0xFFu) ? __shfl(sel4(r.x, r.y, r.z, r.w, (int)(v1 & 3u)), gb + (int)((v1 >> 2) & 7u)) : -1;
+                    const int pb2[2] = {p0, p1}, vx2[2] = {(int)v0, (int)v1};
+                    scan_voxels8<PC, 2>(c, pb2, vx2, s, lane8, bd, sd, border, bp);
+                }
+                const long long b3 = GN_CLK();
+                const double m = group_min8(bd);
+                const bool found = m < 1.7976931348623157e308;
+                const unsigned bo = group_min8((bd == m) ? border : 0xFFFFFFFFu);
+                const bool win = found && bd == m && border == bo;
+                const V3 t = v3(group_bcast8(win ? bp.x : 0.0), group_bcast8(win ? bp.y : 0.0), group_bcast8(win ? bp.z : 0.0));
+                const int lv_new = found ? (int)(bo >> 5) : -1;
+                if (lane8 == 6 && lv_new != lv_raw) c.pc_pb[32 * (size_t)i + 27] = lv_new;
+                // the answer row: everybody else is at least sqrt(D2) away
+                const double D2 = group_min8(fmin(win ? sd : bd, gdrop));
+                double sl2 = -1.0;
+                if (found && D2 < 1.0e300) {
+                    const double slack = 0.5 * (sqrt(D2) - sqrt(m)) * (1.0 - 1e-6);
+                    if (slack > 1e-6) sl2 = slack * slack;
+                } else if (found) {
+                    sl2 = 1.0e300;  // the only candidate in reach of this voxel
+                }
+                const double av = lane8 == 0 ? s.x : lane8 == 1 ? s.y : lane8 == 2 ? s.z : lane8 == 3 ? t.x : lane8 == 4 ? t.y : lane8 == 5 ? t.z
+                                : lane8 == 6 ? sl2 : (double)ctot;
+                c.pc_ans[8 * (size_t)i + lane8] = av;
+                if (lane8 == 0) {
+                    M[17] += (double)ctot;
+                    if (found && m < gate2) gn8_accumulate(M, s, t, kern, k2);
+                }
+#ifdef GN_PHASE_CLOCKS
+                { const long long b4 = GN_CLK(); pb_t[0] += b1 - b0; pb_t[1] += b2 - b1; pb_t[2] += b3 - b2; pb_t[3] += b4 - b3; pb_t[4] += 1; }
+#endif
+              }
+            }
+            __syncthreads();  // the queue is reused by the next chunk
+        }
+        const long long c1 = GN_CLK();
+        // ---- workgroup reduction, fixed tree: the 64 lanes of a wavefront (DPP inside the rows, two crossbar steps across
+        // them), then the wavefronts in order
+#pragma unroll
+        for (int e = 0; e < GN8_ROW_ENTRIES; ++e) {
+            double v = M[e];
+            v += dpp_f64<0xB1>(v);   // lane ^ 1
+            v += dpp_f64<0x4E>(v);   // lane ^ 2
+            v += dpp_f64<0x141>(v);  // half-row mirror
+            v += dpp_f64<0x140>(v);  // row mirror
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            M[e] = v;
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int e = 0; e < GN8_ROW_ENTRIES; ++e) part[e][tid >> 6] = M[e];
+        }
+        __syncthreads();
+        const unsigned flag = gn_flag(epoch, it);
+        const int par = it & 1, ngroups = G < 8 ? G : 8;
+        bool ok = true;
+        if (tid < 2 * GN8_ROW_ENTRIES) {
+            const int e = tid >> 1;
+            double rowv = 0.0;
+            for (int j = 0; j < NW; ++j) rowv += part[e][j];
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(rowv);
+            const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+            __hip_atomic_store(&c.gn_rows_ll[((size_t)par * G + wg) * GN_LL_WORDS + tid],
+                               (unsigned long long)half | ((unsigned long long)flag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const long long c2 = GN_CLK();
+        // ---- one-hop exchange.  G == 32 (the batched runner's share of an XCD): the FIRST WAVEFRONT alone polls all 32 rows -
+        // lane w <-> word w of every row, the 32 loads of a round in flight together - adds them in (group, member) order in
+        // registers and solves straight away: no LDS staging, no workgroup barrier between the last arrival and the
+        // factorisation.  Other G: every 32-lane group polls one row into LDS, then the sums.
+        long long c3 = c2;
+        if (G == 32) {
+            if (tid < 64) {
+                const bool mine = tid < 2 * GN8_ROW_ENTRIES;
+                unsigned h[32];
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned bad = 0u;
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        unsigned long long vv = (unsigned long long)flag << 32;
+                        if (mine) vv = __hip_atomic_load(c.gn_rows_ll + ((size_t)par * 32 + j) * GN_LL_WORDS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        bad |= (unsigned)(vv >> 32) ^ flag;
+                        h[j] = (unsigned)vv;
+                    }
+                    if (__all(bad == 0u)) break;
+                    ++spins;
+                    if (spins > GN_LL_SPINS || ((spins & 1023u) == 0u && gn_abort_seen(&st->gn_abort))) { ok = false; break; }
+                }
+                double t = 0.0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    t += (((0.0 + gn_ll_join(h[g])) + gn_ll_join(h[g + 8])) + gn_ll_join(h[g + 16])) + gn_ll_join(h[g + 24]);
+                if (mine && (tid & 1) == 0) mom[tid >> 1] = t;
+                if (!ok && tid == 0) gn_raise_abort(st);
+                c3 = GN_CLK();
+            }
+        } else {
+            for (int j = grp32; j < G; j += NG32) {
+                const unsigned long long* row = c.gn_rows_ll + ((size_t)par * G + j) * GN_LL_WORDS;
+                unsigned h0, h1;
+                gn_ll_wait2(row + lane32, row + lane32 + 32, lane32 + 32 < 2 * GN8_ROW_ENTRIES, flag, &h0, &h1, &ok, &st->gn_abort);
+                const double v0 = gn_ll_join(h0), v1 = gn_ll_join(h1);
+                if ((lane32 & 1) == 0) {
+                    redL8[j][lane32 >> 1] = v0;
+                    if (16 + (lane32 >> 1) < GN8_ROW_ENTRIES) redL8[j][16 + (lane32 >> 1)] = v1;
+                }
+            }
+            if (!ok) gn_raise_abort(st);
+            ok = __syncthreads_or(ok ? 0 : 1) == 0;
+            c3 = GN_CLK();
+            if (tid < GN8_ROW_ENTRIES) {
+                double t = 0.0;
+                for (int g = 0; g < ngroups; ++g) {
+                    double sg = 0.0;
+                    for (int j = g; j < G; j += 8) sg += redL8[j][tid];
+                    t += sg;
+                }
+                mom[tid] = t;
+            }
+        }
+        if (tid < 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (tid < 27) tot[tid] = sums_from_moments(tid, mom);
+            else if (tid == 27) tot[27] = mom[16];
+            else if (tid == 28) tot[28] = mom[17];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double dx[6];
+            solve6_ldlt_wave(tot, tid, dx);
+            if (tid == 0) {
+                const Rt e = se3_exp_gn(dx);
+                for (int k = 0; k < 9; ++k) Esh2[it & 1][k] = e.R[k];
+                for (int k = 0; k < 3; ++k) Esh2[it & 1][9 + k] = e.t[k];
+                double nn = 0.0;
+                for (int k = 0; k < 6; ++k) nn += dx[k] * dx[k];
+                flag_done2[it & 1] = (nn < conv2 || !ok) ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        const long long c5 = GN_CLK();
+        ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += c5 - c3;
+        if (tid == NT - 1) cand_total_sh += (long long)tot[28];
+        iters = it + 1;
+        if (flag_done2[it & 1]) break;
+    }
+    if (tid == 64 && iters > 0) gn_compose(Esh2[(iters - 1) & 1], Tsh);
+    __syncthreads();
+    if (tid == 0 && c.wg_clk) { c.wg_clk[wg] += ph[0]; c.wg_clk[G + wg] += ph_miss; }
+    if (wg == 0 && tid == 0) {
+        Rt T;
+        for (int k = 0; k < 9; ++k) T.R[k] = Tsh[k];
+        for (int k = 0; k < 3; ++k) T.t[k] = Tsh[9 + k];
+        rt_to16(T, st->T_icp);
+        st->gn_iters = iters;
+        st->gn_ncorr = iters > 0 ? (int)tot[27] : 0;
+        st->gn_cand = cand_total_sh;
+        for (int k = 0; k < 5; ++k) st->gn_phase_clk[k] += ph[k];
+        st->gn_phase_clk[5] += iters;
+        st->gn_phase_clk[6] += ph_miss; st->gn_phase_clk[7] += ph_a;
+#ifdef GN_PHASE_CLOCKS
+        for (int k = 0; k < 5; ++k) st->dbg_sums[k] += (double)pb_t[k];
+#endif
+        gn_post(c, st, false, mode == 0);
+    }
+}
+// one sequence, 8 lanes per point (gn_workgroups <= 64: one-hop exchange)
+template <int PC>
+__global__ __launch_bounds__(GN8_MAX_THREADS) void k_gn_loop8(Ctx c, int mode) {
+    gn8_body<PC>(c, mode, (int)gridDim.x, (int)blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------ K7-K9
 // AddPoints, phase a: world transform, find-or-create the voxel's table entry, join its batch list.
 // `pose` null => points are already in the world frame (stage-level API)
@@ -1314,20 +1854,26 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
 __device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, int n_fixed) {
     const int n = n_ptr ? *n_ptr : n_fixed;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (c.prank[i] != 0) return;
-    const int slot = c.pslot[i];
-    const int pb = c.tab[slot].blk;
-    c.tab[slot].head = -1;
-    if (pb < 0) return;
-    const int b = pb & BLK_ID_MASK;
-    int* h = blk_hdr(c, b);
-    const int cnt = h[0];
-    int nc = cnt + c.plen[i];
-    if (nc > c.P) nc = c.P;
-    h[0] = nc;
-    c.tab[slot].blk = b | (nc << 24);  // the table entry mirrors the count so a probe returns both
-    atomicAdd((unsigned long long*)&c.st->map_points, (unsigned long long)(nc - cnt));
+    int added = 0;
+    if (i < n && c.prank[i] == 0) {
+        const int slot = c.pslot[i];
+        const int pb = c.tab[slot].blk;
+        c.tab[slot].head = -1;
+        if (pb >= 0) {
+            const int b = pb & BLK_ID_MASK;
+            int* h = blk_hdr(c, b);
+            const int cnt = h[0];
+            int nc = cnt + c.plen[i];
+            if (nc > c.P) nc = c.P;
+            h[0] = nc;
+            c.tab[slot].blk = b | (nc << 24);  // the table entry mirrors the count so a probe returns both
+            added = nc - cnt;
+        }
+    }
+    // one atomic per wavefront: tens of thousands of same-address atomics serialise at the memory side (225 us for 8
+    // sequences in one launch, measured)
+    for (int o = 32; o > 0; o >>= 1) added += __shfl_xor(added, o);
+    if ((threadIdx.x & 63) == 0 && added) atomicAdd((unsigned long long*)&c.st->map_points, (unsigned long long)added);
 }
 
 // ------------------------------------------------------------------------------------------------ K10
@@ -1459,9 +2005,11 @@ struct SeqCtx {
     const float* scan_base;        // sweeps of this sequence, resident in HBM
     long long scan_stride_floats;  // floats between consecutive sweeps
     int input_is_range, pad;
+    double* fd_buf[2];             // frame_down of scan k lives in buffer k & 1: the map update of scan k reads it while K3 of scan k + 1 writes the other
 };
 __device__ __forceinline__ Ctx load_seq_ctx(const SeqCtx* a, int s, int scan_k) {
     Ctx c = a[s].c;
+    c.fd = a[s].fd_buf[scan_k & 1];
     const float* p = a[s].scan_base + (size_t)scan_k * (size_t)a[s].scan_stride_floats;
     if (a[s].input_is_range) { c.in_range = (const unsigned*)p; c.in_f32 = nullptr; }
     else { c.in_f32 = p; c.in_range = nullptr; }
@@ -1526,6 +2074,13 @@ __global__ __launch_bounds__(256) void kb_map_rebuild(const SeqCtx* a, int scan_
 // the loop on its own convergence.  Per sequence the point -> workgroup assignment, the reduction trees and the
 // arithmetic are those of k_gn_loop launched alone with gridDim / 8 workgroups: bit-identical results.
 #define GN_MAX_SEQ 8
+template <int PC>
+__global__ __launch_bounds__(GN8_MAX_THREADS) void kx_gn_loop8(const SeqCtx* a, int S, int scan_k) {
+    const int s = (int)(blockIdx.x & 7u);
+    if (s >= S) return;
+    const Ctx c = load_seq_ctx(a, s, scan_k);
+    gn8_body<PC>(c, 0, (int)(gridDim.x >> 3), (int)(blockIdx.x >> 3));
+}
 template <int PC>
 __global__ __launch_bounds__(GN_MAX_THREADS) void kx_gn_loop(const SeqCtx* a, int S, int scan_k) {
     const int s = (int)(blockIdx.x & 7u);

@@ -93,6 +93,7 @@ extern "C" int ptl_icp_default_cfg(ptl_icp_cfg* cfg, double max_range, double mi
     cfg->gn_workgroups = 256;
     cfg->rebuild_every = 16;
     cfg->gn_threads = 1024;
+    cfg->gn_lanes_per_point = 32;
     return PTL_OK;
 }
 
@@ -104,7 +105,7 @@ static int icp_free(ptl_icp* h) {
     (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
     void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, h->fd_buf[0], h->fd_buf[1], c.src0,
-                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.wg_clk, c.pc_key, c.pc_pb, c.gn_rows_ll, c.gn_xsum_ll,
+                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.wg_clk, c.pc_key, c.pc_pb, c.pc_ans, c.gn_rows_ll, c.gn_xsum_ll,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter, h->d_row_mask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -154,7 +155,7 @@ static int icp_reset_device(ptl_icp* h) {
     return PTL_OK;
 }
 
-static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, ptl_icp** out) {
+static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, ptl_icp** out, bool batch_member = false) {
     if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
     // the search maps one lane of a 32-lane group to one stored point of a voxel: more than 32 per voxel would be stored and never examined
     if (cfg->max_points_per_voxel < 1 || cfg->max_points_per_voxel > 32) return set_err(PTL_ERR_ARG, "max_points_per_voxel must be in [1, 32]");
@@ -163,6 +164,9 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     if (cfg->max_points_per_scan < 1 || cfg->gn_workgroups < 1 || cfg->gn_workgroups > 512) return set_err(PTL_ERR_ARG, "bad capacity (gn_workgroups must be in [1, 512])");
     if (cfg->max_iterations < 1 || cfg->max_iterations > 1000) return set_err(PTL_ERR_ARG, "max_iterations must be in [1, 1000]");
     if (cfg->gn_threads < 256 || cfg->gn_threads > GN_MAX_THREADS || (cfg->gn_threads & 63)) return set_err(PTL_ERR_ARG, "gn_threads must be a multiple of 64 in [256, GN_MAX_THREADS]");
+    if (cfg->gn_lanes_per_point != 32 && cfg->gn_lanes_per_point != 8) return set_err(PTL_ERR_ARG, "gn_lanes_per_point must be 32 or 8");
+    if (cfg->gn_lanes_per_point == 8 && cfg->gn_threads > GN8_MAX_THREADS) return set_err(PTL_ERR_ARG, "gn_lanes_per_point = 8 runs at most %d threads per workgroup", GN8_MAX_THREADS);
+    if (cfg->gn_lanes_per_point == 8 && !batch_member && cfg->gn_workgroups > 64) return set_err(PTL_ERR_ARG, "gn_lanes_per_point = 8 uses the one-hop exchange: gn_workgroups <= 64");
     if (ptl_device_count() <= cfg->device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->device_id);
     HIPCHK(hipSetDevice(cfg->device_id));
     {
@@ -171,8 +175,13 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
         // (partitioned GPU, fewer CUs, larger gn_threads) instead of finding out through a poll time-out.
         int per_cu = 0, cus = 0;
         const int P20 = cfg->max_points_per_voxel == 20;
-        hipError_t e = P20 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop<20, true>, cfg->gn_threads, 0)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop<0, true>, cfg->gn_threads, 0);
+        hipError_t e;
+        if (cfg->gn_lanes_per_point == 8)
+            e = P20 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop8<20>, cfg->gn_threads, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop8<0>, cfg->gn_threads, 0);
+        else
+            e = P20 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop<20, true>, cfg->gn_threads, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop<0, true>, cfg->gn_threads, 0);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
         if (e != hipSuccess) return set_err(PTL_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
         if ((int64_t)per_cu * cus < cfg->gn_workgroups)
@@ -235,7 +244,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= dalloc(&c.tab, (size_t)cfg->map_table_capacity) == hipSuccess;
     ok &= hipMalloc((void**)&c.blocks, (size_t)c.pool_cap * c.bstride) == hipSuccess;
     ok &= dalloc(&c.free_stack, c.pool_cap) == hipSuccess;
-    ok &= dalloc(&c.pc_key, n) == hipSuccess && dalloc(&c.pc_pb, 32 * n) == hipSuccess;
+    ok &= dalloc(&c.pc_key, n) == hipSuccess && dalloc(&c.pc_pb, 32 * n) == hipSuccess && dalloc(&c.pc_ans, 8 * n) == hipSuccess;
     ok &= hipHostMalloc((void**)&h->n_src_hint, sizeof(int)) == hipSuccess;
     if (h->n_src_hint) *h->n_src_hint = 0;
     ok &= dalloc(&c.gn_rows_ll, (size_t)2 * c.G * 64) == hipSuccess && hipMemset(c.gn_rows_ll, 0, (size_t)2 * c.G * 64 * 8) == hipSuccess;
@@ -334,7 +343,8 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     // ends with the post-ICP bookkeeping (kiss.py:116-128).  Dense scans (more source points than 32-lane groups) run the
     // variant that keeps probe results in memory; the previous scan's N_s, copied back without a wait, is the hint
     const bool dense = *h->n_src_hint > (int64_t)c.G * (h->cfg.gn_threads / 32);
-    if (c.P == 20) { if (dense) k_gn_loop<20, true><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<20, false><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
+    if (h->cfg.gn_lanes_per_point == 8) { if (c.P == 20) k_gn_loop8<20><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop8<0><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
+    else if (c.P == 20) { if (dense) k_gn_loop<20, true><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<20, false><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
     else { if (dense) k_gn_loop<0, true><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<0, false><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
     if (timed) HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipEventRecord(h->ev_gn, s));
@@ -588,6 +598,14 @@ extern "C" int ptl_icp_gn_wg_clocks(ptl_icp* h, int64_t* out, int32_t max_wgs) {
     return PTL_OK;
 }
 
+// diagnostic: the 32 debug sums of the handle's device state (phase-clock builds park sub-step clocks there)
+extern "C" int ptl_icp_debug_sums(ptl_icp* h, double out[32]) {
+    if (!h || !out) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(out, (char*)h->c.st + offsetof(DevState, dbg_sums), 256, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PTL_OK;
+}
 // diagnostic: accumulated per-phase clock ticks of workgroup 0 in the GN loop since the handle was reset
 // out[0..4] = nn, wg-reduce+publish, barrier, grid-reduce, solve; out[5] = iterations
 extern "C" int ptl_icp_gn_phases(ptl_icp* h, int64_t out[8]) {
@@ -1129,6 +1147,11 @@ struct ptl_batch {
     ptl_seq_cfg cfg;
     int S;
     hipStream_t stream;
+    // the map update and the filter step of scan k run on `side` beside K0-K4 of scan k + 1 (both need only the GN result);
+    // the GN launch of scan k + 1 waits for them
+    hipStream_t side;
+    hipEvent_t ev_gn, ev_side;
+    bool ev_side_valid;
     ptl_icp* icp[GN_MAX_SEQ];
     ptl_ekf* ekf[GN_MAX_SEQ];
     float* d_scans[GN_MAX_SEQ];
@@ -1160,6 +1183,9 @@ extern "C" int ptl_batch_destroy(ptl_batch* b) {
     }
     if (b->d_ctx) (void)hipFree(b->d_ctx);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+    if (b->ev_gn) (void)hipEventDestroy(b->ev_gn);
+    if (b->ev_side) (void)hipEventDestroy(b->ev_side);
+    if (b->side) (void)hipStreamDestroy(b->side);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return PTL_OK;
@@ -1181,7 +1207,10 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
         b->d_res_poses[s] = nullptr; b->d_res_t[s] = nullptr; b->d_rows[s] = nullptr; b->imu_pos[s] = 0;
     }
     int rc = PTL_OK;
+    b->side = nullptr; b->ev_gn = nullptr; b->ev_side = nullptr; b->ev_side_valid = false;
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { delete b; return set_err(PTL_ERR_HIP, "stream"); }
+    if (hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&b->ev_gn, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_side, hipEventDisableTiming) != hipSuccess) { ptl_batch_destroy(b); return set_err(PTL_ERR_HIP, "stream / event creation failed"); }
     ptl_icp_cfg ic = cfg->icp;
     if (ic.max_points_per_scan < cfg->points_per_scan) ic.max_points_per_scan = cfg->points_per_scan;
     b->cfg.icp = ic;
@@ -1189,7 +1218,7 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     ec.device_id = ic.device_id;
     const size_t nim = cfg->n_imu > 0 ? (size_t)cfg->n_imu : 1;
     for (int s = 0; s < b->S && rc == PTL_OK; ++s) {
-        rc = icp_create_impl(&ic, b->stream, &b->icp[s]);
+        rc = icp_create_impl(&ic, b->stream, &b->icp[s], true);
         if (rc == PTL_OK) rc = ekf_create_impl(&ec, b->stream, &b->ekf[s]);
         while (rc == PTL_OK && b->icp[s]->traj_cap < cfg->n_scans) rc = icp_grow_traj(b->icp[s]);
         if (rc == PTL_OK &&
@@ -1249,13 +1278,14 @@ static int batch_push_ctx(ptl_batch* b) {
         Ctx c = b->icp[s]->c;
         c.in_f32 = nullptr; c.in_f64 = nullptr; c.in_range = nullptr; c.t01 = nullptr;
         c.n_in = (int)b->cfg.points_per_scan;
-        c.overlap_pre = 0;  // one stream: the prologue is ordered after the previous map update
+        c.overlap_pre = 1;  // the prologue of scan k + 1 runs beside the map update of scan k (side stream)
         c.ext_guess = (with_ekf && b->cfg.use_imu_prediction) ? (const double*)((char*)b->ekf[s]->st + offsetof(EkfState, pose)) : nullptr;
         if (b->is_range) { c.lut_dir = b->lut->dir; c.lut_off = b->lut->off; c.row_mask = b->icp[s]->d_row_mask; }
         h[s].c = c;
         h[s].scan_base = b->d_scans[s];
         h[s].scan_stride_floats = (long long)b->cfg.points_per_scan * 3;
         h[s].input_is_range = b->is_range;
+        h[s].fd_buf[0] = b->icp[s]->fd_buf[0]; h[s].fd_buf[1] = b->icp[s]->fd_buf[1];
     }
     HIPCHK(hipMemcpyAsync(b->d_ctx, h, sizeof h, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1272,6 +1302,9 @@ static int batch_reset(ptl_batch* b) {
     }
     b->next_scan = 0;
     b->n_out = 0;
+    HIPCHK(hipStreamSynchronize(b->side));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->ev_side_valid = false;
     return PTL_OK;
 }
 extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
@@ -1296,7 +1329,10 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
                 any = any || ea.i1[s] > ea.i0[s];
                 b->imu_pos[s] = b->imu_end[s][(size_t)k] > b->imu_pos[s] ? b->imu_end[s][(size_t)k] : b->imu_pos[s];
             }
-            if (any) kb_ekf_step<<<S, 384, 0, st>>>(ea);
+            if (any) {
+                if (b->ev_side_valid) HIPCHK(hipStreamWaitEvent(st, b->ev_side, 0));
+                kb_ekf_step<<<S, 384, 0, st>>>(ea);
+            }
         }
         const int ki = (int)k;
         kb_scan_prologue<<<dim3(1, S), 1024, 0, st>>>(b->d_ctx, ki);
@@ -1304,6 +1340,7 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
         kb_vds2<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
         kb_compact_fd<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
         kb_compact_src<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        if (b->ev_side_valid) HIPCHK(hipStreamWaitEvent(st, b->ev_side, 0));  // the previous scan's map update and filter step
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (b->prof) {
             if (b->ev_used + 2 > b->ev.size())
@@ -1312,15 +1349,17 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
             HIPCHK(hipEventRecord(e0, st));
         }
         // one sequence per XCD: workgroups with blockIdx & 7 == s run sequence s's loop with gn_workgroups / 8 workgroups
-        if (ic.max_points_per_voxel == 20) kx_gn_loop<20><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
+        if (ic.gn_lanes_per_point == 8) {
+            if (ic.max_points_per_voxel == 20) kx_gn_loop8<20><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
+            else kx_gn_loop8<0><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
+        } else if (ic.max_points_per_voxel == 20) kx_gn_loop<20><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
         else kx_gn_loop<0><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
         if (b->prof) HIPCHK(hipEventRecord(e1, st));
-        kb_map_insert_a<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
-        kb_map_insert_b<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
-        kb_map_insert_c<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
-        kb_map_prune<<<dim3((unsigned)((ic.map_block_capacity + 255) / 256), S), 256, 0, st>>>(b->d_ctx, ki);
+        HIPCHK(hipEventRecord(b->ev_gn, st));
+        hipStream_t sd = b->side;
+        HIPCHK(hipStreamWaitEvent(sd, b->ev_gn, 0));
         const int64_t o = b->n_out;
-        if (with_ekf) {
+        if (with_ekf) {  // first: its pose is the next scan's guess
             EkfBatchArgs ea;
             memset(&ea, 0, sizeof ea);
             for (int s = 0; s < S; ++s) {
@@ -1332,18 +1371,24 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
                 b->imu_pos[s] = e2;
             }
             ea.update_first = 1;
-            kb_ekf_step<<<S, 384, 0, st>>>(ea);
+            kb_ekf_step<<<S, 384, 0, sd>>>(ea);
         }
+        kb_map_insert_a<<<dim3(nb, S), 256, 0, sd>>>(b->d_ctx, ki);
+        kb_map_insert_b<<<dim3(nb, S), 256, 0, sd>>>(b->d_ctx, ki);
+        kb_map_insert_c<<<dim3(nb, S), 256, 0, sd>>>(b->d_ctx, ki);
+        kb_map_prune<<<dim3((unsigned)((ic.map_block_capacity + 255) / 256), S), 256, 0, sd>>>(b->d_ctx, ki);
         for (int s = 0; s < S; ++s) { b->icp[s]->scans_done++; b->icp[s]->last_n = pps; }
         b->n_out++;
         b->next_scan = k + 1;
         if (ic.rebuild_every > 0 && (b->n_out % ic.rebuild_every) == 0) {
             for (int s = 0; s < S; ++s) {
-                HIPCHK(hipMemsetAsync(b->icp[s]->c.tab, 0xFF, ((size_t)b->icp[s]->c.tmask + 1) * sizeof(TabEnt), st));
-                HIPCHK(hipMemsetAsync(&b->icp[s]->c.st->tab_used, 0, sizeof(unsigned), st));
+                HIPCHK(hipMemsetAsync(b->icp[s]->c.tab, 0xFF, ((size_t)b->icp[s]->c.tmask + 1) * sizeof(TabEnt), sd));
+                HIPCHK(hipMemsetAsync(&b->icp[s]->c.st->tab_used, 0, sizeof(unsigned), sd));
             }
-            kb_map_rebuild<<<dim3((unsigned)((ic.map_block_capacity + 255) / 256), S), 256, 0, st>>>(b->d_ctx, ki);
+            kb_map_rebuild<<<dim3((unsigned)((ic.map_block_capacity + 255) / 256), S), 256, 0, sd>>>(b->d_ctx, ki);
         }
+        HIPCHK(hipEventRecord(b->ev_side, sd));
+        b->ev_side_valid = true;
     }
     HIPCHK(hipGetLastError());
     return PTL_OK;
@@ -1352,6 +1397,7 @@ extern "C" int ptl_batch_wait(ptl_batch* b) {
     if (!b) return set_err(PTL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
     int flags[GN_MAX_SEQ] = {0};
+    HIPCHK(hipStreamSynchronize(b->side));
     for (int s = 0; s < b->S; ++s) {
         k_finish_scan<<<1, 64, 0, b->stream>>>(b->icp[s]->c);
         HIPCHK(hipMemcpyAsync(&flags[s], &b->icp[s]->c.st->err_flags, sizeof(int), hipMemcpyDeviceToHost, b->stream));
@@ -1380,6 +1426,7 @@ extern "C" int ptl_batch_results(ptl_batch* b, int32_t s, double* res_poses, dou
     if (!b || s < 0 || s >= b->S) return set_err(PTL_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
     const int64_t n = b->n_out < max_n ? b->n_out : max_n;
+    HIPCHK(hipStreamSynchronize(b->side));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (n > 0) {
         if (res_poses && b->cfg.with_ekf) HIPCHK(hipMemcpy(res_poses, b->d_res_poses[s], (size_t)n * 128, hipMemcpyDeviceToHost));
@@ -1399,9 +1446,15 @@ extern "C" int ptl_batch_copy_traj(ptl_batch* b, int32_t s, void* dst_device, in
     if (!b->cfg.with_ekf) return set_err(PTL_ERR_STATE, "trajectory rows need with_ekf");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
     const int64_t n = b->n_out < max_rows ? b->n_out : max_rows;
+    HIPCHK(hipStreamSynchronize(b->side));
     if (n > 0) HIPCHK(hipMemcpyAsync(dst_device, b->d_rows[s], (size_t)n * 64, hipMemcpyDeviceToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (rows) *rows = n;
+    return PTL_OK;
+}
+extern "C" int ptl_batch_icp(ptl_batch* b, int32_t s, ptl_icp** icp) {
+    if (!b || !icp || s < 0 || s >= b->S) return set_err(PTL_ERR_ARG, "bad argument");
+    *icp = b->icp[s];
     return PTL_OK;
 }
 extern "C" int ptl_batch_gn_phases(ptl_batch* b, int64_t out[8]) {

@@ -1,0 +1,8 @@
+#!/bin/bash
+R="${GRAFT_REPO_ROOT:?}"
+O="$R/gpurun_out"; mkdir -p "$O"
+cd "$R"
+make -C ptudes-lab_amd/csrc -B libptudes_mi.so PHASES=1 > "$O/r02_h_make.txt" 2>&1
+{ python3 tools/phase_batch.py 8;} > "$O/r02_h_phases.txt" 2>&1
+make -C ptudes-lab_amd/csrc -B libptudes_mi.so > /dev/null 2>&1
+cat "$O/r02_h_phases.txt"

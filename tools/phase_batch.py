@@ -13,3 +13,29 @@ b.run()
 out=(C.c_int64*8)(); L.check(L.lib().ptl_batch_gn_phases(b._h,out))
 o=np.array(list(out),dtype=float); it=o[5]
 print("S",S,"grid iters",it,"ticks/iter: nn %.0f wgred %.0f barrier %.0f gridred %.0f solve %.0f"%tuple(o[:5]/it),"total",o[:5].sum()/it, "sum seq iters", sum(sum(st["iterations"] for st in b.results(s)["stats"]) for s in range(S)))
+
+print("wg0 of seq 0: misses/iter %.1f, phase A until compaction %.0f ticks/iter" % (o[6]/it, o[7]/it))
+icp = C.c_void_p()
+G = 32
+try:
+    # per-workgroup point-loop ticks and misses of sequence 0 (needs ptl_batch_icp)
+    L.check(L.lib().ptl_batch_icp(b._h, 0, C.byref(icp)))
+    wc = (C.c_int64 * 512)(); L.check(L.lib().ptl_icp_gn_wg_clocks(icp, wc, 256))
+    w = np.array(list(wc), dtype=float)
+    print("point loop per workgroup, ticks/iter:", np.round(w[:G] / it).astype(int).tolist())
+    print("misses per workgroup per iter:", np.round(w[G:2 * G] / it, 1).tolist())
+except Exception as e:
+    print("no per-wg clocks:", e)
+
+try:
+    import ctypes
+    class _DS(ctypes.Structure): pass
+    # dbg_sums of sequence 0's DevState: phase-B sub-steps of workgroup 0 / group 0 (ticks summed over its passes)
+    st = np.zeros(2048, dtype=np.uint8)
+    from ptudes_lab_amd import _lib
+    print("phase B sub-steps: see ptl_icp_debug_sums")
+    ds = (C.c_double * 32)(); L.check(L.lib().ptl_icp_debug_sums(icp, ds))
+    d = np.array(list(ds)); n = max(d[4], 1)
+    print("phase B per pass (wg 0, group 0): load row/key %.0f | first round %.0f | survivors %.0f | tail %.0f  ticks; passes/iter %.2f" % (d[0]/n, d[1]/n, d[2]/n, d[3]/n, d[4]/it))
+except Exception as e:
+    print("no sub-steps:", e)
