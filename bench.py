@@ -45,9 +45,9 @@ def scan_bytes(s, n_raw):
     return b_pre + b_ds + icp_bytes(s) + b_map
 
 
-def _cpu_pass(seq, n_total, use_imu_prediction, budget_s, with_ekf=True):
+def _cpu_pass(seq, n_total, use_imu_prediction, budget_s, with_ekf=True, oracle_over=None):
     from oracle import cpu as orc
-    icp = orc.ICP(max_range=seq.max_range, min_range=seq.min_range)
+    icp = orc.ICP(max_range=seq.max_range, min_range=seq.min_range, **(oracle_over or {}))
     ekf = orc.EKF()
     t01 = seq.column_times()
     kiss, res = [], []
@@ -72,7 +72,7 @@ def _cpu_pass(seq, n_total, use_imu_prediction, budget_s, with_ekf=True):
     return done, spent, np.array(kiss), np.array(res)
 
 
-def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0, with_ekf=True):
+def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0, with_ekf=True, oracle_over=None):
     """The CPU oracle (kind "port": our C restatement of the reference path) timed on this host on the first
     sweeps of the same sequence: one sequential pass (~1/3 of the budget; also the parity check of the GPU
     trajectory) and one pass with the loops kiss-icp runs under TBB spread over every usable core (oracle.h
@@ -81,11 +81,11 @@ def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0, with_ekf=True)
     from ptudes_lab_amd.synth import usable_cores
     cores = usable_cores()
     orc.set_threads(1)
-    d1, s1, kiss, res = _cpu_pass(seq, n_total, use_imu_prediction, budget_s / 3.0, with_ekf)
+    d1, s1, kiss, res = _cpu_pass(seq, n_total, use_imu_prediction, budget_s / 3.0, with_ekf, oracle_over)
     v1, vm, dm, sm = d1 / s1, 0.0, 0, 0.0
     if cores > 1:
         orc.set_threads(cores)
-        dm, sm, kiss_m, res_m = _cpu_pass(seq, n_total, use_imu_prediction, budget_s * 2.0 / 3.0, with_ekf)
+        dm, sm, kiss_m, res_m = _cpu_pass(seq, n_total, use_imu_prediction, budget_s * 2.0 / 3.0, with_ekf, oracle_over)
         orc.set_threads(1)
         vm = dm / sm
         if dm > d1:
@@ -189,7 +189,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seqs-per-gpu", type=int, default=1)
+    ap.add_argument("--seqs-per-gpu", type=int, default=8,
+                    help="independent sequences per GPU (SURVEY.md 8(e), second level): 8 = one per XCD in the batched runner "
+                         "(default); 1 = the single-sequence latency pipeline (one sequence over the whole chip)")
     ap.add_argument("--seed-base", type=int, default=1000, help="sequence s of SURVEY.md 8(d) uses seed seed_base + s")
     ap.add_argument("--equal-work", action="store_true",
                     help="every rank registers its own copy of sequences seed_base .. seed_base + S - 1 (equal work per GPU) "
@@ -230,6 +232,8 @@ def main():
 
     import ptudes_lab_amd  # noqa: F401
     from ptudes_lab_amd import _lib, core, synth
+    if args.seqs_per_gpu < 1 or args.seqs_per_gpu > 8:
+        sys.exit("bench.py: --seqs-per-gpu must be in [1, 8]")
     n_dev = _lib.lib().ptl_device_count()  # (hipGetDeviceCount: does not initialise a device)
     if n_dev < 1:
         sys.exit("bench.py: no HIP device - the HIP path is the only path")
@@ -431,7 +435,8 @@ def main():
                          "rmse_vs_gt_m": rmse_gt},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, kiss_cpu, res_cpu = cpu_baseline(sq, n_total, use_imu, args.cpu_budget, with_ekf=with_ekf)
+            cb, kiss_cpu, res_cpu = cpu_baseline(sq, n_total, use_imu, args.cpu_budget, with_ekf=with_ekf,
+                                                  oracle_over={"voxel_size": args.voxel_size} if args.voxel_size else None)
             m = len(res_cpu)
             line["cpu_baseline"] = cb
             d = np.linalg.norm(est[:m, :3, 3] - res_cpu[:, :3, 3], axis=1)

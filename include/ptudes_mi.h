@@ -147,6 +147,17 @@ int ptl_lut_apply(ptl_lut *l, const uint32_t *range_mm, double *xyz_out);
  * (0.001; 0.008 for the RNG15 profile, :242-252): out5 = {count, mean, population variance, min, max} */
 int ptl_range_stats(int device_id, const uint32_t *range, int32_t H, int32_t W, int32_t beams_num, double range_to_m,
                     double out5[5]);
+/* Posed scans for the map fly-by.
+ * ouster.sdk.pose_util.TrajectoryEvaluator.poses_at as the reference uses it (utils.py:368 time_bounds 1.5,
+ * cli/ekf_bench.py:489 time_bounds 1.0; third-party): pose at each of n timestamps on the SE(3) geodesic between the
+ * bracketing knots (ts strictly increasing, poses 4x4 row-major); the first / last segment is extended by bound_before /
+ * bound_after seconds; timestamps further out get the identity and are counted in n_outside (the reference skips them). */
+int ptl_traj_poses_at(int device_id, const double *knot_ts, const double *knot_poses16, int64_t n_knots, double bound_before,
+                      double bound_after, const double *ts, int64_t n, double *poses16_out, int64_t *n_outside);
+/* ouster client.dewarp(XYZLut(scan), column_poses = scan.pose) (reference fly.py:75-86 through ScansAccumulator): world
+ * xyz (H*W x 3 f64) of a range image whose W columns carry their own pose (W x 16).  As upstream, pixels without a
+ * return land on their column's sensor origin; n_valid (nullable) counts the pixels with a return. */
+int ptl_lut_dewarp(ptl_lut *l, const uint32_t *range_mm, const double *col_poses16, double *xyz_out, int64_t *n_valid);
 /* rows kept active by reduce_active_beams(ls, beams_num); beams_num <= 0 = all rows.  Applies to range-image input. */
 int ptl_icp_set_active_beams(ptl_icp *h, int32_t H, int32_t beams_num);
 /* register_frame on a raw range image; per-pixel times are column-implicit (kiss.py:34-35) */

@@ -77,6 +77,8 @@ PROTOTYPES = {
     "ptl_lut_create": (C.c_int, [C.c_int, C.c_int32, C.c_int32, c_d_p, c_d_p, C.c_double, c_d_p, c_d_p, _vpp]),
     "ptl_lut_destroy": (C.c_int, [_vp]),
     "ptl_lut_apply": (C.c_int, [_vp, C.POINTER(C.c_uint32), c_d_p]),
+    "ptl_traj_poses_at": (C.c_int, [C.c_int, c_d_p, c_d_p, C.c_int64, C.c_double, C.c_double, c_d_p, C.c_int64, c_d_p, c_i64_p]),
+    "ptl_lut_dewarp": (C.c_int, [_vp, C.POINTER(C.c_uint32), c_d_p, c_d_p, c_i64_p]),
     "ptl_icp_set_active_beams": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "ptl_icp_register_range": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32), C.c_double, c_d_p, c_d_p,
                                          C.POINTER(IcpStats)]),

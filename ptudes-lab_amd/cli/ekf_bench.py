@@ -185,8 +185,14 @@ def _synthetic_source(seed: int, n_scans: int):
               help="sensor metadata .json of the PCAP / BAG (needed when it is not found next to FILE)")
 @click.option("--start-scan", type=int, default=0, help="first scan to use (0-based)")
 @click.option("--end-scan", type=int, help="last scan to use (inclusive)")
+@click.option("-p", "--plot", required=False, type=str,
+              help="Plotting option [graphs, point_viz]: `graphs` prints the ground-truth comparison; the figures and the "
+                   "viewer themselves are not part of this build")
 @click.option("--use-imu-prediction", is_flag=True,
               help="hand the filter's predicted pose to KissICP as initial guess (loosely coupled lidar-inertial odometry)")
+@click.option("--use-gt-guess", is_flag=True,
+              help="hand the ground-truth pose (--gt-file, interpolated at the scan's timestamp) to KissICP as initial "
+                   "guess (sanity testing only)")
 @click.option("-g", "--gt-file", required=False, type=click.Path(exists=True, dir_okay=False, readable=True),
               help="Newer College ground-truth CSV to compare the result with")
 @click.option("--kiss-min-range", type=float, default=1, help="KissICP: shortest range kept, metres (default 1)")
@@ -199,12 +205,16 @@ def _synthetic_source(seed: int, n_scans: int):
 @click.option("--synthetic", type=int, default=None,
               help="Run on the synthetic 128x1024 sequence with this seed instead of FILE (no ouster-sdk needed)")
 def ptudes_ekf_ouster(file: Optional[str], meta: Optional[str], start_scan: int, end_scan: Optional[int],
-                      use_imu_prediction: bool, gt_file: Optional[str], beams: int, save_kitti_poses: Optional[str],
-                      save_nc_gt_poses: Optional[str], kiss_min_range: float, kiss_max_range: float,
-                      synthetic: Optional[int]) -> None:
+                      plot: Optional[str], use_imu_prediction: bool, use_gt_guess: bool, gt_file: Optional[str], beams: int,
+                      save_kitti_poses: Optional[str], save_nc_gt_poses: Optional[str], kiss_min_range: float,
+                      kiss_max_range: float, synthetic: Optional[int]) -> None:
     """EKF with Ouster IMUs and scan KissICP poses updates (smoothing of the KissICP trajectory)."""
+    from ..ins.data import StreamStatsTracker
     from ..sequence import run_events
-    from ..utils import active_beam_rows
+    from ..utils import TrajectoryEvaluator, active_beam_rows
+    if not gt_file and use_gt_guess:  # reference :416-418
+        print("ERROR: --use-gt-guess requires the GT poses (--gt-file)")
+        raise SystemExit(1)
     if synthetic is None:
         try:
             import ouster.client  # noqa: F401
@@ -234,10 +244,25 @@ def ptudes_ekf_ouster(file: Optional[str], meta: Optional[str], start_scan: int,
     display_header += f"metadata path: {meta}\n\n"
     display_header += f"scans range: {start_scan} - {end_scan}\n"
     display_header += f"kiss min/max: {kiss_min_range} - {kiss_max_range}\n"
-    display_header += f"use-imu-prediction: {use_imu_prediction}, use-gt-guess: False\n"
+    display_header += f"use-imu-prediction: {use_imu_prediction}, use-gt-guess: {use_gt_guess}\n"
     display_header += f"beams: {beams or info.format.pixels_per_column}\n"
     display_header += f"sensor: {info.prod_line}, {info.mode}\n"
     print(display_header)
+    log_metrics = bool(plot)
+    print(f"metrics logging: {log_metrics}")
+
+    # --use-gt-guess (reference :486-489, :536-542): the GT pose at the scan's last column, relative to the first one used
+    gts = read_newer_college_gt(gt_file) if gt_file else []
+    guess_fn = None
+    if use_gt_guess:
+        gt_traj = TrajectoryEvaluator(gts, time_bounds=1.0)
+        origin = []
+
+        def guess_fn(ts):
+            gt_guess = gt_traj.pose_at(ts)
+            if not origin:
+                origin.append(np.linalg.inv(gt_guess))
+            return origin[0] @ gt_guess
 
     def feed():
         scan_idx = 0
@@ -260,8 +285,9 @@ def ptudes_ekf_ouster(file: Optional[str], meta: Optional[str], start_scan: int,
             elif scan_idx >= start_scan_feed:  # IMUs before start_scan are dropped (reference data.py:76)
                 yield ev
 
+    stats = StreamStatsTracker(use_beams_num=32, metadata=info)  # reference :457
     out = run_events(feed(), info, kiss_min_range=kiss_min_range, kiss_max_range=kiss_max_range,
-                     use_imu_prediction=use_imu_prediction)
+                     use_imu_prediction=use_imu_prediction, guess_fn=guess_fn, logging=log_metrics, stats=stats)
     res_t, res_poses, kiss_poses = out["res_t"], out["res_poses"], out["kiss_poses"]
     header = display_header + f"(scans/updates num: {len(res_poses)})\n"
     header += "time: " + datetime.now().strftime("%Y%m%d_%H%M%S")
@@ -272,30 +298,36 @@ def ptudes_ekf_ouster(file: Optional[str], meta: Optional[str], start_scan: int,
         save_poses_nc_gt_format(save_nc_gt_poses, t=res_t, poses=res_poses, header=header)
         print(f"NC GT poses saved to: {save_nc_gt_poses}")
     tm = out["timings"]
-    if res_poses:
+    if tm["n_imu"] and tm["n_corr"]:  # reference :590-595
         print("\nTimings:")
         print(f"  ESEKF imu process:      {tm['imu']:.05f} s per step")
         print(f"  ESEKF update:           {tm['corr']:.05f} s per update")
         print(f"  KissICP register frame: {tm['kiss']:.05f} s per frame")
-    gts = read_newer_college_gt(gt_file) if gt_file else []
-    if gts and res_poses:
-        gts, res_t_matched = filter_nc_gt_by_close_ts(gts, res_t)
-        idx, kiss_m, res_m = 0, [], []
-        for t_m in res_t_matched:
-            while res_t[idx] != t_m:
+        print(f"  Stats tracking:         {tm['track']:.05f} s per frame")
+    if plot == "graphs":  # reference :599-660: the comparison is printed, the figures are not drawn here
+        if gts and res_poses:
+            gts, res_t_matched = filter_nc_gt_by_close_ts(gts, res_t)
+            idx, kiss_m, res_m = 0, [], []
+            for t_m in res_t_matched:
+                while res_t[idx] != t_m:
+                    idx += 1
+                kiss_m.append(kiss_poses[idx])
+                res_m.append(res_poses[idx])
                 idx += 1
-            kiss_m.append(kiss_poses[idx])
-            res_m.append(res_poses[idx])
-            idx += 1
-        if gts:
-            pose0 = res_m[0] @ np.linalg.inv(gts[0][1])
-            gt2 = [pose0 @ g[1] for g in gts]
-            for label, poses in ((f"with ES EKF smoothing {len(gt2)} poses", res_m),
-                                 (f"no-EKF, only KissICP {len(gt2)} poses", kiss_m)):
-                ate_rot, ate_trans = calc_ate(poses, gt2)
-                print(f"\nGround truth comparison ({label}):")
-                print(f"ATE_rot:   {ate_rot:.04f} deg")
-                print(f"ATE trans: {ate_trans:.04f} m")
+            if gts:
+                pose0 = res_m[0] @ np.linalg.inv(gts[0][1])
+                gt2 = [pose0 @ g[1] for g in gts]
+                for label, poses in ((f"with ES EKF smoothing {len(gt2)} poses", res_m),
+                                     (f"no-EKF, only KissICP {len(gt2)} poses", kiss_m)):
+                    ate_rot, ate_trans = calc_ate(poses, gt2)
+                    print(f"\nGround truth comparison ({label}):")
+                    print(f"ATE_rot:   {ate_rot:.04f} deg")
+                    print(f"ATE trans: {ate_trans:.04f} m")
+        print("NOTE: the graphs themselves (matplotlib) are not part of this build")
+    elif plot == "point_viz":
+        print("NOTE: the point viewer (ouster-sdk PointViz) is not part of this build")
+    elif plot:
+        print(f"WARNING: plot param '{plot}' doesn't supported")
 
 
 @click.command(name="cmp")

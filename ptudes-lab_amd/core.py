@@ -188,6 +188,30 @@ class Lut:
         return out
 
 
+    def dewarp(self, range_mm, col_poses):
+        """client.dewarp(XYZLut(scan), column_poses=scan.pose): (H*W, 3) world xyz and the number of returns"""
+        r = np.ascontiguousarray(range_mm, dtype=np.uint32).reshape(-1)
+        P = L.as_f64(col_poses).reshape(-1, 16)
+        if r.size != self.H * self.W or len(P) != self.W:
+            raise ValueError("need an H x W range image and one 4x4 pose per column")
+        out = np.empty((self.H * self.W, 3))
+        nv = C.c_int64()
+        L.check(L.lib().ptl_lut_dewarp(self._h, r.ctypes.data_as(C.POINTER(C.c_uint32)), L.dptr(P), L.dptr(out), C.byref(nv)))
+        return out, nv.value
+
+
+def traj_poses_at(knot_ts, knot_poses, ts, bound_before=0.0, bound_after=0.0, device_id=0):
+    """TrajectoryEvaluator.poses_at on device: (n, 4, 4) poses and the number of timestamps outside the bounds"""
+    kt, kp, t = L.as_f64(knot_ts), L.as_f64(knot_poses).reshape(-1, 16), L.as_f64(ts).reshape(-1)
+    if len(kt) != len(kp):
+        raise ValueError("one pose per knot timestamp")
+    out = np.empty((len(t), 4, 4))
+    nout = C.c_int64()
+    L.check(L.lib().ptl_traj_poses_at(device_id, L.dptr(kt), L.dptr(kp), len(kt), float(bound_before), float(bound_after),
+                                      L.dptr(t), len(t), L.dptr(out), C.byref(nout)))
+    return out, nout.value
+
+
 class Ekf:
     def __init__(self, init_grav=None, init_bacc=None, init_bgyr=None, device_id=0):
         self.cfg = ekf_cfg(init_grav, init_bacc, init_bgyr, device_id)

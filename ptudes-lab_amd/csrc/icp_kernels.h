@@ -1416,9 +1416,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G, co
     }
     if (tid == NT - 1) cand_total_sh = 0;
     __syncthreads();
-    // contiguous scan-order share of this workgroup (a band of beams: its voxels stay in the L1 / L2 it uses)
-    const int per_wg = (n + G - 1) / G;
-    const int first = wg * per_wg, last = (first + per_wg < n) ? first + per_wg : n;
+    // Point j of this workgroup is source point wg + G j: every workgroup gets an even sample of the scan, so the number of
+    // points that need a full search is the same everywhere (with contiguous shares it ranged from 48 to 73 of 203 per
+    // iteration, and a workgroup with more than blockDim / 8 of them pays a second search pass while the others wait).  The
+    // sequence's workgroups share one L2, so the voxels they touch are resident there either way.
+    const int per_wg = (n - wg + G - 1) / G;  // points wg, wg + G, ...
+    const int first = 0, last = per_wg;
     // the direction (di, dj, dk) of this lane's four row entries, 2 bits per axis: 0 = -1, 1 = 0, 2 = +1
     int dcode[4];
 #pragma unroll
@@ -1445,9 +1448,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G, co
             // ((D - d0) / 2)^2 with a safety factor, < 0 = no answer | candidate count of the 27 voxels.  The distance, the
             // gate and the weight come from the current s either way - same values as after a search.
             {
-                const int i = cbase + tid;
+                const int j = cbase + tid, i = wg + G * j;
                 int miss = -1;
-                if (i < last) {
+                if (j < last) {
                     Rt E;
                     for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
                     for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];

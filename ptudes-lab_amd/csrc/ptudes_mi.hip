@@ -773,6 +773,115 @@ extern "C" int ptl_icp_register_range(ptl_icp* h, ptl_lut* lut, const uint32_t* 
     return PTL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ posed scans (flyby)
+// Poses along a time-stamped trajectory == ouster.sdk.pose_util.TrajectoryEvaluator as the reference uses it
+// (utils.py:344-392 pose_scans_from_nc_gt, time_bounds = 1.5; cli/ekf_bench.py:489, :537 --use-gt-guess, time_bounds = 1.0;
+// third-party, [UPSTREAM-KNOWLEDGE]): between the knots (t_i, P_i) that bracket ts the pose is the SE(3) geodesic
+//   P(ts) = P_i Exp(alpha Log(P_i^-1 P_i+1)),  alpha = (ts - t_i) / (t_i+1 - t_i);
+// up to `before` / `after` seconds outside the knots the first / last segment is extended (alpha < 0 / > 1); further out
+// is an error (the reference skips such scans, utils.py:382-384).  One thread per timestamp, binary search for the segment.
+__global__ __launch_bounds__(256) void k_traj_poses_at(const double* kt, const double* kp, int n, double before, double after,
+                                                       const double* ts, int m, double* out, int* n_outside) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const double t = ts[j];
+    if (!(t >= kt[0] - before) || !(t <= kt[n - 1] + after)) {
+        atomicAdd(n_outside, 1);
+        for (int k = 0; k < 16; ++k) out[16 * (size_t)j + k] = (k % 5 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    int lo = 0, hi = n - 1;  // largest i with kt[i] <= t, clamped to a valid segment start
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (kt[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int i = lo < n - 1 ? lo : n - 2;
+    const double alpha = (t - kt[i]) / (kt[i + 1] - kt[i]);
+    const Rt P0 = rt_from16(kp + 16 * (size_t)i), P1 = rt_from16(kp + 16 * (size_t)(i + 1));
+    double xi[6];
+    se3_log(rt_mul(rt_inv(P0), P1), xi);
+    for (int k = 0; k < 6; ++k) xi[k] *= alpha;
+    rt_to16(rt_mul(P0, se3_exp(xi)), out + 16 * (size_t)j);
+}
+extern "C" int ptl_traj_poses_at(int device_id, const double* knot_ts, const double* knot_poses16, int64_t n_knots,
+                                 double bound_before, double bound_after, const double* ts, int64_t n, double* poses16_out,
+                                 int64_t* n_outside) {
+    if (!knot_ts || !knot_poses16 || !ts || !poses16_out || n_knots < 2 || n < 0) return set_err(PTL_ERR_ARG, "bad argument (a trajectory needs >= 2 knots)");
+    for (int64_t i = 1; i < n_knots; ++i)
+        if (!(knot_ts[i] > knot_ts[i - 1])) return set_err(PTL_ERR_ARG, "knot timestamps must increase strictly (knot %lld)", (long long)i);
+    if (ptl_device_count() <= device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", device_id);
+    HIPCHK(hipSetDevice(device_id));
+    if (n_outside) *n_outside = 0;
+    if (n == 0) return PTL_OK;
+    double *d_kt = nullptr, *d_kp = nullptr, *d_ts = nullptr, *d_out = nullptr;
+    int* d_cnt = nullptr;
+    hipError_t e = dalloc(&d_kt, (size_t)n_knots);
+    if (e == hipSuccess) e = dalloc(&d_kp, (size_t)n_knots * 16);
+    if (e == hipSuccess) e = dalloc(&d_ts, (size_t)n);
+    if (e == hipSuccess) e = dalloc(&d_out, (size_t)n * 16);
+    if (e == hipSuccess) e = dalloc(&d_cnt, 1);
+    if (e == hipSuccess) e = hipMemcpy(d_kt, knot_ts, (size_t)n_knots * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_kp, knot_poses16, (size_t)n_knots * 128, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_ts, ts, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(int));
+    int outside = 0;
+    if (e == hipSuccess) {
+        k_traj_poses_at<<<(int)((n + 255) / 256), 256>>>(d_kt, d_kp, (int)n_knots, bound_before, bound_after, d_ts, (int)n, d_out, d_cnt);
+        e = hipMemcpy(poses16_out, d_out, (size_t)n * 128, hipMemcpyDeviceToHost);
+    }
+    if (e == hipSuccess) e = hipMemcpy(&outside, d_cnt, sizeof(int), hipMemcpyDeviceToHost);
+    for (void* q : {(void*)d_kt, (void*)d_kp, (void*)d_ts, (void*)d_out, (void*)d_cnt})
+        if (q) (void)hipFree(q);
+    if (e != hipSuccess) return set_err(PTL_ERR_HIP, "ptl_traj_poses_at: %s", hipGetErrorString(e));
+    if (n_outside) *n_outside = outside;
+    return PTL_OK;
+}
+// ouster client.dewarp(XYZLut(scan), column_poses = scan.pose) (what ScansAccumulator does with a posed scan, reference
+// fly.py:75-86): pixel (u, v) -> R_v (range dir + off) + t_v with the pose of ITS column.  As upstream, pixels without a
+// return (range 0 -> xyz 0) land on their column's sensor origin; n_valid counts the others.
+__global__ __launch_bounds__(256) void k_dewarp(int H, int W, const unsigned* range, const double* dir, const double* off,
+                                                const double* col_poses, double* xyz, int* n_valid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool valid = false;
+    if (i < H * W) {
+        const unsigned rg = range[i];
+        const double r = (double)rg;
+        const double* P = col_poses + 16 * (size_t)(i % W);
+        double p[3];
+        for (int k = 0; k < 3; ++k) p[k] = rg ? r * dir[3 * (size_t)i + k] + off[3 * (size_t)i + k] : 0.0;
+        for (int k = 0; k < 3; ++k) xyz[3 * (size_t)i + k] = ((P[4 * k] * p[0] + P[4 * k + 1] * p[1]) + P[4 * k + 2] * p[2]) + P[4 * k + 3];
+        valid = rg != 0;
+    }
+    const int nv = __syncthreads_count(valid ? 1 : 0);
+    if (threadIdx.x == 0 && nv) atomicAdd(n_valid, nv);
+}
+extern "C" int ptl_lut_dewarp(ptl_lut* l, const uint32_t* range_mm, const double* col_poses16, double* xyz_out, int64_t* n_valid) {
+    if (!l || !range_mm || !col_poses16 || !xyz_out) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(l->device_id));
+    const size_t n = (size_t)l->H * l->W;
+    unsigned* d_r = nullptr;
+    double *d_x = nullptr, *d_p = nullptr;
+    int* d_c = nullptr;
+    hipError_t e = dalloc(&d_r, n);
+    if (e == hipSuccess) e = dalloc(&d_x, 3 * n);
+    if (e == hipSuccess) e = dalloc(&d_p, (size_t)l->W * 16);
+    if (e == hipSuccess) e = dalloc(&d_c, 1);
+    if (e == hipSuccess) e = hipMemcpy(d_r, range_mm, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_p, col_poses16, (size_t)l->W * 128, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_c, 0, sizeof(int));
+    int cnt = 0;
+    if (e == hipSuccess) {
+        k_dewarp<<<(int)((n + 255) / 256), 256>>>(l->H, l->W, d_r, l->dir, l->off, d_p, d_x, d_c);
+        e = hipMemcpy(xyz_out, d_x, n * 24, hipMemcpyDeviceToHost);
+    }
+    if (e == hipSuccess) e = hipMemcpy(&cnt, d_c, sizeof(int), hipMemcpyDeviceToHost);
+    for (void* q : {(void*)d_r, (void*)d_x, (void*)d_p, (void*)d_c})
+        if (q) (void)hipFree(q);
+    if (e != hipSuccess) return set_err(PTL_ERR_HIP, "ptl_lut_dewarp: %s", hipGetErrorString(e));
+    if (n_valid) *n_valid = cnt;
+    return PTL_OK;
+}
+
 // ================================================================================================ EKF
 struct ptl_ekf {
     ptl_ekf_cfg cfg;

@@ -17,18 +17,23 @@ from .kiss import KissICPWrapper
 
 
 def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use_imu_prediction=False,
-               guess_fn=None, logging=False, device_id=0):
+               guess_fn=None, logging=False, device_id=0, stats=None):
     """Returns dict(res_t, res_poses, kiss_poses, kiss_icp, ekf, timings).  `guess_fn(ts)` (optional) supplies an
-    external guess (the reference's --use-gt-guess, ekf_bench.py:536-542)."""
+    external guess (the reference's --use-gt-guess, ekf_bench.py:536-542); `stats` (optional) is the StreamStatsTracker
+    the loop feeds (ekf_bench.py:497-499, :522-524), its time goes into timings["track"]."""
     kiss_icp = KissICPWrapper(metadata, _use_extrinsics=True, _min_range=kiss_min_range, _max_range=kiss_max_range,
                               device_id=device_id)
     ekf = ESEKF(_logging=logging, device_id=device_id)
     res_t, res_poses, kiss_poses = [], [], []
-    t_imu = t_corr = t_kiss = 0.0
+    t_imu = t_corr = t_kiss = t_track = 0.0
     n_imu = n_corr = 0
     imus_per_scan = 1  # ekf_bench.py:491
     for ev in events:
         if ev[0] == "imu":
+            if stats is not None:
+                t1 = time.monotonic()
+                stats.trackImu(ev[1])
+                t_track += time.monotonic() - t1
             t1 = time.monotonic()
             ekf.processImu(ev[1])
             t_imu += time.monotonic() - t1
@@ -38,6 +43,15 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
         if not imus_per_scan:  # ekf_bench.py:512-518
             continue
         imus_per_scan = 0
+        if stats is not None:  # ekf_bench.py:522-524 (before the beams are reduced)
+            t1 = time.monotonic()
+            if ev[0] == "lidar_scan":
+                stats.trackScan(ev[1])
+            else:  # points: the ranges are their norms (mm, like the sensor's RANGE field)
+                W = int(getattr(getattr(metadata, "format", None), "columns_per_frame", 0)) or len(ev[1])
+                rng = np.round(np.linalg.norm(np.asarray(ev[1], dtype=np.float64), axis=1) * 1000.0).astype(np.uint32).reshape(-1, W)
+                stats.trackScan(rng, last_valid_column_ts_ns=int(round(ev[3] * 1e9)))
+            t_track += time.monotonic() - t1
         if ev[0] == "lidar_scan":  # an ouster LidarScan from the packet feed (data.OusterLidarData)
             xyz, t01, ts = None, None, float(getattr(ev[1], "timestamp", [0])[-1]) * 1e-9 if hasattr(ev[1], "timestamp") else 0.0
         else:
@@ -62,7 +76,8 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
         kiss_poses.append(kiss_icp.pose)
         res_poses.append(ekf.nav.pose_mat())
         res_t.append(ekf.ts)
-    timings = dict(imu=t_imu / max(n_imu, 1), corr=t_corr / max(n_corr, 1), kiss=t_kiss / max(n_corr, 1))
+    timings = dict(imu=t_imu / max(n_imu, 1), corr=t_corr / max(n_corr, 1), kiss=t_kiss / max(n_corr, 1),
+                   track=t_track / max(n_corr, 1), n_imu=n_imu, n_corr=n_corr)
     return dict(res_t=res_t, res_poses=res_poses, kiss_poses=kiss_poses, kiss_icp=kiss_icp, ekf=ekf, timings=timings)
 
 

@@ -5,7 +5,7 @@ function names, argument meaning and byte-for-byte identical files, so `ptudes f
 --nc-gt-poses` and `ptudes ekf-bench cmp` keep consuming what this package writes.  The viz / packet-IO
 helpers of that file (PointViz, pcap/bag openers) are outside the pose path and are not provided.
 """
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 from scipy.spatial.transform import Rotation
@@ -174,3 +174,57 @@ def reduce_active_beams(scan, beams_num: int):
     drop[active_beam_rows(h, beams_num)] = False
     arr[drop] = 0
     return scan
+
+
+class TrajectoryEvaluator:
+    """Poses along a time-stamped trajectory: the part of ouster.sdk.pose_util.TrajectoryEvaluator the reference uses
+    (utils.py:368 `pose_scans_from_nc_gt`, cli/ekf_bench.py:489 / :537 `--use-gt-guess`; third-party, behaviour from its
+    published description): SE(3) geodesic between the bracketing knots, the end segments extended by `time_bounds`
+    seconds (a number, or (before, after)), ValueError further out.  The interpolation runs on the GPU
+    (`ptl_traj_poses_at`): a sweep asks for 1024 or 2048 poses at once."""
+
+    def __init__(self, poses, time_bounds=0.0, device_id: int = 0):
+        poses = list(poses)
+        if len(poses) < 2:
+            raise ValueError("a trajectory needs at least two (ts, pose) knots")
+        self._ts = np.array([p[0] for p in poses], dtype=np.float64)
+        self._poses = np.array([np.asarray(p[1], dtype=np.float64) for p in poses])
+        self._bounds = (float(time_bounds), float(time_bounds)) if np.isscalar(time_bounds) else tuple(map(float, time_bounds))
+        self._device_id = device_id
+
+    def poses_at(self, ts) -> np.ndarray:
+        from . import core
+        ts = np.atleast_1d(np.asarray(ts, dtype=np.float64))
+        out, outside = core.traj_poses_at(self._ts, self._poses, ts, self._bounds[0], self._bounds[1], self._device_id)
+        if outside:
+            raise ValueError(f"{outside} of {len(ts)} timestamps lie outside the trajectory "
+                             f"({self._ts[0]} .. {self._ts[-1]}, bounds {self._bounds})")
+        return out
+
+    def pose_at(self, ts: float) -> np.ndarray:
+        return self.poses_at([ts])[0]
+
+    def __call__(self, scan, col_ts=None):
+        """write the pose of every column of `scan` (ts of its columns in seconds) into scan.pose, like upstream"""
+        col_ts = np.asarray(scan.timestamp, dtype=np.float64) * 1e-9 if col_ts is None else np.asarray(col_ts, dtype=np.float64)
+        scan.pose[:] = self.poses_at(col_ts)
+
+
+def pose_scans_from_nc_gt(source, nc_gt_poses_file: Optional[str] = None, nc_gt_poses=None, device_id: int = 0):
+    """Give every scan of `source` the ground-truth pose of each of its columns (reference utils.py:344-392): scans whose
+    columns are not all within 1.5 s of the trajectory are left out, and counted in the closing note.  A scan is
+    anything with `timestamp` (W ns) and `pose` (W, 4, 4) - an ouster LidarScan, or `fly.PosedScan`."""
+    gts = read_newer_college_gt(nc_gt_poses_file) if nc_gt_poses_file else nc_gt_poses
+    traj_eval = TrajectoryEvaluator(gts, time_bounds=1.5, device_id=device_id)
+    skipped_scans = 0
+    for scan in source:
+        if not (hasattr(scan, "timestamp") and hasattr(scan, "pose")):
+            continue
+        try:
+            traj_eval(scan, col_ts=np.asarray(scan.timestamp, dtype=np.float64) * 1e-9)
+        except ValueError:
+            skipped_scans += 1
+            continue
+        yield scan
+    print(f"NOTE: Therere where {skipped_scans} skipped scans that wasn't "
+          "because they were outside of the NC GT poses available")

@@ -96,3 +96,13 @@ def test_squared_gate_is_equivalent_to_the_square_root_test():
         for _ in range(40):  # ... and T and 39 above
             assert not (np.sqrt(x) < M) and not (x < T)
             x = np.nextafter(x, np.inf)
+
+
+def test_ouster_gt_guess_needs_a_gt_file_and_plot_is_an_option():
+    """reference cli/ekf_bench.py:337-349, :416-418: the option set a user's existing command line relies on"""
+    res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "ouster", "nofile.pcap", "--use-gt-guess"])
+    assert res.exit_code == 1 and "ERROR: --use-gt-guess requires the GT poses (--gt-file)" in res.output
+    res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "ouster", "--help"])
+    assert res.exit_code == 0
+    for opt in ("-p, --plot", "--use-gt-guess", "--use-imu-prediction", "-g, --gt-file", "--beams", "--save-nc-gt-poses"):
+        assert opt in res.output, opt

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "8",
-                          "--cpu-budget", "3"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--cpu-budget", "3", "--seqs-per-gpu", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
@@ -43,7 +43,7 @@ def test_bench_launches_its_own_ranks_on_distinct_sequences(tmp_path):
     dump = str(tmp_path / "traj.npz")
     K, W = 10, 4
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(K), "--warmup", str(W),
-                          "--gn-wgs", "64", "--dump-traj", dump], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                          "--gn-wgs", "64", "--seqs-per-gpu", "1", "--dump-traj", dump], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
@@ -67,3 +67,20 @@ def test_bench_launches_its_own_ranks_on_distinct_sequences(tmp_path):
         assert rows.shape == (n, 8)
         assert np.array_equal(rows[:, 0], o["res_t"]) and np.array_equal(rows[:, 1:4], o["res_poses"][:, :3, 3])
     assert not np.array_equal(got["rank0_seq0"][:, 1:4], got["rank1_seq0"][:, 1:4])
+
+
+@pytest.mark.gpu
+def test_bench_default_is_the_batched_runner_one_sequence_per_xcd():
+    """no flags but short: 8 independent sequences on the GPU (seeds 1000..1007), the per-XCD Gauss-Newton kernel dominant,
+    `value` = 8 scans per step, sequence 0 checked against the oracle inside the run"""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "8", "--cpu-budget", "3"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 8 and d["config"]["sequence_seeds"].startswith("1000..1007")
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["kernel"] == "kx_gn_loop8" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["launches"] == 16
+    assert d["roofline"]["traffic"] is None  # no PMC pass was collected on THIS workload (16 + 8 sweeps)
+    assert d["cpu_baseline"]["value"] > 0 and d["parity_vs_oracle"]["max_dpos_m"] < 1e-9

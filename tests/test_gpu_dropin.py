@@ -106,3 +106,29 @@ def test_ouster_command_on_synthetic_writes_pose_files(tmp_path):
     # cmp of the file against itself: zero error
     res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "cmp", str(fn), str(fn)])
     assert res.exit_code == 0 and "ATE trans: 0.0000 m" in res.output
+
+
+def test_ouster_command_gt_guess_plot_and_timings(tmp_path):
+    """`--use-gt-guess` (GT pose interpolated at the scan's timestamp as KissICP guess, reference ekf_bench.py:536-542),
+    `-p graphs` (the ground-truth comparison block, :599-633) and the four-line Timings block (:590-595)"""
+    from ptudes_lab_amd import synth
+    n = 8
+    seq = synth.make_sequence(seed=1002, n_scans=n)
+    t = np.arange(0.0, (n + 1) * seq.scan_dt, 0.02)
+    gt_csv = tmp_path / "gt.csv"
+    pu.save_poses_nc_gt_format(str(gt_csv), t=list(seq.t_base + t), poses=list(seq.pose_at(t)))
+    res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "ouster", "--synthetic", "1002", "--end-scan", str(n - 1),
+                                          "--use-gt-guess", "-g", str(gt_csv), "-p", "graphs"])
+    assert res.exit_code == 0, res.output
+    out = res.output
+    assert "use-imu-prediction: False, use-gt-guess: True" in out and "metrics logging: True" in out
+    for line in ("ESEKF imu process:", "ESEKF update:", "KissICP register frame:", "Stats tracking:"):
+        assert line in out, line
+    assert "Ground truth comparison (with ES EKF smoothing" in out and "Ground truth comparison (no-EKF, only KissICP" in out
+    ate = [float(ln.split()[2]) for ln in out.splitlines() if ln.startswith("ATE trans:")]
+    assert len(ate) == 2 and max(ate) < 0.05  # m^2 (reference-style mean squares): the guess is the truth
+    # without -p the comparison block is not printed (it lives under `plot == "graphs"` in the reference)
+    res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "ouster", "--synthetic", "1002", "--end-scan", "3", "-g", str(gt_csv)])
+    assert res.exit_code == 0 and "Ground truth comparison" not in res.output and "metrics logging: False" in res.output
+    res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "ouster", "--synthetic", "1002", "--end-scan", "2", "-p", "nonsense"])
+    assert res.exit_code == 0 and "WARNING: plot param 'nonsense' doesn't supported" in res.output
