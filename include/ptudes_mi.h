@@ -68,8 +68,9 @@ typedef struct {
     int32_t rebuild_every;        /* rebuild the map hash table every this many scans (drops tombstones) */
     int32_t gn_threads;           /* threads per workgroup of that kernel (multiple of 64, 256..1024) */
     int32_t gn_lanes_per_point;   /* 32: latency form (one point per 32 lanes, one sequence over the whole chip);
-                                   * 8: throughput form (8 points per wavefront, moment accumulation, one-hop exchange;
-                                   * needs gn_workgroups <= 64) - what the batched runner uses per sequence */
+                                   * 8: throughput form (lane-per-point answer cache, 8 lanes per searched point, moment
+                                   * accumulation; gn_threads <= 512) - what the batched runner uses per sequence, and the
+                                   * faster form for dense scans (tens of thousands of source points) */
 } ptl_icp_cfg;
 
 /* per-scan counters; identical meaning to oracle/oracle.h orc_icp_stats (SURVEY.md 8(d) byte model) */

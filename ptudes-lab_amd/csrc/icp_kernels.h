@@ -1705,7 +1705,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G, co
                 if (!ok && tid == 0) gn_raise_abort(st);
                 c3 = GN_CLK();
             }
-        } else {
+        } else if (G <= 64) {
             for (int j = grp32; j < G; j += NG32) {
                 const unsigned long long* row = c.gn_rows_ll + ((size_t)par * G + j) * GN_LL_WORDS;
                 unsigned h0, h1;
@@ -1727,6 +1727,67 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G, co
                     t += sg;
                 }
                 mom[tid] = t;
+            }
+        } else {
+            // one sequence over the whole chip (G up to 512): the two-hop exchange of the 32-lane kernel - rows -> the
+            // leader of each group (wg & 7) -> 8 group sums to every consumer slot - with this kernel's 18-entry rows
+            if (wg < ngroups) {
+                const int nmem = (G - wg + 7) / 8;
+                for (int j = grp32; j < nmem; j += NG32) {
+                    const unsigned long long* row = c.gn_rows_ll + ((size_t)par * G + (wg + 8 * j)) * GN_LL_WORDS;
+                    unsigned h0, h1;
+                    gn_ll_wait2(row + lane32, row + lane32 + 32, lane32 + 32 < 2 * GN8_ROW_ENTRIES, flag, &h0, &h1, &ok, &st->gn_abort);
+                    const double v0 = gn_ll_join(h0), v1 = gn_ll_join(h1);
+                    if ((lane32 & 1) == 0) {
+                        redL8[j][lane32 >> 1] = v0;
+                        if (16 + (lane32 >> 1) < GN8_ROW_ENTRIES) redL8[j][16 + (lane32 >> 1)] = v1;
+                    }
+                }
+                if (!ok) gn_raise_abort(st);
+                __syncthreads();
+                if (tid < GN8_ROW_ENTRIES) {  // sum in member order; both halves of the entry to every consumer slot
+                    double sm = 0.0;
+                    for (int j = 0; j < nmem; ++j) sm += redL8[j][tid];
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(sm), fl = (unsigned long long)flag << 32;
+                    const unsigned long long lo = (bits & 0xFFFFFFFFull) | fl, hi = (bits >> 32) | fl;
+#pragma unroll
+                    for (int r = 0; r < GN_XSUM_COPIES; ++r) {
+                        unsigned long long* dst = c.gn_xsum_ll + (((size_t)par * 8 + r) * 8 + wg) * GN_LL_WORDS + 2 * tid;
+                        __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (tid < 64) {  // everybody: the group sums addressed to this workgroup's slot, added in group order
+                const bool mine = tid < 2 * GN8_ROW_ENTRIES;
+                bool ok2 = true;
+                unsigned h[8];
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned bad = 0u;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        unsigned long long vv = (unsigned long long)flag << 32;
+                        if (mine && g < ngroups)
+                            vv = __hip_atomic_load(c.gn_xsum_ll + (((size_t)par * 8 + (wg & (GN_XSUM_COPIES - 1))) * 8 + g) * GN_LL_WORDS + tid,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        bad |= (unsigned)(vv >> 32) ^ flag;
+                        h[g] = (unsigned)vv;
+                    }
+                    if (__all(bad == 0u)) break;
+                    ++spins;
+                    if (spins > GN_LL_SPINS || ((spins & 1023u) == 0u && gn_abort_seen(&st->gn_abort))) { ok2 = false; break; }
+                }
+                double t = 0.0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const double v = gn_ll_join(h[g]);
+                    if (g < ngroups) t += v;
+                }
+                if (mine && (tid & 1) == 0) mom[tid >> 1] = t;
+                if (!ok2 && tid == 0) gn_raise_abort(st);
+                ok = ok && ok2;
+                c3 = GN_CLK();
             }
         }
         if (tid < 64) {
@@ -1775,7 +1836,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G, co
         gn_post(c, st, false, mode == 0);
     }
 }
-// one sequence, 8 lanes per point (gn_workgroups <= 64: one-hop exchange)
+// one sequence, 8 lanes per point (gn_workgroups <= 64: one-hop exchange; more: two hops through 8 group leaders)
 template <int PC>
 __global__ __launch_bounds__(GN8_MAX_THREADS) void k_gn_loop8(Ctx c, int mode) {
     gn8_body<PC>(c, mode, (int)gridDim.x, (int)blockIdx.x);

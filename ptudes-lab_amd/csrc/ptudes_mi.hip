@@ -166,7 +166,6 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     if (cfg->gn_threads < 256 || cfg->gn_threads > GN_MAX_THREADS || (cfg->gn_threads & 63)) return set_err(PTL_ERR_ARG, "gn_threads must be a multiple of 64 in [256, GN_MAX_THREADS]");
     if (cfg->gn_lanes_per_point != 32 && cfg->gn_lanes_per_point != 8) return set_err(PTL_ERR_ARG, "gn_lanes_per_point must be 32 or 8");
     if (cfg->gn_lanes_per_point == 8 && cfg->gn_threads > GN8_MAX_THREADS) return set_err(PTL_ERR_ARG, "gn_lanes_per_point = 8 runs at most %d threads per workgroup", GN8_MAX_THREADS);
-    if (cfg->gn_lanes_per_point == 8 && !batch_member && cfg->gn_workgroups > 64) return set_err(PTL_ERR_ARG, "gn_lanes_per_point = 8 uses the one-hop exchange: gn_workgroups <= 64");
     if (ptl_device_count() <= cfg->device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->device_id);
     HIPCHK(hipSetDevice(cfg->device_id));
     {

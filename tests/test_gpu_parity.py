@@ -502,3 +502,20 @@ def test_throughput_kernel_8_lanes_per_point_vs_oracle():
     for k in range(n):
         for key in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "sum_cand", "map_voxels", "map_points"):
             assert out["stats"][k][key] == ref["stats"][k][key], (k, key)
+
+
+def test_throughput_kernel_over_the_whole_chip_vs_oracle():
+    """the 8-lanes-per-point kernel for ONE sequence on all 256 workgroups (two-hop exchange; the dense-scan form)"""
+    n = 24
+    sq = synth.make_sequence(seed=1004, n_scans=n)
+    ref = _threaded_oracle(sq.events(n), max_range=70.0, min_range=1.0, use_imu_prediction=True)
+    r = core.SeqRunner(n, sq.H * sq.W, sq.imu_range_for_scan(n - 1)[1], max_range=70.0, min_range=1.0,
+                       use_imu_prediction=True, with_ekf=True, gn_lanes_per_point=8, gn_threads=512)
+    _upload(sq, r, n)
+    r.run()
+    out = r.results()
+    d = np.linalg.norm(out["res_poses"][:, :3, 3] - ref["res_poses"][:, :3, 3], axis=1)
+    assert d.max() <= 1e-9, d
+    for k in range(n):
+        for key in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "sum_cand", "map_voxels", "map_points"):
+            assert out["stats"][k][key] == ref["stats"][k][key], (k, key)
