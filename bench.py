@@ -189,9 +189,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seqs-per-gpu", type=int, default=8,
-                    help="independent sequences per GPU (SURVEY.md 8(e), second level): 8 = one per XCD in the batched runner "
-                         "(default); 1 = the single-sequence latency pipeline (one sequence over the whole chip)")
+    ap.add_argument("--seqs-per-gpu", type=int, default=16,
+                    help="independent sequences per GPU (SURVEY.md 8(e), second level), batched runner: 8 = one per XCD, 16 "
+                         "(default) / 32 = two / four per XCD - one Gauss-Newton loop alone leaves an XCD latency-bound, a "
+                         "second one fills the gaps; 1 = the single-sequence latency pipeline (one sequence over the whole chip)")
     ap.add_argument("--seed-base", type=int, default=1000, help="sequence s of SURVEY.md 8(d) uses seed seed_base + s")
     ap.add_argument("--equal-work", action="store_true",
                     help="every rank registers its own copy of sequences seed_base .. seed_base + S - 1 (equal work per GPU) "
@@ -230,22 +231,28 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if args.seqs_per_gpu < 1 or args.seqs_per_gpu > 32:
+        sys.exit("bench.py: --seqs-per-gpu must be in [1, 32]")
+    multi = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # a rank of a multi-process run
+    dist = None
+    torch = None
+    ctl = None
+    if multi:
+        # torch FIRST: it bundles its own HIP runtime, and libptudes_mi.so (linked against the system's) has to find that
+        # one already loaded - the other order puts two runtimes into the process and torch then sees no GPU
+        import datetime
+        import torch
+        import torch.distributed as dist
+        n_dev = torch.cuda.device_count()  # (does not initialise a device)
     import ptudes_lab_amd  # noqa: F401
     from ptudes_lab_amd import _lib, core, synth
-    if args.seqs_per_gpu < 1 or args.seqs_per_gpu > 8:
-        sys.exit("bench.py: --seqs-per-gpu must be in [1, 8]")
-    n_dev = _lib.lib().ptl_device_count()  # (hipGetDeviceCount: does not initialise a device)
+    if not multi:
+        n_dev = _lib.lib().ptl_device_count()  # (hipGetDeviceCount: does not initialise a device)
     if n_dev < 1:
         sys.exit("bench.py: no HIP device - the HIP path is the only path")
     local_rank = (int(os.environ.get("LOCAL_RANK", "0")) % n_dev) if args.device < 0 else args.device
     shared_device = world > n_dev  # several ranks on one GPU (1-GPU box): RCCL refuses duplicate devices, the gather goes over gloo
-    dist = None
-    torch = None
-    ctl = None
-    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # a rank of a multi-process run
-        import datetime
-        import torch
-        import torch.distributed as dist
+    if multi:
         # RCCL carries the one collective of the path, the trajectory gather after the run.  Its communicator is brought
         # up there and not before: a live RCCL communicator in the process stretches the cross-stream hand-overs of the
         # scan pipeline from 63 to 110 us per scan (2700 -> 2400 scans/s, measured with one rank).  Barriers and the

@@ -1378,8 +1378,11 @@ __device__ __forceinline__ void gn8_accumulate(double (&M)[GN8_ROW_ENTRIES], V3 
     M[13] += w * cx; M[14] += w * cy; M[15] += w * cz;
     M[16] += 1.0;
 }
-template <int PC>
-__device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G, const int wg) {
+// GC (compile time): the number of cooperating workgroups when it is 32 / 16 / 8 (the batched runner's shares of an XCD:
+// the exchange then unrolls over exactly that many rows), 0 = any (run-time G).
+template <int PC, int GC>
+__device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt, const int wg) {
+    const int G = GC > 0 ? GC : G_rt;
     __shared__ int missq[GN8_MAX_THREADS];            // points of this chunk whose answer row did not settle them, compacted
     __shared__ int wsum[GN8_MAX_THREADS / 64];
     __shared__ double part[GN8_ROW_ENTRIES][16];
@@ -1674,22 +1677,22 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G, co
                                (unsigned long long)half | ((unsigned long long)flag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const long long c2 = GN_CLK();
-        // ---- one-hop exchange.  G == 32 (the batched runner's share of an XCD): the FIRST WAVEFRONT alone polls all 32 rows -
+        // ---- one-hop exchange.  G == 32 / 16 / 8 (the batched runner's share of an XCD for 1 / 2 / 4 sequences per XCD): the FIRST WAVEFRONT alone polls all 32 rows -
         // lane w <-> word w of every row, the 32 loads of a round in flight together - adds them in (group, member) order in
         // registers and solves straight away: no LDS staging, no workgroup barrier between the last arrival and the
         // factorisation.  Other G: every 32-lane group polls one row into LDS, then the sums.
         long long c3 = c2;
-        if (G == 32) {
+        if (GC > 0) {
             if (tid < 64) {
                 const bool mine = tid < 2 * GN8_ROW_ENTRIES;
-                unsigned h[32];
+                unsigned h[GC > 0 ? GC : 32];
                 unsigned spins = 0;
                 for (;;) {
                     unsigned bad = 0u;
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) {
+                    for (int j = 0; j < (GC > 0 ? GC : 32); ++j) {
                         unsigned long long vv = (unsigned long long)flag << 32;
-                        if (mine) vv = __hip_atomic_load(c.gn_rows_ll + ((size_t)par * 32 + j) * GN_LL_WORDS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (mine) vv = __hip_atomic_load(c.gn_rows_ll + ((size_t)par * G + j) * GN_LL_WORDS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         bad |= (unsigned)(vv >> 32) ^ flag;
                         h[j] = (unsigned)vv;
                     }
@@ -1699,8 +1702,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G, co
                 }
                 double t = 0.0;
 #pragma unroll
-                for (int g = 0; g < 8; ++g)
-                    t += (((0.0 + gn_ll_join(h[g])) + gn_ll_join(h[g + 8])) + gn_ll_join(h[g + 16])) + gn_ll_join(h[g + 24]);
+                for (int g = 0; g < 8; ++g) {  // members g, g + 8, ... of group g in order, then the groups in order
+                    double sg = 0.0 + gn_ll_join(h[g]);
+                    if (GC > 8) sg += gn_ll_join(h[(g + 8) % (GC > 0 ? GC : 32)]);
+                    if (GC > 16) { sg += gn_ll_join(h[(g + 16) % (GC > 0 ? GC : 32)]); sg += gn_ll_join(h[(g + 24) % (GC > 0 ? GC : 32)]); }
+                    t += sg;
+                }
                 if (mine && (tid & 1) == 0) mom[tid >> 1] = t;
                 if (!ok && tid == 0) gn_raise_abort(st);
                 c3 = GN_CLK();
@@ -1839,7 +1846,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G, co
 // one sequence, 8 lanes per point (gn_workgroups <= 64: one-hop exchange; more: two hops through 8 group leaders)
 template <int PC>
 __global__ __launch_bounds__(GN8_MAX_THREADS) void k_gn_loop8(Ctx c, int mode) {
-    gn8_body<PC>(c, mode, (int)gridDim.x, (int)blockIdx.x);
+    if (gridDim.x == 32) gn8_body<PC, 32>(c, mode, 32, (int)blockIdx.x);       // (the exchange's association is the same
+    else if (gridDim.x == 16) gn8_body<PC, 16>(c, mode, 16, (int)blockIdx.x);  // in every instance: a batch member equals
+    else if (gridDim.x == 8) gn8_body<PC, 8>(c, mode, 8, (int)blockIdx.x);     // the single run with as many workgroups)
+    else gn8_body<PC, 0>(c, mode, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ K7-K9
@@ -2137,18 +2147,30 @@ __global__ __launch_bounds__(256) void kb_map_rebuild(const SeqCtx* a, int scan_
 // its workgroups meet through the one-hop exchange of gn_loop_body<XL = true> - nothing crosses the chip - and it leaves
 // the loop on its own convergence.  Per sequence the point -> workgroup assignment, the reduction trees and the
 // arithmetic are those of k_gn_loop launched alone with gridDim / 8 workgroups: bit-identical results.
-#define GN_MAX_SEQ 8
-template <int PC>
+#define GN_MAX_SEQ 32  /* up to four sequences per XCD */
+// S <= 8: sequence s <-> XCD s with all gridDim / 8 workgroups of that XCD.  S > 8: the XCD's workgroups are split evenly
+// among the sequences s, s + 8, s + 16, ... it hosts (spx of them, a power of two): one sequence alone leaves an XCD
+// latency-bound and mostly idle (it costs the same per iteration as eight on eight), a second and a fourth loop fill
+// the gaps.
+__device__ __forceinline__ bool kx_assign(int S, int& s, int& G, int& wg) {
+    const int x = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3), J = (int)(gridDim.x >> 3);
+    const int spx = S <= 8 ? 1 : (S <= 16 ? 2 : 4);
+    G = J / spx;
+    s = x + 8 * (j / G);
+    wg = j % G;
+    return s < S;
+}
+template <int PC, int GC>
 __global__ __launch_bounds__(GN8_MAX_THREADS) void kx_gn_loop8(const SeqCtx* a, int S, int scan_k) {
-    const int s = (int)(blockIdx.x & 7u);
-    if (s >= S) return;
+    int s, G, wg;
+    if (!kx_assign(S, s, G, wg)) return;
     const Ctx c = load_seq_ctx(a, s, scan_k);
-    gn8_body<PC>(c, 0, (int)(gridDim.x >> 3), (int)(blockIdx.x >> 3));
+    gn8_body<PC, GC>(c, 0, G, wg);
 }
 template <int PC>
 __global__ __launch_bounds__(GN_MAX_THREADS) void kx_gn_loop(const SeqCtx* a, int S, int scan_k) {
-    const int s = (int)(blockIdx.x & 7u);
-    if (s >= S) return;
+    int s, G, wg;
+    if (!kx_assign(S, s, G, wg)) return;
     const Ctx c = load_seq_ctx(a, s, scan_k);
-    gn_loop_body<PC, true, true>(c, 0, (int)(gridDim.x >> 3), (int)(blockIdx.x >> 3));
+    gn_loop_body<PC, true, true>(c, 0, G, wg);
 }

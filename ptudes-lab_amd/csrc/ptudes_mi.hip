@@ -342,7 +342,7 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     // ends with the post-ICP bookkeeping (kiss.py:116-128).  Dense scans (more source points than 32-lane groups) run the
     // variant that keeps probe results in memory; the previous scan's N_s, copied back without a wait, is the hint
     const bool dense = *h->n_src_hint > (int64_t)c.G * (h->cfg.gn_threads / 32);
-    if (h->cfg.gn_lanes_per_point == 8) { if (c.P == 20) k_gn_loop8<20><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop8<0><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
+    if (h->cfg.gn_lanes_per_point == 8) { if (c.P == 20) k_gn_loop8<20><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop8<0><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }  // (k_gn_loop8 picks its exchange instance from gridDim)
     else if (c.P == 20) { if (dense) k_gn_loop<20, true><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<20, false><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
     else { if (dense) k_gn_loop<0, true><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<0, false><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
     if (timed) HIPCHK(hipEventRecord(e1, s));
@@ -1302,7 +1302,7 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
     if (n_sequences < 1 || n_sequences > GN_MAX_SEQ) return set_err(PTL_ERR_ARG, "n_sequences must be in [1, %d]", GN_MAX_SEQ);
     if (cfg->n_scans < 1 || cfg->points_per_scan < 1) return set_err(PTL_ERR_ARG, "empty sequence");
-    if ((cfg->icp.gn_workgroups & 7) || cfg->icp.gn_workgroups > 512) return set_err(PTL_ERR_ARG, "batched runs need gn_workgroups = 8 x (workgroups per sequence <= 64)");
+    if ((cfg->icp.gn_workgroups & 31) || cfg->icp.gn_workgroups > 512) return set_err(PTL_ERR_ARG, "batched runs need gn_workgroups = a multiple of 32 (8 XCDs x up to 4 sequences each), at most 512");
     if (ptl_device_count() <= cfg->icp.device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->icp.device_id);
     HIPCHK(hipSetDevice(cfg->icp.device_id));
     ptl_batch* b = new ptl_batch();
@@ -1458,8 +1458,12 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
         }
         // one sequence per XCD: workgroups with blockIdx & 7 == s run sequence s's loop with gn_workgroups / 8 workgroups
         if (ic.gn_lanes_per_point == 8) {
-            if (ic.max_points_per_voxel == 20) kx_gn_loop8<20><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
-            else kx_gn_loop8<0><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
+            const int gseq = (ic.gn_workgroups / 8) / (S <= 8 ? 1 : S <= 16 ? 2 : 4);  // workgroups per sequence
+            const bool p20 = ic.max_points_per_voxel == 20;
+#define KX8(GC) do { if (p20) kx_gn_loop8<20, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki); \
+                     else kx_gn_loop8<0, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki); } while (0)
+            if (gseq == 32) KX8(32); else if (gseq == 16) KX8(16); else if (gseq == 8) KX8(8); else KX8(0);
+#undef KX8
         } else if (ic.max_points_per_voxel == 20) kx_gn_loop<20><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
         else kx_gn_loop<0><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
         if (b->prof) HIPCHK(hipEventRecord(e1, st));

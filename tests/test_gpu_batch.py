@@ -10,16 +10,17 @@ from ptudes_lab_amd import core, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("use_imu,S,lanes", [(True, 3, 8), (False, 3, 8), (True, 8, 8), (True, 3, 32)])
+@pytest.mark.parametrize("use_imu,S,lanes", [(True, 3, 8), (False, 3, 8), (True, 8, 8), (True, 3, 32), (True, 12, 8), (True, 20, 8)])
 def test_batch_equals_independent_runs(use_imu, S, lanes):
-    n = 10
+    n = 10 if S <= 8 else 6
     seqs = [synth.make_sequence(seed=1010 + s, n_scans=n) for s in range(S)]
     n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
     b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=use_imu, with_ekf=True, gn_lanes_per_point=lanes, gn_threads=512 if lanes == 8 else 1024)
     singles = []
     for s, sq in enumerate(seqs):
-        # one sequence of the batch runs on 256 / 8 = 32 workgroups: the independent run it must equal uses 32 too
-        r = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=use_imu, with_ekf=True, gn_workgroups=32,
+        # one sequence of the batch runs on 256 / 8 = 32 workgroups (16 / 8 when two / four sequences share an XCD): the
+        # independent run it must equal uses as many
+        r = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=use_imu, with_ekf=True, gn_workgroups=32 if S <= 8 else 16 if S <= 16 else 8,
                            gn_lanes_per_point=lanes, gn_threads=512 if lanes == 8 else 1024)
         ends = [sq.imu_range_for_scan(k)[1] for k in range(n)]
         for k in range(n):

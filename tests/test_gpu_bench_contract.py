@@ -70,17 +70,40 @@ def test_bench_launches_its_own_ranks_on_distinct_sequences(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_default_is_the_batched_runner_one_sequence_per_xcd():
-    """no flags but short: 8 independent sequences on the GPU (seeds 1000..1007), the per-XCD Gauss-Newton kernel dominant,
-    `value` = 8 scans per step, sequence 0 checked against the oracle inside the run"""
+def test_bench_default_is_the_batched_runner():
+    """no flags but short: 16 independent sequences on the GPU (seeds 1000..1015, two per XCD), the per-XCD Gauss-Newton
+    kernel dominant, `value` = 16 scans per step, sequence 0 checked against the oracle inside the run"""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "8", "--cpu-budget", "3"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 8 and d["config"]["sequence_seeds"].startswith("1000..1007")
-    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 16 and d["config"]["sequence_seeds"].startswith("1000..1015")
+    assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["kernel"] == "kx_gn_loop8" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["launches"] == 16
     assert d["roofline"]["traffic"] is None  # no PMC pass was collected on THIS workload (16 + 8 sweeps)
     assert d["cpu_baseline"]["value"] > 0 and d["parity_vs_oracle"]["max_dpos_m"] < 1e-9
+
+
+@pytest.mark.gpu
+def test_bench_under_the_launcher_gathers_over_rccl():
+    """the driver's N > 1 command form with one rank: `python -m torch.distributed.run ... bench.py --gpus 1` - the rank
+    takes the launcher's environment, torch (its bundled HIP runtime) is loaded before libptudes_mi.so, and the final
+    trajectory gather goes through the RCCL communicator with the rows copied device-to-device into a torch tensor"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8",
+                          "--warmup", "4", "--seqs-per-gpu", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 2
+    g = d["gathered_trajectories"]
+    assert g["sequences"] == 2 and g["rows_each"] == [12] and g["backend"].startswith("nccl")
