@@ -36,6 +36,8 @@ try:
     print("phase B sub-steps: see ptl_icp_debug_sums")
     ds = (C.c_double * 32)(); L.check(L.lib().ptl_icp_debug_sums(icp, ds))
     d = np.array(list(ds)); n = max(d[4], 1)
+    nscan = max(sum(1 for st in b.results(0)["stats"] if st["iterations"] > 0), 1)
+    print("misses of workgroup 0 by iteration index (mean per scan):", np.round(d[8:32] / nscan, 1).tolist())
     print("phase B per pass (wg 0, group 0): load row/key %.0f | first round %.0f | survivors %.0f | tail %.0f  ticks; passes/iter %.2f" % (d[0]/n, d[1]/n, d[2]/n, d[3]/n, d[4]/it))
 except Exception as e:
     print("no sub-steps:", e)
