@@ -1495,6 +1495,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 nmiss = total;
 #ifdef GN_PHASE_CLOCKS
                 ph_miss += total; ph_a += GN_CLK() - c0;
+                if (wg == 0 && tid == 0 && it < 24) st->dbg_sums[8 + it] += (double)total;  // misses by iteration index
 #endif
                 if (cnt) missq[woff + incl - 1] = mine1;  // (a slot at or below the own one: everybody has read its slot)
                 __syncthreads();
