@@ -1337,6 +1337,226 @@ __device__ __forceinline__ void scan_voxels8(const CT& c, const int (&pb)[NV], c
     }
 }
 
+// ---- the same group primitives for LP = 8 or 4 lanes per point (4: the two quad permutes are the whole reduction)
+template <int LP> __device__ __forceinline__ double group_minL(double v) {
+    v = fmin(v, dpp_f64<0xB1>(v));
+    v = fmin(v, dpp_f64<0x4E>(v));
+    return LP == 8 ? fmin(v, dpp_f64<0x141>(v)) : v;
+}
+template <int LP> __device__ __forceinline__ unsigned group_minL(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+    return LP == 8 ? min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true)) : v;
+}
+template <int LP> __device__ __forceinline__ int group_sumL(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    return LP == 8 ? v + __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true) : v;
+}
+template <int LP> __device__ __forceinline__ double group_bcastL(double v) {  // one lane's value, the others pass 0.0
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    return LP == 8 ? v + dpp_f64<0x141>(v) : v;
+}
+// entry q (group-uniform) of this lane's RE row entries
+template <int RE> __device__ __forceinline__ int sel_entry(const int (&r)[RE], int q) {
+    int v = r[0];
+#pragma unroll
+    for (int k = 1; k < RE; ++k) v = (q == k) ? r[k] : v;
+    return v;
+}
+// NV stored voxels against the point with LP lanes: lane l <-> stored points l, l + LP, ... - every load of the call in
+// flight before the first distance is formed.  sd = smallest distance this lane has seen lose.
+template <int PC, int LP, int NV, class CT>
+__device__ __forceinline__ void scan_voxelsL(const CT& c, const int (&pb)[NV], const int (&vx)[NV], V3 s, int laneL, double& bd, double& sd,
+                                             unsigned& border, V3& bp) {
+    const int P = (PC > 0) ? PC : c.P;
+    constexpr int NCH = (PC > 0) ? (PC + LP - 1) / LP : 24 / LP;  // chunks of LP stored points (P <= 24 when not compile-time)
+    if (P <= 24) {
+        double q[NV][NCH][3];
+        bool act[NV][NCH];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int cnt = (pb[v] < 0) ? 0 : (int)((unsigned)pb[v] >> 24);
+            const double* X = blk_x(c, pb[v] & BLK_ID_MASK);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int idx = LP * k + laneL;
+                act[v][k] = idx < cnt;
+                q[v][k][0] = act[v][k] ? X[idx] : 0.0;
+                q[v][k][1] = act[v][k] ? X[P + idx] : 0.0;
+                q[v][k][2] = act[v][k] ? X[2 * P + idx] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (act[v][k]) {
+                    const double dx = q[v][k][0] - s.x, dy = q[v][k][1] - s.y, dz = q[v][k][2] - s.z;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    const unsigned id = (unsigned)(vx[v] * 32 + LP * k + laneL);
+                    if (d2 < bd || (d2 == bd && id < border)) { sd = fmin(sd, bd); bd = d2; border = id; bp = v3(q[v][k][0], q[v][k][1], q[v][k][2]); }
+                    else sd = fmin(sd, d2);
+                }
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int cnt = (pb[v] < 0) ? 0 : (int)((unsigned)pb[v] >> 24);
+            const double* X = blk_x(c, pb[v] & BLK_ID_MASK);
+            for (int base = 0; __any(base < cnt); base += LP) {
+                const int idx = base + laneL;
+                if (idx < cnt) {
+                    const double qx = X[idx], qy = X[P + idx], qz = X[2 * P + idx];
+                    const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    const unsigned id = (unsigned)(vx[v] * 32 + idx);
+                    if (d2 < bd || (d2 == bd && id < border)) { sd = fmin(sd, bd); bd = d2; border = id; bp = v3(qx, qy, qz); }
+                    else sd = fmin(sd, d2);
+                }
+            }
+        }
+    }
+}
+// The full 27-voxel search of source point i at s by a group of LP lanes (all of them call it): probe row (re-probed when
+// the point changed voxel), box distances, first round = own voxel + last winner's voxel (+ the two nearest other boxes
+// when LP == 8), the remaining voxels exactly pruned and scanned two at a time, the new answer row.  Returns in every
+// lane the neighbour, its squared distance, found, and the candidate count of the 27 voxels.
+template <int PC, int LP>
+__device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, double inv_vs, int laneL, int gb, V3& t, double& m, bool& found, int& ctot) {
+    constexpr int RE = 32 / LP;  // row entries per lane
+    const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
+    const unsigned long long key = pack_key(kx, ky, kz);
+    int r[RE];
+    {
+        const int4* rp = (const int4*)(c.pc_pb + 32 * (size_t)i + RE * laneL);  // (requested together with the key that validates it)
+#pragma unroll
+        for (int k = 0; k < RE / 4; ++k) { const int4 v = rp[k]; r[4 * k] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w; }
+    }
+    const bool same_voxel = it > 0 && c.pc_key[i] == key;
+    if (!same_voxel) {  // uniform over the group: probe this lane's neighbour voxels, rebuild the row
+        int cs = 0;
+#pragma unroll
+        for (int q = 0; q < RE; ++q) {
+            const int ee = RE * laneL + q;
+            r[q] = (ee < 27) ? map_find(c, pack_key(kx + ee / 9 - 1, ky + (ee / 3) % 3 - 1, kz + ee % 3 - 1)) : -1;
+            cs += (r[q] < 0) ? 0 : (int)((unsigned)r[q] >> 24);
+        }
+        cs = group_sumL<LP>(cs);
+        if (laneL == 28 / RE) r[28 % RE] = cs;  // entry 28: candidates of the 27 voxels (entry 27: no last winner yet = -1)
+        int4* wp = (int4*)(c.pc_pb + 32 * (size_t)i + RE * laneL);
+#pragma unroll
+        for (int k = 0; k < RE / 4; ++k) wp[k] = make_int4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+        if (laneL == 0) c.pc_key[i] = key;
+    }
+    const int lv_raw = __shfl(r[27 % RE], gb + 27 / RE);
+    ctot = __shfl(r[28 % RE], gb + 28 / RE);
+    const int lv = (lv_raw != 13) ? lv_raw : -1;
+    const int pbc = __shfl(r[13 % RE], gb + 13 / RE);  // the point's own voxel
+    const int pbl = (lv >= 0) ? __shfl(sel_entry<RE>(r, lv % RE), gb + lv / RE) : -1;
+    double bd = 1.7976931348623157e308, sd = 1.7976931348623157e308;
+    unsigned border = 0xFFFFFFFFu;
+    V3 bp = v3(0, 0, 0);
+    // squared distance from the point to the box of each of this lane's (stored) neighbour voxels: known before any load
+    double gap2[RE];
+    {
+        double g2m[3], g2p[3];
+        const int kk[3] = {kx, ky, kz};
+        const double xx[3] = {s.x, s.y, s.z};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const int vm = kk[ax] - 1, vp = kk[ax] + 1;
+            const int bim = (vm < 0) ? vm : vm + 1, bip = (vp > 0) ? vp : vp - 1;
+            const double gm = fmax(-((double)bim * c.vs - xx[ax]) - 1e-9, 0.0), gp = fmax(((double)bip * c.vs - xx[ax]) - 1e-9, 0.0);
+            g2m[ax] = gm * gm; g2p[ax] = gp * gp;
+        }
+#pragma unroll
+        for (int q = 0; q < RE; ++q) {
+            const int ee = RE * laneL + q;
+            gap2[q] = 1.7976931348623157e308;  // not a candidate voxel: absent, the own one, the last winner's, no voxel
+            if (ee >= 27 || ee == 13 || ee == lv || r[q] < 0) continue;
+            const int cx = ee / 9, cy = (ee / 3) % 3, cz = ee % 3;
+            const double gx = cx == 0 ? g2m[0] : cx == 1 ? 0.0 : g2p[0];
+            const double gy = cy == 0 ? g2m[1] : cy == 1 ? 0.0 : g2p[1];
+            const double gz = cz == 0 ? g2m[2] : cz == 1 ? 0.0 : g2p[2];
+            gap2[q] = (gx + gy) + gz;
+        }
+    }
+    if (LP == 8) {
+        // first round: the own voxel, the last winner's and the two nearest other boxes, all loads in flight together (a
+        // voxel scanned although its box turns out to lie beyond the best distance is harmless: it is one of the 27)
+        int vsel[2], psel[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            double gl = 1.7976931348623157e308;
+            int ql = 0;
+#pragma unroll
+            for (int q = 0; q < RE; ++q) if (gap2[q] < gl) { gl = gap2[q]; ql = q; }
+            const double gmin = group_minL<LP>(gl);
+            const unsigned v = group_minL<LP>((gl == gmin && gmin < 1.0e300) ? (unsigned)(RE * laneL + ql) : 0xFFu);
+            vsel[u] = (v == 0xFFu) ? -1 : (int)v;
+            psel[u] = (v == 0xFFu) ? -1 : __shfl(sel_entry<RE>(r, (int)(v % RE)), gb + (int)((v / RE) & (LP - 1)));
+            if (v != 0xFFu && (int)(v / RE) == laneL) {
+#pragma unroll
+                for (int q = 0; q < RE; ++q) if (q == (int)(v % RE)) gap2[q] = 1.7976931348623157e308;
+            }
+        }
+        const int pb4[4] = {pbc, pbl, psel[0], psel[1]}, vx4[4] = {13, lv, vsel[0], vsel[1]};
+        scan_voxelsL<PC, LP, 4>(c, pb4, vx4, s, laneL, bd, sd, border, bp);
+    } else {
+        const int pb2[2] = {pbc, pbl}, vx2[2] = {13, lv};
+        scan_voxelsL<PC, LP, 2>(c, pb2, vx2, s, laneL, bd, sd, border, bp);
+    }
+    // the other voxels: dropped when their box lies farther than the best distance so far (exact, see nn_scan32)
+    unsigned mine = 0u;
+    double gdrop = 1.7976931348623157e308;  // smallest squared box distance among the voxels this lane dropped
+    {
+        const double m0 = group_minL<LP>(bd);
+#pragma unroll
+        for (int q = 0; q < RE; ++q) {
+            if (!(gap2[q] < 1.0e300)) continue;
+            if (gap2[q] > m0) gdrop = fmin(gdrop, gap2[q]); else mine |= 1u << q;
+        }
+    }
+    for (;;) {  // the surviving voxels, two at a time (their loads in flight together)
+        unsigned cand = mine ? (unsigned)(RE * laneL + __ffs(mine) - 1) : 0xFFu;
+        const unsigned v0 = group_minL<LP>(cand);
+        if (v0 == 0xFFu) break;  // uniform over the group
+        if ((int)(v0 / RE) == laneL) mine &= mine - 1u;
+        cand = mine ? (unsigned)(RE * laneL + __ffs(mine) - 1) : 0xFFu;
+        const unsigned v1 = group_minL<LP>(cand);
+        if (v1 != 0xFFu && (int)(v1 / RE) == laneL) mine &= mine - 1u;
+        const int p0 = __shfl(sel_entry<RE>(r, (int)(v0 % RE)), gb + (int)(v0 / RE));
+        const int p1 = (v1 != 0xFFu) ? __shfl(sel_entry<RE>(r, (int)(v1 % RE)), gb + (int)((v1 / RE) & (LP - 1))) : -1;
+        const int pb2[2] = {p0, p1}, vx2[2] = {(int)v0, (int)v1};
+        scan_voxelsL<PC, LP, 2>(c, pb2, vx2, s, laneL, bd, sd, border, bp);
+    }
+    m = group_minL<LP>(bd);
+    found = m < 1.7976931348623157e308;
+    const unsigned bo = group_minL<LP>((bd == m) ? border : 0xFFFFFFFFu);
+    const bool win = found && bd == m && border == bo;
+    t = v3(group_bcastL<LP>(win ? bp.x : 0.0), group_bcastL<LP>(win ? bp.y : 0.0), group_bcastL<LP>(win ? bp.z : 0.0));
+    const int lv_new = found ? (int)(bo >> 5) : -1;
+    if (laneL == 27 / RE && lv_new != lv_raw) c.pc_pb[32 * (size_t)i + 27] = lv_new;
+    // the answer row: everybody else is at least sqrt(D2) away
+    const double D2 = group_minL<LP>(fmin(win ? sd : bd, gdrop));
+    double sl2 = -1.0;
+    if (found && D2 < 1.0e300) {
+        const double slack = 0.5 * (sqrt(D2) - sqrt(m)) * (1.0 - 1e-6);
+        if (slack > 1e-6) sl2 = slack * slack;
+    } else if (found) {
+        sl2 = 1.0e300;  // the only candidate in reach of this voxel
+    }
+    const double row8[8] = {s.x, s.y, s.z, t.x, t.y, t.z, sl2, (double)ctot};
+#pragma unroll
+    for (int k = 0; k < 8 / LP; ++k) {
+        double av = row8[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) av = ((8 / LP) * laneL + k == e) ? row8[e] : av;
+        c.pc_ans[8 * (size_t)i + (8 / LP) * laneL + k] = av;
+    }
+}
+
 // packed upper triangle of JTJ (21) + JTr (6) from the 16 moments
 //   M: 0 W | 1..3 W s | 4 xx 5 xy 6 xz 7 yy 8 yz 9 zz | 10..12 sum w r | 13..15 sum w s x r
 __device__ __forceinline__ double sums_from_moments(int e, const double* M) {
@@ -1361,6 +1581,9 @@ __device__ __forceinline__ double sums_from_moments(int e, const double* M) {
 }
 
 #define GN8_ROW_ENTRIES 18   /* 16 moments, pair count, candidate count */
+#ifndef GN8_LPB
+#define GN8_LPB 8             /* lanes per point of the full search (8 or 4) */
+#endif
 #ifndef GN8_MAX_THREADS
 #define GN8_MAX_THREADS 512  /* 8 wavefronts per workgroup: 256 VGPRs per lane, nothing spills (at 768 / 168 VGPRs the search spills ~50) */
 #endif
@@ -1425,13 +1648,6 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     // sequence's workgroups share one L2, so the voxels they touch are resident there either way.
     const int per_wg = (n - wg + G - 1) / G;  // points wg, wg + G, ...
     const int first = 0, last = per_wg;
-    // the direction (di, dj, dk) of this lane's four row entries, 2 bits per axis: 0 = -1, 1 = 0, 2 = +1
-    int dcode[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = 4 * lane8 + q;
-        dcode[q] = (e < 27) ? ((e / 9) | (((e / 3) % 3) << 2) | ((e % 3) << 4)) : -1;
-    }
     int iters = 0;
     long long ph_miss = 0, ph_a = 0, pb_t[5] = {0, 0, 0, 0, 0};
     long long ph[5] = {0, 0, 0, 0, 0};  // (only with -DGN_PHASE_CLOCKS) point loop | wg reduce + publish | exchange | - | totals + solve
@@ -1500,149 +1716,29 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 if (cnt) missq[woff + incl - 1] = mine1;  // (a slot at or below the own one: everybody has read its slot)
                 __syncthreads();
             }
-            // ---- phase B, 8 LANES PER POINT: the full search of the noted points, 8 of them per wavefront
-            for (int k = grp8; __any(k < nmiss); k += NG8) {
-              if (k < nmiss) {
-                const long long b0 = GN_CLK();
-                const int i = missq[k];
-                const V3 s = v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]);
-                const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
-                const unsigned long long key = pack_key(kx, ky, kz);
-                // the point's probe row: lane l holds entries 4 l .. 4 l + 3 (requested together with the key that validates it)
-                int4 r = *(const int4*)(c.pc_pb + 32 * (size_t)i + 4 * lane8);
-                const bool same_voxel = it > 0 && c.pc_key[i] == key;
-                if (!same_voxel) {  // uniform over the group: probe this lane's four neighbour voxels, rebuild the row
-                    int e[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int ee = 4 * lane8 + q;
-                        e[q] = (ee < 27) ? map_find(c, pack_key(kx + ee / 9 - 1, ky + (ee / 3) % 3 - 1, kz + ee % 3 - 1)) : -1;
+            // ---- phase B, GN8_LPB LANES PER POINT: the full search of the noted points (gn8_search)
+            {
+                constexpr int LPB = GN8_LPB;
+                const int laneL = tid & (LPB - 1), gb = (tid & 63) & ~(LPB - 1);
+                for (int k = tid / LPB; __any(k < nmiss); k += NT / LPB) {
+                  if (k < nmiss) {
+                    const long long b0 = GN_CLK();
+                    const int i = missq[k];
+                    const V3 s = v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]);
+                    V3 t;
+                    double m;
+                    bool found;
+                    int ctot;
+                    gn8_search<PC, LPB>(c, i, it, s, inv_vs, laneL, gb, t, m, found, ctot);
+                    if (laneL == 0) {
+                        M[17] += (double)ctot;
+                        if (found && m < gate2) gn8_accumulate(M, s, t, kern, k2);
                     }
-                    int cs = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cs += (e[q] < 0) ? 0 : (int)((unsigned)e[q] >> 24);
-                    cs = group_sum8(cs);
-                    if (lane8 == 6) e[3] = -1;  // entry 27: no last winner yet
-                    if (lane8 == 7) e[0] = cs;  // entry 28: candidates of the 27 voxels
-                    r = make_int4(e[0], e[1], e[2], e[3]);
-                    *(int4*)(c.pc_pb + 32 * (size_t)i + 4 * lane8) = r;
-                    if (lane8 == 0) c.pc_key[i] = key;
-                }
-                const long long b1 = GN_CLK();
-                const int gb = (tid & 63) & ~7;  // first lane of this group within the wavefront
-                const int lv_raw = __shfl(r.w, gb + 6);
-                const int ctot = __shfl(r.x, gb + 7);
-                const int lv = (lv_raw != 13) ? lv_raw : -1;
-                const int pbc = __shfl(r.y, gb + 3);  // entry 13: the point's own voxel
-                const int pbl = (lv >= 0) ? __shfl(sel4(r.x, r.y, r.z, r.w, lv & 3), gb + (lv >> 2)) : -1;
-                double bd = 1.7976931348623157e308, sd = 1.7976931348623157e308;
-                unsigned border = 0xFFFFFFFFu;
-                V3 bp = v3(0, 0, 0);
-                // squared distance from the point to the box of each of this lane's (stored) neighbour voxels: it depends on
-                // the point alone, so it is known before anything is loaded
-                double gap2[4];
-                {
-                    double g2m[3], g2p[3];
-                    const int kk[3] = {kx, ky, kz};
-                    const double xx[3] = {s.x, s.y, s.z};
-#pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) {
-                        const int vm = kk[ax] - 1, vp = kk[ax] + 1;
-                        const int bim = (vm < 0) ? vm : vm + 1, bip = (vp > 0) ? vp : vp - 1;
-                        const double gm = fmax(-((double)bim * c.vs - xx[ax]) - 1e-9, 0.0), gp = fmax(((double)bip * c.vs - xx[ax]) - 1e-9, 0.0);
-                        g2m[ax] = gm * gm; g2p[ax] = gp * gp;
-                    }
-                    const int ent[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int ee = 4 * lane8 + q;
-                        gap2[q] = 1.7976931348623157e308;  // not a candidate voxel: absent, the own one, the last winner's, no voxel
-                        if (dcode[q] < 0 || ee == 13 || ee == lv || ent[q] < 0) continue;
-                        const int cx = dcode[q] & 3, cy = (dcode[q] >> 2) & 3, cz = (dcode[q] >> 4) & 3;
-                        const double gx = cx == 0 ? g2m[0] : cx == 1 ? 0.0 : g2p[0];
-                        const double gy = cy == 0 ? g2m[1] : cy == 1 ? 0.0 : g2p[1];
-                        const double gz = cz == 0 ? g2m[2] : cz == 1 ? 0.0 : g2p[2];
-                        gap2[q] = (gx + gy) + gz;
-                    }
-                }
-                // first round: the own voxel, the last winner's and the two nearest other boxes - the voxels a better point
-                // could most likely sit in - with all their loads in flight together (a voxel scanned although its box turns
-                // out to lie beyond the best distance is harmless: it is one of the 27)
-                unsigned spec = 0xFFFFFFFFu;  // the entries taken speculatively: v_a | v_b << 8
-                {
-                    int vsel[2], psel[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        double gl = 1.7976931348623157e308;
-                        int ql = 0;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) if (gap2[q] < gl) { gl = gap2[q]; ql = q; }
-                        const double gmin = group_min8(gl);
-                        const unsigned v = group_min8((gl == gmin && gmin < 1.0e300) ? (unsigned)(4 * lane8 + ql) : 0xFFu);
-                        vsel[u] = (v == 0xFFu) ? -1 : (int)v;
-                        psel[u] = (v == 0xFFu) ? -1 : __shfl(sel4(r.x, r.y, r.z, r.w, (int)(v & 3u)), gb + (int)((v >> 2) & 7u));
-                        if (v != 0xFFu && (int)(v >> 2) == lane8) {  // taken: no longer a candidate of the later rounds
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) if (q == (int)(v & 3u)) gap2[q] = 1.7976931348623157e308;
-                        }
-                    }
-                    spec = (unsigned)(vsel[0] & 0xFF) | ((unsigned)(vsel[1] & 0xFF) << 8);
-                    const int pb4[4] = {pbc, pbl, psel[0], psel[1]}, vx4[4] = {13, lv, vsel[0], vsel[1]};
-                    scan_voxels8<PC, 4>(c, pb4, vx4, s, lane8, bd, sd, border, bp);
-                }
-                const long long b2 = GN_CLK();
-                // the other voxels: dropped when their box lies farther than the best distance so far (exact, see nn_scan32)
-                unsigned mine = 0u;
-                double gdrop = 1.7976931348623157e308;  // smallest squared box distance among the voxels this lane dropped
-                {
-                    const double m0 = group_min8(bd);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (!(gap2[q] < 1.0e300)) continue;
-                        if (gap2[q] > m0) gdrop = fmin(gdrop, gap2[q]); else mine |= 1u << q;
-                    }
-                }
-                for (;;) {  // the surviving voxels, two at a time (their loads in flight together)
-                    unsigned cand = mine ? (unsigned)(4 * lane8 + __ffs(mine) - 1) : 0xFFu;
-                    const unsigned v0 = group_min8(cand);
-                    if (v0 == 0xFFu) break;  // uniform over the group
-                    if ((int)(v0 >> 2) == lane8) mine &= mine - 1u;
-                    cand = mine ? (unsigned)(4 * lane8 + __ffs(mine) - 1) : 0xFFu;
-                    const unsigned v1 = group_min8(cand);
-                    if (v1 != 0xFFu && (int)(v1 >> 2) == lane8) mine &= mine - 1u;
-                    const int p0 = __shfl(sel4(r.x, r.y, r.z, r.w, (int)(v0 & 3u)), gb + (int)(v0 >> 2));
-                    const int p1 = (v1 != 0xFFu) ? __shfl(sel4(r.x, r.y, r.z, r.w, (int)(v1 & 3u)), gb + (int)((v1 >> 2) & 7u)) : -1;
-                    const int pb2[2] = {p0, p1}, vx2[2] = {(int)v0, (int)v1};
-                    scan_voxels8<PC, 2>(c, pb2, vx2, s, lane8, bd, sd, border, bp);
-                }
-                const long long b3 = GN_CLK();
-                const double m = group_min8(bd);
-                const bool found = m < 1.7976931348623157e308;
-                const unsigned bo = group_min8((bd == m) ? border : 0xFFFFFFFFu);
-                const bool win = found && bd == m && border == bo;
-                const V3 t = v3(group_bcast8(win ? bp.x : 0.0), group_bcast8(win ? bp.y : 0.0), group_bcast8(win ? bp.z : 0.0));
-                const int lv_new = found ? (int)(bo >> 5) : -1;
-                if (lane8 == 6 && lv_new != lv_raw) c.pc_pb[32 * (size_t)i + 27] = lv_new;
-                // the answer row: everybody else is at least sqrt(D2) away
-                const double D2 = group_min8(fmin(win ? sd : bd, gdrop));
-                double sl2 = -1.0;
-                if (found && D2 < 1.0e300) {
-                    const double slack = 0.5 * (sqrt(D2) - sqrt(m)) * (1.0 - 1e-6);
-                    if (slack > 1e-6) sl2 = slack * slack;
-                } else if (found) {
-                    sl2 = 1.0e300;  // the only candidate in reach of this voxel
-                }
-                const double av = lane8 == 0 ? s.x : lane8 == 1 ? s.y : lane8 == 2 ? s.z : lane8 == 3 ? t.x : lane8 == 4 ? t.y : lane8 == 5 ? t.z
-                                : lane8 == 6 ? sl2 : (double)ctot;
-                c.pc_ans[8 * (size_t)i + lane8] = av;
-                if (lane8 == 0) {
-                    M[17] += (double)ctot;
-                    if (found && m < gate2) gn8_accumulate(M, s, t, kern, k2);
-                }
 #ifdef GN_PHASE_CLOCKS
-                { const long long b4 = GN_CLK(); pb_t[0] += b1 - b0; pb_t[1] += b2 - b1; pb_t[2] += b3 - b2; pb_t[3] += b4 - b3; pb_t[4] += 1; }
+                    { pb_t[0] += GN_CLK() - b0; pb_t[4] += 1; }
 #endif
-              }
+                  }
+                }
             }
             __syncthreads();  // the queue is reused by the next chunk
         }
