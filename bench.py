@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 GN_EVENT_EVERY = 8
 GATHER_TIMEOUT_S = 120
+CPU_MIN_SWEEPS = 300  # sweeps offered to the CPU baseline (it stops at its time budget)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -281,9 +282,14 @@ def main():
     # sequences, nothing shared, no data-path collective.  They differ by up to 40 % in GN iterations per scan, so the
     # max-over-ranks clock of such a run is the slowest sequence's; --equal-work gives every rank a private copy of the
     # same sequence(s) instead (the pure scaling measurement).
+    if world > 1:  # the ranks of one host share its cores: no oversubscription while every rank renders its sweeps
+        synth.set_threads(max(2, min(16, synth.usable_cores() // world)))
     seq_ids = [j if args.equal_work else rank + world * j for j in range(S)]
-    seqs = [synth.make_sequence(seed=args.seed_base + s, n_scans=n_total, H=args.rows, W=args.cols, min_range=args.min_range,
-                                max_range=args.max_range) for s in seq_ids]
+    # the CPU baseline wants a sample of its own size (>= CPU_MIN_SWEEPS sweeps within its time budget) however short the
+    # timed GPU run is: sequence 0 of rank 0 is generated that long, the GPU registers its first n_total sweeps
+    n_cpu = max(n_total, CPU_MIN_SWEEPS) if (world == 1 and not args.no_cpu_baseline) else n_total
+    seqs = [synth.make_sequence(seed=args.seed_base + s, n_scans=(n_cpu if j == 0 else n_total), H=args.rows, W=args.cols,
+                                min_range=args.min_range, max_range=args.max_range) for j, s in enumerate(seq_ids)]
     n_imu = seqs[0].imu_range_for_scan(n_total - 1)[1] if with_ekf else 0
     # S == 1: the single-sequence runner (its Gauss-Newton kernel caches hash probes across iterations);
     # S > 1: all sequences of this rank advance in lockstep in one batched runner (one launch per stage for all)
@@ -442,11 +448,11 @@ def main():
                          "rmse_vs_gt_m": rmse_gt},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, kiss_cpu, res_cpu = cpu_baseline(sq, n_total, use_imu, args.cpu_budget, with_ekf=with_ekf,
+            cb, kiss_cpu, res_cpu = cpu_baseline(sq, n_cpu, use_imu, args.cpu_budget, with_ekf=with_ekf,
                                                   oracle_over={"voxel_size": args.voxel_size} if args.voxel_size else None)
-            m = len(res_cpu)
+            m = min(len(res_cpu), len(est))
             line["cpu_baseline"] = cb
-            d = np.linalg.norm(est[:m, :3, 3] - res_cpu[:, :3, 3], axis=1)
+            d = np.linalg.norm(est[:m, :3, 3] - res_cpu[:m, :3, 3], axis=1)
             line["parity_vs_oracle"] = {"scans": m, "max_dpos_m": float(d.max()), "rmse_dpos_m": float(np.sqrt(np.mean(d ** 2)))}
             line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
         else:

@@ -55,6 +55,11 @@ def _l():
     return _lib
 
 
+def set_threads(n: int):
+    """threads the renderer uses per sweep (default: the usable cores, at most 16); ranks that share a host divide them"""
+    _l().ptl_synth_set_threads(max(1, int(n)))
+
+
 def usable_cores():
     """cores this process may actually use: the affinity mask capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0))
