@@ -176,6 +176,9 @@ int ptl_icp_gn_phases(ptl_icp *h, int64_t out[8]);
 int ptl_icp_gn_wg_clocks(ptl_icp *h, int64_t *out, int32_t max_wgs);
 /* diagnostic: the device state's 32 debug sums (phase-clock builds park sub-step clocks there) */
 int ptl_icp_debug_sums(ptl_icp *h, double out[32]);
+/* test hook: workgroup `wg` of the following Gauss-Newton launches returns at once (-1 = back to normal, also clears the
+ * time-out flag): the others must run into the exchange time-out, abort together and report it - not hang */
+int ptl_icp_debug_stall_workgroup(ptl_icp *h, int32_t wg);
 /* test hook: set the 22-bit launch epoch of the Gauss-Newton exchange (exercises its wrap-around) */
 int ptl_icp_debug_set_epoch(ptl_icp *h, uint32_t epoch);
 

@@ -54,6 +54,7 @@ struct DevState {
     unsigned gn_epoch;  // bumped before every single-sequence GN launch: part of the flag of its published words
     int gn_iters, gn_ncorr;
     int gn_abort;       // set by the first Gauss-Newton workgroup whose exchange poll ran out: everybody leaves the loop
+    int dbg_dead_wg;    // test hook (ptl_icp_debug_stall_workgroup): this workgroup of the next GN launches returns at once; -1 = none
     long long gn_cand;
     double gn_max_dist, gn_kernel;
     double T_icp[16];
@@ -950,6 +951,7 @@ __device__ __forceinline__ void gn_loop_body(const Ctx& c, int mode, const int G
         }
         return;
     }
+    if (wg == st->dbg_dead_wg) return;  // test hook: a workgroup that never arrives (exercises the time-out / abort path)
     const double kern = st->gn_kernel, k2 = kern * kern;
     const double gate2 = sqrt_gate(st->gn_max_dist);  // sqrt(d2) < max_dist  <=>  d2 < gate2
     const double conv2 = sqrt_gate(c.conv);           // likewise for the convergence test on |dx|
@@ -1631,6 +1633,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         }
         return;
     }
+    if (wg == st->dbg_dead_wg) return;  // test hook: a workgroup that never arrives
     const double kern = st->gn_kernel, k2 = kern * kern;
     const double gate2 = sqrt_gate(st->gn_max_dist);
     const double conv2 = sqrt_gate(c.conv);

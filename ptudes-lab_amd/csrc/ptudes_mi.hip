@@ -131,6 +131,7 @@ __global__ void k_state_init(DevState* st, int pool_cap) {
     rt_to16(I, st->model_dev); rt_to16(I, st->guess); rt_to16(I, st->new_pose); rt_to16(I, st->T_icp);
     st->free_top = pool_cap;
     st->stats_pending = -1;
+    st->dbg_dead_wg = -1;
 }
 
 static int icp_reset_device(ptl_icp* h) {
@@ -583,6 +584,18 @@ extern "C" int ptl_icp_debug_set_epoch(ptl_icp* h, uint32_t epoch) {
     int rc = icp_check_flags(h);
     if (rc) return rc;
     k_set_epoch<<<1, 64, 0, h->stream>>>(h->c.st, epoch);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PTL_OK;
+}
+
+// test hook: workgroup `wg` of the following Gauss-Newton launches returns at once (-1: back to normal).  The others run into
+// the exchange time-out, raise the abort word and leave; the call that synchronises next reports the error flag.
+__global__ void k_set_dead_wg(DevState* st, int wg) { if (threadIdx.x == 0 && blockIdx.x == 0) { st->dbg_dead_wg = wg; st->err_flags &= ~ERR_GN_TIMEOUT; } }
+extern "C" int ptl_icp_debug_stall_workgroup(ptl_icp* h, int32_t wg) {
+    if (!h) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->map_stream));
+    k_set_dead_wg<<<1, 64, 0, h->stream>>>(h->c.st, wg);
     HIPCHK(hipStreamSynchronize(h->stream));
     return PTL_OK;
 }

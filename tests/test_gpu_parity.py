@@ -519,3 +519,42 @@ def test_throughput_kernel_over_the_whole_chip_vs_oracle():
     for k in range(n):
         for key in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "sum_cand", "map_voxels", "map_points"):
             assert out["stats"][k][key] == ref["stats"][k][key], (k, key)
+
+
+def test_persistent_launch_is_checked_and_a_missing_workgroup_does_not_hang(seq):
+    """(1) a Gauss-Newton grid that cannot be co-resident is refused at create (occupancy x CUs), not discovered
+    through a poll time-out; (2) a workgroup that never arrives (test hook) makes the others time out ONCE, raise the abort
+    word and leave together - seconds, not max_iter x time-out - and the error surfaces at the next synchronising call;
+    (3) the handle works again afterwards"""
+    import time
+    from ptudes_lab_amd import _lib as L
+    with pytest.raises(RuntimeError, match="co-resident"):
+        core.Icp(70.0, 1.0, gn_workgroups=512)  # 512 x 1024 threads: two workgroups per CU do not fit
+    icp = core.Icp(70.0, 1.0)
+    x0, x1 = seq.scan(0), seq.scan(1)
+    icp.register_frame(x0, None)
+    L.check(L.lib().ptl_icp_debug_stall_workgroup(icp._h, 37))
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="0x10|timeout"):
+        icp.register_frame(x1, None)
+    assert time.perf_counter() - t0 < 120.0
+    L.check(L.lib().ptl_icp_debug_stall_workgroup(icp._h, -1))
+    ref = core.Icp(70.0, 1.0)
+    ref.register_frame(x0, None)
+    T = ref.register_frame(x1, None)
+    assert np.isfinite(T).all()
+    # the 8-lanes-per-point kernel (one-hop exchange, what a batch member runs) leaves the same way
+    import ctypes as C
+    r = core.SeqRunner(3, seq.H * seq.W, 0, max_range=70.0, min_range=1.0, with_ekf=False, gn_workgroups=32,
+                       gn_lanes_per_point=8, gn_threads=512)
+    for k in range(3):
+        r.upload_scan(k, seq.scan(k))
+    r.upload_imu(np.zeros((0, 7)), [0] * 3)
+    h = C.c_void_p()
+    L.check(L.lib().ptl_seq_icp(r._h, C.byref(h)))
+    r.run(1)
+    L.check(L.lib().ptl_icp_debug_stall_workgroup(h, 5))
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="0x10|timeout"):
+        r.advance(2)
+    assert time.perf_counter() - t0 < 120.0
