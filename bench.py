@@ -215,6 +215,8 @@ def main():
     ap.add_argument("--workload-name", type=str, default="")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default LOCAL_RANK %% visible devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-sequence", action="store_true",
+                    help="skip the extra figure of the default line: sequence 0 alone through the single-sequence latency pipeline")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--dump-traj", type=str, default="", help="rank 0 writes the gathered (T, 8) NC-GT rows of every sequence to this .npz")
     args = ap.parse_args()
@@ -457,6 +459,33 @@ def main():
             line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
         else:
             line["cpu_baseline"] = None
+        if world == 1 and S > 1 and not args.no_single_sequence:
+            # SURVEY.md 8(e) wants both figures: k sequences per GPU (`value`) and one.  Sequence 0 alone, same sweeps, through
+            # the single-sequence latency pipeline (one sequence over the whole chip, 32-lane kernel), after the timed region.
+            runner.close()  # (its 2 x 16 handles' streams would share hardware queues with the pipeline measured next)
+            one = core.SeqRunner(n_total, pps, n_imu, max_range=args.max_range, min_range=args.min_range,
+                                 use_imu_prediction=use_imu, with_ekf=with_ekf, device_id=local_rank,
+                                 **{k: v for k, v in icp_over.items() if k not in ("gn_lanes_per_point", "gn_threads", "gn_workgroups")})
+            for k in range(n_total):
+                one.upload_scan(k, sq.scan(k))
+            one.upload_imu(sq.imu[:n_imu] if with_ekf else np.zeros((0, 7)),
+                           [sq.imu_range_for_scan(k)[1] if with_ekf else 0 for k in range(n_total)])
+            one.run(W)
+            one.profile(enable=GN_EVENT_EVERY, reset=True)
+            core.device_sync(local_rank)
+            t1 = time.perf_counter()
+            one.enqueue(K)
+            one.wait()
+            core.device_sync(local_rank)
+            dt1 = time.perf_counter() - t1
+            ms1, n1 = one.profile(enable=False)
+            o1 = one.results()
+            est1 = o1["res_poses"] if with_ekf else o1["kiss_poses"]
+            line["single_sequence"] = {"value": K / dt1, "unit": "scans/s", "ms_per_step": 1e3 * dt1 / K, "kernel": "k_gn_loop",
+                                       "avg_launch_us": 1e3 * ms1 / max(n1, 1),
+                                       "max_dpos_vs_batched_m": float(np.linalg.norm(est1[:, :3, 3] - est[:len(est1), :3, 3], axis=1).max()),
+                                       "note": "sequence 0 alone (--seqs-per-gpu 1): one sequence over the whole chip"}
+            one.close()
         if gathered is not None:
             line["gathered_trajectories"] = {"sequences": len(gathered), "rows_each": sorted({len(v) for v in gathered.values()}),
                                              "backend": "gloo (ranks share a GPU; RCCL refuses duplicate devices)" if shared_device else "nccl (RCCL)"}

@@ -84,6 +84,8 @@ def test_bench_default_is_the_batched_runner():
     assert d["roofline"]["kernel"] == "kx_gn_loop8" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["launches"] == 16
     assert d["roofline"]["traffic"] is None  # no PMC pass was collected on THIS workload (16 + 8 sweeps)
     assert d["cpu_baseline"]["value"] > 0 and d["parity_vs_oracle"]["max_dpos_m"] < 1e-9
+    one = d["single_sequence"]  # k sequences per GPU and one - sequence 0 alone through the latency pipeline
+    assert one["value"] > 0 and one["kernel"] == "k_gn_loop" and one["max_dpos_vs_batched_m"] < 1e-9
 
 
 @pytest.mark.gpu
