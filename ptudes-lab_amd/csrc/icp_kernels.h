@@ -1645,12 +1645,14 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     }
     if (tid == NT - 1) cand_total_sh = 0;
     __syncthreads();
-    // Point j of this workgroup is source point wg + G j: every workgroup gets an even sample of the scan, so the number of
-    // points that need a full search is the same everywhere (with contiguous shares it ranged from 48 to 73 of 203 per
-    // iteration, and a workgroup with more than blockDim / 8 of them pays a second search pass while the others wait).  The
-    // sequence's workgroups share one L2, so the voxels they touch are resident there either way.
-    const int per_wg = (n - wg + G - 1) / G;  // points wg, wg + G, ...
-    const int first = 0, last = per_wg;
+    // The scan's source points are dealt to the workgroups in blocks of 64 consecutive points, round robin: block q of this
+    // workgroup is global block q G + wg, a wavefront of phase A takes one block (its loads coalesce), and every workgroup
+    // gets an even sample of the scan - the number of points that need a full search is then the same everywhere (with
+    // one contiguous share per workgroup it ranged from 48 to 73 of 203 per iteration, and a workgroup with more than
+    // blockDim / 8 of them pays a second search pass while the others wait).  The sequence's workgroups share one L2, so
+    // the voxels they touch are resident there either way.
+    const int nblk = (n + 63) >> 6;
+    const int my_blocks = (nblk - wg + G - 1) / G;  // blocks wg, wg + G, ...
     int iters = 0;
     long long ph_miss = 0, ph_a = 0, pb_t[5] = {0, 0, 0, 0, 0};
     long long ph[5] = {0, 0, 0, 0, 0};  // (only with -DGN_PHASE_CLOCKS) point loop | wg reduce + publish | exchange | - | totals + solve
@@ -1661,7 +1663,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         double M[GN8_ROW_ENTRIES];
 #pragma unroll
         for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
-        for (int cbase = first; cbase < last; cbase += NT) {
+        for (int qb = 0; qb < my_blocks; qb += NW) {
             // ---- phase A, ONE LANE PER POINT (one pass, one memory round trip): apply the increment, look at the point's
             // answer row.  The last full search of the point (at s0, same voxel => same 27-voxel candidate set) found t at
             // distance d0 and every other candidate - scanned, or inside a dropped voxel's box - at >= D.  After a move by
@@ -1670,9 +1672,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             // ((D - d0) / 2)^2 with a safety factor, < 0 = no answer | candidate count of the 27 voxels.  The distance, the
             // gate and the weight come from the current s either way - same values as after a search.
             {
-                const int j = cbase + tid, i = wg + G * j;
+                const int q = qb + (tid >> 6), i = ((q * G + wg) << 6) + (tid & 63);
                 int miss = -1;
-                if (j < last) {
+                if (q < my_blocks && i < n) {
                     Rt E;
                     for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
                     for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
