@@ -1244,102 +1244,28 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
 
 // ================================================================================================ K5, 8 lanes per point
 // Throughput form of the Gauss-Newton loop for workgroups that walk MANY source points per iteration (the batched
-// runner: one sequence per XCD, ~200 points per workgroup and iteration).  The 32-lanes-per-point search above is
-// VALU-issue-bound - every lane executes the whole search for a voxel that holds 7-8 points on average - so this one
-// gives a point 8 lanes (8 points per wavefront):
-//   * a voxel is scanned in chunks of 8 stored points (lane l <-> point base + l), group reductions are three DPP steps
-//     inside the VALU (quad permutes + half-row mirror), nothing goes through the LDS crossbar;
-//   * the 27 probe results of a point live in its 128-byte row in memory (lane l holds entries 4 l .. 4 l + 3; entry 27 =
-//     the voxel of the last winner, entry 28 = the candidate count of the 27 voxels), re-probed only when the point has
-//     changed voxel;
-//   * the exact pruning of nn_scan32 (own voxel + last winner's voxel first, box distance against the bound, survivors in
-//     turn) and its (distance, visiting order) minimum: the SAME correspondence for every point;
-//   * the linear system is accumulated as 16 moments sum w z_a z_b over z = (1, s, r, s x r) instead of 27 products picked
-//     per lane:  JTJ = [[ W I, -hat(Ws) ], [ ., tr(S) I - S ]] with W = sum w, Ws = sum w s, S = sum w s s^T, and
-//     JTr = [ sum w r ; sum w s x r ]  (J = [I | -hat(s)], Registration.cpp BuildLinearSystem); lane l of a group
-//     accumulates moments l and l + 8 with operands read from a 10-entry table its lane 0 wrote to LDS.
-// Same weights, same gate, same correspondences as the 32-lane kernel; the sums differ from it in association only
-// (agreement with the oracle at the 1e-9 relative level of the other kernels, poses far below the 1e-9 m bar).
-// Rows travel through the one-hop exchange (G <= 64 workgroups, all polled by everybody).
-__device__ __forceinline__ double group_min8(double v) {
-    v = fmin(v, dpp_f64<0xB1>(v));   // lane ^ 1
-    v = fmin(v, dpp_f64<0x4E>(v));   // lane ^ 2
-    return fmin(v, dpp_f64<0x141>(v));  // row_half_mirror: lane i <-> 7 - i of each 8 (every quad holds its minimum already)
-}
-__device__ __forceinline__ unsigned group_min8(unsigned v) {
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
-    return min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
-}
-__device__ __forceinline__ int group_sum8(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
-    return v + __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
-}
-// the value one lane of the group holds (everybody else passes 0.0): x + 0 = x exactly, so a sum is a broadcast
-__device__ __forceinline__ double group_bcast8(double v) {
-    v += dpp_f64<0xB1>(v);
-    v += dpp_f64<0x4E>(v);
-    return v + dpp_f64<0x141>(v);
-}
-__device__ __forceinline__ int sel4(int e0, int e1, int e2, int e3, int q) { return q == 0 ? e0 : q == 1 ? e1 : q == 2 ? e2 : e3; }
-
-// Stored voxels against the point, lane l <-> stored points l, l + 8, l + 16 (P <= 24: every load of the call is in flight
-// before the first distance is formed - one memory round trip per call instead of one per chunk of 8).  sd = smallest
-// distance this lane has seen lose.  NV voxels per call (the first round takes the point's own voxel and the last
-// winner's together).
-template <int PC, int NV, class CT>
-__device__ __forceinline__ void scan_voxels8(const CT& c, const int (&pb)[NV], const int (&vx)[NV], V3 s, int lane8, double& bd, double& sd,
-                                             unsigned& border, V3& bp) {
-    const int P = (PC > 0) ? PC : c.P;
-    if (P <= 24) {
-        double q[NV][3][3];
-        bool act[NV][3];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int cnt = (pb[v] < 0) ? 0 : (int)((unsigned)pb[v] >> 24);
-            const double* X = blk_x(c, pb[v] & BLK_ID_MASK);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int idx = 8 * k + lane8;
-                act[v][k] = idx < cnt;
-                q[v][k][0] = act[v][k] ? X[idx] : 0.0;
-                q[v][k][1] = act[v][k] ? X[P + idx] : 0.0;
-                q[v][k][2] = act[v][k] ? X[2 * P + idx] : 0.0;
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (act[v][k]) {
-                    const double dx = q[v][k][0] - s.x, dy = q[v][k][1] - s.y, dz = q[v][k][2] - s.z;
-                    const double d2 = dx * dx + dy * dy + dz * dz;
-                    const unsigned id = (unsigned)(vx[v] * 32 + 8 * k + lane8);
-                    if (d2 < bd || (d2 == bd && id < border)) { sd = fmin(sd, bd); bd = d2; border = id; bp = v3(q[v][k][0], q[v][k][1], q[v][k][2]); }
-                    else sd = fmin(sd, d2);
-                }
-    } else {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int cnt = (pb[v] < 0) ? 0 : (int)((unsigned)pb[v] >> 24);
-            const double* X = blk_x(c, pb[v] & BLK_ID_MASK);
-            for (int base = 0; __any(base < cnt); base += 8) {
-                const int idx = base + lane8;
-                if (idx < cnt) {
-                    const double qx = X[idx], qy = X[P + idx], qz = X[2 * P + idx];
-                    const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
-                    const double d2 = dx * dx + dy * dy + dz * dz;
-                    const unsigned id = (unsigned)(vx[v] * 32 + idx);
-                    if (d2 < bd || (d2 == bd && id < border)) { sd = fmin(sd, bd); bd = d2; border = id; bp = v3(qx, qy, qz); }
-                    else sd = fmin(sd, d2);
-                }
-            }
-        }
-    }
-}
-
-// ---- the same group primitives for LP = 8 or 4 lanes per point (4: the two quad permutes are the whole reduction)
+// runner: one, two or four sequences per XCD, 200-800 points per workgroup and iteration; dense scans).  The 32-lanes-per-
+// point search above is VALU-issue-bound there - every lane executes the whole search for voxels that hold 7-8 points on
+// average.  Per iteration (gn8_body):
+//   * phase A, one LANE per point, one pass: apply the increment, test the point's answer row (exact answer cache: the
+//     neighbour of the last full search provably stays the nearest while the point has moved less than a slack derived
+//     from the second-nearest distance and the dropped voxels' boxes); settled points go straight into the lane's sums;
+//   * the others are compacted in point order (deterministic) and get the full 27-voxel search with 8 lanes per point
+//     (gn8_search): 128-byte probe row per point in memory (lane l holds entries 4 l .. 4 l + 3; entry 27 = the voxel of
+//     the last winner, entry 28 = the candidate count of the 27 voxels), box distances from the point alone, first round
+//     = own + last winner's + the two nearest other voxels with every load in flight together (lane l <-> stored points
+//     l, l + 8, l + 16), the rest exactly pruned as in nn_scan32, group reductions by DPP;
+//   * the SAME correspondence, distance, gate and weight for every point as the 32-lane kernel; the linear system is
+//     accumulated as 16 moments sum w z_a z_b over z = (1, s, r, s x r) per lane instead of 27 products picked per lane:
+//     JTJ = [[ W I, -hat(Ws) ], [ ., tr(S) I - S ]] with W = sum w, Ws = sum w s, S = sum w s s^T, and
+//     JTr = [ sum w r ; sum w s x r ]  (J = [I | -hat(s)], Registration.cpp BuildLinearSystem) - the sums differ from the
+//     32-lane kernel's in association only (poses agree far below the 1e-9 m bar, integer statistics are identical);
+//   * wavefront reduction by DPP, workgroup reduction through LDS in wavefront order, one 18-entry row per workgroup;
+//     exchange in one hop (<= 64 workgroups: the first wavefront polls every row itself and solves straight away) or in
+//     two hops through 8 group leaders (one sequence over the whole chip).
+// ---- group primitives for LP = 8 or 4 lanes per point: DPP steps inside the VALU (quad permutes, for 8 lanes the half-row
+// mirror on top - every quad holds its result already, so pairing mirrored lanes is as good as xor 4); nothing goes through
+// the LDS crossbar.  group_bcastL: the value one lane of the group holds (everybody else passes 0.0; x + 0 = x exactly)
 template <int LP> __device__ __forceinline__ double group_minL(double v) {
     v = fmin(v, dpp_f64<0xB1>(v));
     v = fmin(v, dpp_f64<0x4E>(v));
