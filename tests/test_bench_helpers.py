@@ -1,0 +1,87 @@
+"""Host-side pieces of bench.py and the data tooling that need no GPU: the workload key that ties a PMC summary to the
+run it was collected on, the trajectory-row helpers of the gather, the controlled drives of the tracking experiments."""
+import importlib.util
+import json
+import os
+import types
+
+import numpy as np
+
+import ptudes_lab_amd  # noqa: F401
+from ptudes_lab_amd import parallel, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _args(**over):
+    a = dict(rows=128, cols=1024, min_range=1.0, max_range=70.0, voxel_size=0.0, seed_base=1000, warmup=20, steps=200,
+             const_velocity=False, icp_only=False, gn_lanes=0)
+    a.update(over)
+    return types.SimpleNamespace(**a)
+
+
+def test_roofline_traffic_only_from_a_pmc_pass_of_the_same_workload(tmp_path, monkeypatch):
+    b = _bench()
+    k16, k8 = b.workload_key(_args(), 16), b.workload_key(_args(), 8)
+    assert k16 != k8 and b.workload_key(_args(steps=60), 16) != k16 and b.workload_key(_args(voxel_size=0.1), 16) != k16
+    assert b.workload_key(_args(gn_lanes=8), 1) != b.workload_key(_args(), 1)
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r09_x_pmc_hbm_traffic_a.json").write_text(json.dumps({"workload_key": k8, "traffic_bytes_per_launch": 1.0e9}))
+    (prof / "r01_n_pmc_hbm_traffic.json").write_text(json.dumps({"k_gn_loop_traffic_bytes_per_launch": 2.5e7}))  # round-1 form: no key
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    assert b.pmc_traffic_for(k8) == (1.0e9, "r09_x_pmc_hbm_traffic_a.json")
+    assert b.pmc_traffic_for(k16) is None  # another workload's counters are not this run's
+
+
+def test_committed_pmc_summaries_name_their_workload():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*pmc_hbm_traffic*.json")))
+    assert files
+    for f in files:
+        d = json.load(open(f))
+        assert d.get("workload_key") and d.get("traffic_bytes_per_launch", 0) > 0 and d["hbm_bytes_per_launch"]["kernel"]
+
+
+def test_scan_and_icp_byte_models_follow_survey_8d():
+    b = _bench()
+    st = dict(iterations=10, n_src=1000, sum_cand=50000, n_valid=100000, n_down=30000, map_voxels=20000)
+    assert b.icp_bytes(st) == 10 * (12 + 27 * 16) * 1000 + 12 * 50000
+    n_raw = 131072
+    assert b.scan_bytes(st, n_raw) == (12 * n_raw + 12 * 100000) + ((12 + 16) * 100000 + 12 * 30000 + (12 + 16) * 30000 + 12 * 1000) \
+        + b.icp_bytes(st) + ((12 + 16 + 12) * 30000 + (16 + 12) * 20000)
+
+
+def test_pose_rows_round_trip():
+    rng = np.random.default_rng(2)
+    from scipy.spatial.transform import Rotation
+    T = np.tile(np.eye(4), (7, 1, 1))
+    T[:, :3, :3] = Rotation.from_rotvec(rng.normal(0, 0.5, (7, 3))).as_matrix()
+    T[:, :3, 3] = rng.normal(0, 10, (7, 3))
+    t = 1000.0 + np.arange(7) * 0.1
+    rows = parallel.poses_to_rows(t, T)
+    assert rows.shape == (7, 8) and np.allclose(np.linalg.norm(rows[:, 4:8], axis=1), 1.0)
+    t2, T2 = parallel.rows_to_poses(rows)
+    assert np.array_equal(t2, t) and np.abs(T2 - T).max() < 1e-12
+    assert parallel.poses_to_rows([], np.zeros((0, 4, 4))).shape == (0, 8)
+
+
+def test_controlled_drive_is_what_it_says():
+    seq = synth.make_path_sequence(n_scans=30, step_m=0.5, static_sweeps=3, ramp_sweeps=4, wobble_deg=1.0, heave_m=0.03)
+    gt = seq.gt_poses(0.5)
+    assert np.abs(gt[:3, :3, 3] - gt[0, :3, 3]).max() < 1e-12              # standing still for the first sweeps
+    steps = np.linalg.norm(np.diff(gt[:, :3, 3], axis=0), axis=1)
+    assert abs(steps[-1] - 0.5) < 5e-3 and np.all(np.diff(steps[2:8]) > -1e-9)  # ramps up to 0.5 m per sweep
+    tilt = np.degrees(np.arccos(np.clip(gt[:, 2, 2], -1, 1)))
+    assert tilt[:3].max() < 1e-9 and 0.2 < tilt[10:].max() < 2.0           # rocks once it moves
+    x = seq.scan(12)
+    assert x.shape == (128 * 1024, 3) and (np.linalg.norm(x, axis=1) > 0).mean() > 0.5
+    # the lane around the path is clear of obstacles
+    assert np.all(np.abs(seq.boxes[:, 1]) - seq.boxes[:, 4] > 3.9) and np.all(np.abs(seq.cyls[:, 1]) - seq.cyls[:, 2] > 3.9)
