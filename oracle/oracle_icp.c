@@ -486,12 +486,31 @@ void orc_solve6(const double sums[27], double dx[6]) {
     }
 }
 
+/* The poses of kiss-icp are Sophus::SE3d: a UNIT QUATERNION and a translation.  The 4x4 guess the reference hands over
+ * (kiss.py:108-114 -> pybind `Sophus::SE3d initial_guess(T_guess)`) becomes one on entry, and what comes back,
+ * `(T_icp * initial_guess).matrix()`, is the matrix of one: every registration re-orthonormalises the rotation.  A
+ * restatement on bare 3x3 matrices must do that explicitly - without it the constant-velocity recursion
+ * last (prev^-1 last) amplifies rounding-level non-orthogonality by ~2.4x per sweep (1e-16 -> 1e-5 in 30 sweeps) and the
+ * track is lost around sweep 35-40 on ANY input (round-2 finding).  Projection = matrix -> unit quaternion
+ * (the branch on the largest of the diagonal entries and the trace, then normalise) -> matrix. */
+static void so3_project16(double T[16]) {
+    double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]}, q[4];
+    mat_to_quat(R, q);
+    quat_to_mat(q, R);
+    T[0] = R[0]; T[1] = R[1]; T[2] = R[2]; T[4] = R[3]; T[5] = R[4]; T[6] = R[5]; T[8] = R[6]; T[9] = R[7]; T[10] = R[8];
+    T[12] = 0.0; T[13] = 0.0; T[14] = 0.0; T[15] = 1.0;
+}
+void orc_so3_project(double T[16]) { so3_project16(T); }
+
 /* Registration.cpp RegisterFrame (reference call site kiss.py:108-114) */
-void orc_register(const orc_map *m, const double *frame, int64_t n, const double guess[16], double max_dist,
+void orc_register(const orc_map *m, const double *frame, int64_t n, const double guess_in[16], double max_dist,
                   double kernel, int32_t max_iter, double conv, double out_pose[16], int32_t *iters,
                   int32_t *n_corr_last, int64_t *sum_cand) {
     if (iters) *iters = 0;
     if (n_corr_last) *n_corr_last = 0;
+    double guess[16];
+    memcpy(guess, guess_in, sizeof guess);
+    so3_project16(guess); /* Sophus::SE3d initial_guess(T_guess) */
     if (m->nblk == 0) { /* voxel_map.Empty() => return initial_guess */
         memcpy(out_pose, guess, 16 * sizeof(double));
         return;
@@ -518,6 +537,7 @@ void orc_register(const orc_map *m, const double *frame, int64_t n, const double
         if (sqrt(nn) < conv) break;
     }
     orc_se3_mul(Ticp, guess, out_pose);
+    so3_project16(out_pose); /* (T_icp * initial_guess).matrix() of an SE3d */
     free(src);
 }
 
@@ -650,6 +670,7 @@ int orc_icp_register_frame(orc_icp *h, const double *xyz, const double *t01, int
         else T_identity(last);
         orc_se3_mul(last, pred, guess);
     }
+    so3_project16(guess); /* the registration works on the SE3d of it (orc_register does the same to its copy) */
     /* :108-114 */
     double new_pose[16];
     int32_t iters = 0, nc = 0;

@@ -110,6 +110,17 @@ PTL_HD void R_to_quat(const double R[9], double q[4]) {
     const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
 }
+// The poses of kiss-icp are Sophus::SE3d (unit quaternion + translation): the guess becomes one when it enters the
+// registration, the result is the matrix of one - every registration re-orthonormalises the rotation.  On bare matrices
+// that has to be done explicitly (see oracle/oracle_icp.c so3_project16): without it the constant-velocity recursion
+// amplifies rounding-level non-orthogonality by ~2.4x per sweep and the track is lost around sweep 35-40.
+PTL_HD Rt rt_project(const Rt& a) {
+    double q[4];
+    Rt r = a;
+    R_to_quat(a.R, q);
+    quat_to_R(q, r.R);
+    return r;
+}
 PTL_HD void rotvec_to_R(const double v[3], double R[9]) {
     const double a = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     double s;

@@ -821,9 +821,9 @@ __device__ __forceinline__ PointWalk point_walk(int n, int G, int wg, int NG, in
 // row.  full != 0 => a real scan (trajectory + stats row, closes with finish_pending); 0 => ptl_icp_align.
 __device__ __forceinline__ const double* guess_src(const Ctx& c) { return c.ext_guess ? c.ext_guess : c.st->guess; }
 __device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_empty, int full) {
-    Rt guess = rt_from16(guess_src(c));
-    if (c.ext_guess) rt_to16(guess, st->guess);
-    Rt np = map_empty ? guess : rt_mul(rt_from16(st->T_icp), guess);
+    const Rt guess = rt_project(rt_from16(guess_src(c)));  // Sophus::SE3d initial_guess(T_guess): as the kernel registered it
+    rt_to16(guess, st->guess);
+    const Rt np = map_empty ? guess : rt_project(rt_mul(rt_from16(st->T_icp), guess));  // (T_icp * initial_guess).matrix()
     rt_to16(np, st->new_pose);
     if (!full) return;
     Rt gain = rt_mul(rt_inv(guess), np);  // kiss.py:116, :128
@@ -964,13 +964,13 @@ __device__ __forceinline__ void gn_loop_body(const Ctx& c, int mode, const int G
             for (int b = a; b < 6; ++b) { if (o == lane32) { ia = a; ib = b; } ++o; }
         if (lane32 >= 21) { ia = lane32 - 21; ib = 6; }
     }
-    if (tid < 12) {
-        // element tid of [R | t] of the guess, read straight from the 4x4 (indexing a local copy by tid would put it, and
-        // with it the whole kernel, on scratch memory)
-        double gv = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
-        if (mode != 1) { const double* g16 = guess_src(c); gv = (tid < 9) ? g16[4 * (tid / 3) + (tid % 3)] : g16[4 * (tid - 9) + 3]; }
-        Esh2[1][tid] = gv;
-        Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
+    if (tid < 12) Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
+    if (tid == 64) {
+        // the guess as a Sophus::SE3d would hold it (rotation through a unit quaternion): one lane of the second wavefront
+        Rt g = rt_identity();
+        if (mode != 1) g = rt_project(rt_from16(guess_src(c)));
+        for (int k = 0; k < 9; ++k) Esh2[1][k] = g.R[k];
+        for (int k = 0; k < 3; ++k) Esh2[1][9 + k] = g.t[k];
     }
     __syncthreads();
     __shared__ long long cand_total_sh;  // (kept out of the registers: only workgroup 0 reads it, after the loop)
@@ -1564,10 +1564,11 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     const double gate2 = sqrt_gate(st->gn_max_dist);
     const double conv2 = sqrt_gate(c.conv);
     const double inv_vs = 1.0 / c.vs;
-    if (tid < 12) {
-        const double* g16 = guess_src(c);
-        Esh2[1][tid] = (tid < 9) ? g16[4 * (tid / 3) + (tid % 3)] : g16[4 * (tid - 9) + 3];
-        Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
+    if (tid < 12) Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
+    if (tid == 64) {  // the guess as a Sophus::SE3d would hold it (rotation through a unit quaternion)
+        const Rt g = rt_project(rt_from16(guess_src(c)));
+        for (int k = 0; k < 9; ++k) Esh2[1][k] = g.R[k];
+        for (int k = 0; k < 3; ++k) Esh2[1][9 + k] = g.t[k];
     }
     if (tid == NT - 1) cand_total_sh = 0;
     __syncthreads();

@@ -22,6 +22,9 @@ typedef struct {
     double dropout;                /* probability of a missing return */
     double rough_amp;              /* surface roughness: world-anchored displacement amplitude (m) */
     double rough_len;              /* ... and its longest wavelength (m) */
+    double ray_jitter_deg;         /* per-ray, per-sweep angular jitter of the firing direction (deg, uniform +-): the direction that
+                                    * is cast is jittered, the point is reported along the NOMINAL direction's jittered twin - i.e. the
+                                    * sensor knows where it fired (experiments on sampling-lattice effects; 0 = a perfect grid) */
 } ptl_synth_sensor;
 
 static inline uint64_t splitmix64(uint64_t *s) {
@@ -132,7 +135,14 @@ void ptl_synth_render(const double room[6], const double *boxes, int32_t nb, con
         double ce = cos(el * deg), se = sin(el * deg);
         for (int col = 0; col < W; ++col) {
             double az = 2.0 * M_PI * (double)col / (double)W;
-            double db[3] = {ce * cos(az), ce * sin(az), se};
+            double cej = ce, sej = se;
+            if (s->ray_jitter_deg > 0.0) {
+                uint64_t sj = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(row * W + col) * 0xD6E8FEB86659FD93ull + 0x51ull;
+                double ja = (2.0 * u01(&sj) - 1.0) * s->ray_jitter_deg * deg, je = (2.0 * u01(&sj) - 1.0) * s->ray_jitter_deg * deg;
+                az += ja;
+                cej = cos(el * deg + je); sej = sin(el * deg + je);
+            }
+            double db[3] = {cej * cos(az), cej * sin(az), sej};
             const double *P = col_poses + 12 * col;
             double dw[3] = {P[0] * db[0] + P[1] * db[1] + P[2] * db[2],
                             P[3] * db[0] + P[4] * db[1] + P[5] * db[2],

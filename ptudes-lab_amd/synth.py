@@ -25,7 +25,8 @@ GRAV = 9.782940329221166  # reference ins/data.py:10
 class _Sensor(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("el_top_deg", C.c_double), ("el_bot_deg", C.c_double),
                 ("min_range", C.c_double), ("max_range", C.c_double), ("noise_std", C.c_double),
-                ("dropout", C.c_double), ("rough_amp", C.c_double), ("rough_len", C.c_double)]
+                ("dropout", C.c_double), ("rough_amp", C.c_double), ("rough_len", C.c_double),
+                ("ray_jitter_deg", C.c_double)]
 
 
 _lib = None
@@ -100,6 +101,7 @@ class Sequence:
     dropout: float
     rough_amp: float = 0.0
     rough_len: float = 1.5
+    ray_jitter_deg: float = 0.0
     # fine trajectory (1 kHz)
     traj_dt: float = 1e-3
     traj_R: np.ndarray = field(default=None, repr=False)   # (n,3,3) world<-body
@@ -142,7 +144,7 @@ class Sequence:
         cp = np.ascontiguousarray(np.concatenate([T[:, :3, :3].reshape(self.W, 9), T[:, :3, 3]], axis=1))
         out = np.empty((self.H * self.W, 3), dtype=np.float32)
         s = _Sensor(self.H, self.W, 45.0, -45.0, self.min_range, self.max_range, self.noise_std, self.dropout,
-                    self.rough_amp, self.rough_len)
+                    self.rough_amp, self.rough_len, self.ray_jitter_deg)
         boxes = np.ascontiguousarray(self.boxes, dtype=np.float64)
         cyls = np.ascontiguousarray(self.cyls, dtype=np.float64)
         room = np.ascontiguousarray(self.room, dtype=np.float64)

@@ -21,7 +21,7 @@ def static_scan(seq, T, seed=7):
     W = seq.W
     cp = np.ascontiguousarray(np.tile(np.concatenate([T[:3, :3].reshape(9), T[:3, 3]]), (W, 1)))
     out = np.empty((seq.H * W, 3), dtype=np.float32)
-    s = synth._Sensor(seq.H, W, 45.0, -45.0, seq.min_range, seq.max_range, seq.noise_std, seq.dropout, seq.rough_amp, seq.rough_len)
+    s = synth._Sensor(seq.H, W, 45.0, -45.0, seq.min_range, seq.max_range, seq.noise_std, seq.dropout, seq.rough_amp, seq.rough_len, getattr(seq, 'ray_jitter_deg', 0.0))
     p = synth._p
     synth._l().ptl_synth_render(p(np.ascontiguousarray(seq.room)), p(np.ascontiguousarray(seq.boxes)), len(seq.boxes),
                                 p(np.ascontiguousarray(seq.cyls)), len(seq.cyls), C.byref(s), p(cp), C.c_uint64(seed),

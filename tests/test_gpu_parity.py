@@ -311,8 +311,14 @@ def test_known_answer_registration_on_device():
     dt, dr = _pose_diff(out_ref, out)
     assert dt <= ICP_T_TOL and dr <= ICP_R_TOL
     g = orc.se3_exp(np.array([1.0, 2.0, 3.0, 0.1, 0.2, 0.3]))
-    out, it = core.Icp(100.0, 1.0).align(body, g, 6.0, 2 / 3)       # empty map => the guess
-    assert np.array_equal(out, g) and it == 0
+    out, it = core.Icp(100.0, 1.0).align(body, g, 6.0, 2 / 3)       # empty map => the guess (as an SE3d holds it)
+    assert np.abs(out - g).max() < 1e-15 and it == 0
+    g_bad = g.copy()
+    g_bad[:3, :3] += 1e-6 * rng.normal(size=(3, 3))                   # a guess that has drifted off SO(3) comes back a rotation
+    out, _ = core.Icp(100.0, 1.0).align(body, g_bad, 6.0, 2 / 3)
+    assert np.abs(out[:3, :3] @ out[:3, :3].T - np.eye(3)).max() < 1e-15 and np.abs(out - g).max() < 1e-5
+    ref_bad, _, _, _ = orc.Map(0.7, 100.0, 20).register(body, g_bad, 6.0, 2 / 3)
+    assert np.abs(out - ref_bad).max() < 1e-15
     out, it = icp.align(body + 1000.0, np.eye(4), 6.0, 2 / 3)        # no correspondences => the guess
     assert np.array_equal(out, np.eye(4)) and it == 1
 
@@ -435,13 +441,11 @@ def test_free_running_220_sweeps_imu_mode_vs_oracle():
 
 
 def test_free_running_icp_only_vs_oracle():
-    """BASELINE config 2's mode: ICP only, the reference's default constant-velocity guess (kiss.py:102-105), no filter -
-    against the ORACLE.  On this world that loop is unstable (tests/test_tracking_diagnosis.py): it amplifies ANY
-    perturbation, rounding differences between two correct implementations included, by about 2.4 x per sweep (1e-15 m at
-    sweep 1, 4e-8 m at sweep 21, then the first differing iteration count and 7e-4 m at sweep 22, 1e-2 m at sweep 35,
-    measured) - so the bar is 1e-9 m while that leaves room for it (12 sweeps) and 1e-6 m over 20; integer statistics
-    identical throughout the first."""
-    n = 20
+    """BASELINE config 2's mode: ICP only, the reference's DEFAULT constant-velocity guess (kiss.py:102-105), no filter -
+    against the ORACLE over 200 sweeps of the benchmark's sequence.  (Until round 2 re-orthonormalised the poses the way
+    upstream's Sophus::SE3d does, this loop amplified rounding differences 2.4 x per sweep and lost the track around
+    sweep 40; it is now as tight as the IMU mode.)  The trajectory stays on the ground truth up to the bootstrap offset."""
+    n = 200
     sq = synth.make_sequence(seed=1000, n_scans=n)
     ref = _threaded_oracle(sq.events(n), max_range=70.0, min_range=1.0, with_ekf=False)
     r = core.SeqRunner(n, sq.H * sq.W, 0, max_range=70.0, min_range=1.0, with_ekf=False)
@@ -452,11 +456,40 @@ def test_free_running_icp_only_vs_oracle():
     out = r.results()
     assert len(out["kiss_poses"]) == n == len(ref["kiss_poses"])
     d = np.linalg.norm(out["kiss_poses"][:, :3, 3] - ref["kiss_poses"][:, :3, 3], axis=1)
-    assert d[:12].max() <= 1e-9 and d.max() <= 1e-6, d
-    for k in range(12):
-        for key in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "map_voxels", "map_points"):
+    assert d.max() <= 1e-9, d.max()
+    for k in range(n):
+        for key in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "sum_cand", "map_voxels", "map_points"):
             assert out["stats"][k][key] == ref["stats"][k][key], (k, key)
         assert abs(out["stats"][k]["sigma"] - ref["stats"][k]["sigma"]) <= 1e-9
+    R = out["kiss_poses"][:, :3, :3]
+    assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-14  # every pose a rotation to rounding
+    gt = sq.gt_poses(0.5)
+    gt = np.array([np.linalg.inv(gt[0]) @ g for g in gt])
+    err = np.linalg.norm(out["kiss_poses"][:, :3, 3] - gt[:, :3, 3], axis=1)
+    assert err.max() < 0.6 and abs(err[-1] - err[60]) < 0.15, (err.max(), err[60], err[-1])  # flat: the bootstrap offset
+
+
+def test_constant_velocity_vehicle_drive_on_device():
+    """200 sweeps at 10 m/s (190 m) in the reference's default mode through the device-resident loop: holds the track,
+    drift under 0.8 % of the distance travelled, and equals the oracle's trajectory to 1e-9 m"""
+    n = 200
+    sq = synth.make_path_sequence(n_scans=n, step_m=1.0, static_sweeps=2, ramp_sweeps=10, noise_std=0.01, dropout=0.02,
+                                  wobble_deg=1.0, heave_m=0.03, rough_amp=0.0, n_boxes=400, n_cyls=200, room_size=(280.0, 60.0, 200.0))
+    sq.ray_jitter_deg = 0.3
+    ref = _threaded_oracle(sq.events(n), max_range=70.0, min_range=1.0, with_ekf=False)
+    r = core.SeqRunner(n, sq.H * sq.W, 0, max_range=70.0, min_range=1.0, with_ekf=False)
+    for k in range(n):
+        r.upload_scan(k, sq.scan(k))
+    r.upload_imu(np.zeros((0, 7)), [0] * n)
+    r.run()
+    out = r.results()
+    d = np.linalg.norm(out["kiss_poses"][:, :3, 3] - ref["kiss_poses"][:, :3, 3], axis=1)
+    assert d.max() <= 1e-9, d.max()
+    gt = sq.gt_poses(0.5)
+    gt = np.array([np.linalg.inv(gt[0]) @ g for g in gt])
+    err = np.linalg.norm(out["kiss_poses"][:, :3, 3] - gt[:, :3, 3], axis=1)
+    travelled = np.linalg.norm(gt[-1, :3, 3])
+    assert travelled > 180.0 and err.max() < 0.008 * travelled, (travelled, err.max())
 
 
 def test_dense_map_config5_full_size_vs_oracle():

@@ -1,5 +1,8 @@
-"""Why the restated KISS-ICP v0.2.10 pipeline does not hold a track under the reference's DEFAULT constant-velocity guess
-(reference kiss.py:102-105) on the synthetic worlds - generator artefact or restatement bug?  (VERDICT r1, weak #1.)
+"""Round 1 found that the restated KISS-ICP v0.2.10 pipeline did not hold a track under the reference's DEFAULT constant-
+velocity guess (reference kiss.py:102-105) on the synthetic worlds - generator artefact or restatement bug?  (VERDICT r1,
+weak #1.)  Both, it turned out: the experiments below separate accuracy properties of nearest-neighbour point-to-point ICP
+on idealised worlds (1-3, still true) from THE reason the track was lost (4): the restatement kept its poses as bare
+matrices, upstream keeps them as Sophus::SE3d - a unit quaternion that is normalised at every step.
 
 The experiments below take the sequence loop out of the picture and look at single registrations (Registration.cpp
 RegisterFrame as restated in oracle/oracle_icp.c; the HIP twin runs the same cases through ptl_icp_map_add /
@@ -15,12 +18,16 @@ ptl_icp_align and must give the same numbers).  What they pin:
  3. Sampling-lattice forces remain even then.  Against a map built from GROUND-TRUTH poses and perfectly deskewed sweeps,
     from the TRUE guess, the fixed point of the nearest-neighbour iteration sits centimetres off the truth (median > 1.5 cm,
     worst > 5 cm over 14 sweeps at the initial threshold): one source point per 1.05 m voxel against 0.35 m map samples
-    on large regular planes is that accurate and no better.  A constant-velocity guess extrapolates this noise (x 2), the
-    deskew twist and the map inherit it: the free-running loop amplifies it until the track is lost after some tens of
-    sweeps (test_tracking_free_running below), while a guess that does not depend on the previous registrations (IMU
-    filter, ground truth) keeps it bounded.
-So: a property of (nearest-neighbour point-to-point ICP x idealised planar world), shared bit for bit by oracle and HIP path -
-not a divergence between them, and nothing an upstream KISS-ICP would be spared on the same input.
+    on large regular planes is that accurate and no better (a ray pattern jittered by 0.3 deg per sweep, i.e. no lattice,
+    brings the median down to 1.8 cm: tools/track_experiments.py).
+ 4. The track itself was lost to something else: through the loop guess = last (prev^-1 last) -> registration of a cloud
+    transformed by that (slightly sheared) matrix -> pose = T_icp guess -> map -> next guess, rounding-level
+    non-orthogonality of the pose matrices grew ~2.4 x per sweep (the recursion alone only adds it up linearly); the
+    rotation blocks were off SO(3) by 1e-6 at sweep 25 and the map tore apart around sweep 35-40 - on every scene, with or
+    without deskew, wobble or lattice.  Upstream cannot get there: the guess becomes a Sophus::SE3d on entry and the result is the
+    matrix of one.  With the same projection in the restatement (oracle so3_project16, HIP rt_project) the default mode
+    tracks: 0.25 % drift over a 190 m vehicle drive, the benchmark's random walks flat at their bootstrap offset
+    (test_tracking_free_running, tests/test_gpu_parity.py::test_free_running_icp_only_*).
 """
 import numpy as np
 import pytest
@@ -88,28 +95,37 @@ def test_fixed_point_against_a_ground_truth_map_is_centimetres_off():
     assert errs.max() < 0.5                 # ... but bounded: no registration runs away by itself
 
 
-@pytest.mark.parametrize("guess,ok", [("cv", False), ("gt", True)])
-def test_tracking_free_running(guess, ok):
-    """the whole pipeline (deskew, adaptive threshold, map from own poses) on a vehicle-speed drive: with the default
-    constant-velocity guess the error is metres after 60 sweeps, with an external (ground-truth) guess it stays bounded"""
-    n = 60
+def _vehicle(n, jitter=0.3):
     seq = synth.make_path_sequence(n_scans=n, step_m=1.0, static_sweeps=2, ramp_sweeps=10, noise_std=0.01, dropout=0.02,
-                                   wobble_deg=1.0, heave_m=0.03, rough_amp=0.0, n_boxes=400, n_cyls=200, room_size=(180.0, 60.0, 200.0))
+                                   wobble_deg=1.0, heave_m=0.03, rough_amp=0.0, n_boxes=400, n_cyls=200,
+                                   room_size=(max(180.0, n + 80.0), 60.0, 200.0))
+    seq.ray_jitter_deg = jitter
     gt = seq.gt_poses(0.5)
-    gt = np.array([np.linalg.inv(gt[0]) @ g for g in gt])
+    return seq, np.array([np.linalg.inv(gt[0]) @ g for g in gt])
+
+
+@pytest.mark.parametrize("guess", ["cv", "gt"])
+def test_tracking_free_running(guess):
+    """the whole pipeline (deskew, adaptive threshold, map from own poses) on a vehicle-speed drive, 10 m/s for 12 s: with
+    the reference's DEFAULT constant-velocity guess (kiss.py:102-105) it holds the track - drift well under 1 % of the
+    distance travelled, every pose a rotation to rounding - as it does with an external (ground-truth) guess.  Until the
+    registration re-orthonormalised its poses (oracle_icp.c so3_project16) the constant-velocity run lost every track
+    around sweep 35-40."""
+    n = 120
+    seq, gt = _vehicle(n)
     icp = orc.ICP(max_range=70.0, min_range=1.0)
     t01 = seq.column_times()
     orc.set_threads(min(8, synth.usable_cores()))
     try:
-        errs = [tk.err_of(icp.register_frame(seq.scan(k).astype(np.float64), t01, gt[k] if guess == "gt" else None), gt[k])[0]
-                for k in range(n)]
+        poses = [icp.register_frame(seq.scan(k).astype(np.float64), t01, gt[k] if guess == "gt" else None) for k in range(n)]
     finally:
         orc.set_threads(1)
-    errs = np.array(errs)
-    if ok:
-        assert np.nanmax(errs) < 0.5 and np.sqrt(np.mean(errs ** 2)) < 0.2, errs
-    else:
-        assert not np.all(np.isfinite(errs)) or np.nanmax(errs) > 2.0, errs
+    errs = np.array([tk.err_of(p, g) for p, g in zip(poses, gt)])
+    travelled = np.linalg.norm(gt[-1][:3, 3])
+    assert travelled > 100.0 and np.isfinite(errs).all()
+    assert errs[:, 0].max() < 0.008 * travelled and errs[:, 1].max() < 1.0, (errs[:, 0].max(), errs[:, 1].max())
+    for p in poses:
+        assert np.abs(p[:3, :3] @ p[:3, :3].T - np.eye(3)).max() < 1e-14
 
 
 @pytest.mark.gpu
