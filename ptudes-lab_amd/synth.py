@@ -186,7 +186,7 @@ class Sequence:
 
 def make_sequence(seed=1000, n_scans=100, H=128, W=1024, *, min_range=1.0, max_range=70.0, noise_std=0.01,
                   dropout=0.02, scan_hz=10.0, t_base=1626432000.0, room_size=(80.0, 60.0, 15.0),
-                  n_boxes=40, n_cyls=20, imu_noise=(0.05, 0.005), rough_amp=0.15, rough_len=1.5):
+                  n_boxes=40, n_cyls=20, imu_noise=(0.05, 0.005), rough_amp=0.15, rough_len=1.5, ray_jitter_deg=0.0):
     """Scene + random-walk trajectory + IMU for sequence `seed` (seeds 1000..1007)."""
     rng = np.random.default_rng(seed)
     lx, ly, lz = room_size
@@ -258,14 +258,15 @@ def make_sequence(seed=1000, n_scans=100, H=128, W=1024, *, min_range=1.0, max_r
     imu[:, 4:7] = wb[idx] + b_g + rng.normal(0, imu_noise[1], (len(idx), 3))
     return Sequence(H=H, W=W, n_scans=n_scans, seed=seed, scan_dt=scan_dt, t_base=t_base, room=room,
                     boxes=boxes_w, cyls=cyls_w, min_range=min_range, max_range=max_range,
-                    noise_std=noise_std, dropout=dropout, rough_amp=rough_amp, rough_len=rough_len, traj_dt=traj_dt, traj_R=Rm, traj_p=p_w, traj_vw=vw,
+                    noise_std=noise_std, dropout=dropout, rough_amp=rough_amp, rough_len=rough_len, ray_jitter_deg=ray_jitter_deg,
+                    traj_dt=traj_dt, traj_R=Rm, traj_p=p_w, traj_vw=vw,
                     traj_wb=wb, imu=imu, imu_bias_acc=b_a, imu_bias_gyr=b_g)
 
 
 def make_path_sequence(seed=2000, n_scans=100, H=128, W=1024, *, step_m=0.5, static_sweeps=0, ramp_sweeps=0, yaw_rate=0.0,
                        min_range=1.0, max_range=70.0, noise_std=0.0, dropout=0.0, scan_hz=10.0, t_base=1626432000.0,
                        room_size=None, n_boxes=None, n_cyls=None, rough_amp=0.15, rough_len=1.5, imu_noise=(0.0, 0.0),
-                       clear_halfwidth=4.0, wobble_deg=0.0, wobble_hz=1.3, heave_m=0.0):
+                       clear_halfwidth=4.0, wobble_deg=0.0, wobble_hz=1.3, heave_m=0.0, ray_jitter_deg=0.0):
     """A controlled sequence for tracking experiments (not SURVEY.md 8(d)'s random walk): the sensor drives along +x at
     `step_m` metres per sweep (0.05 = walking pace, 1.0 = 10 m/s vehicle speed), optionally standing still for the first
     `static_sweeps` sweeps (no un-deskewed motion baked into the first map), accelerating over `ramp_sweeps` sweeps
@@ -346,5 +347,6 @@ def make_path_sequence(seed=2000, n_scans=100, H=128, W=1024, *, step_m=0.5, sta
     imu[:, 4:7] = wb[idx] + b_g + rng.normal(0, 1.0, (len(idx), 3)) * imu_noise[1]
     return Sequence(H=H, W=W, n_scans=n_scans, seed=seed, scan_dt=scan_dt, t_base=t_base, room=room, boxes=boxes, cyls=cyls,
                     min_range=min_range, max_range=max_range, noise_std=noise_std, dropout=dropout, rough_amp=rough_amp,
-                    rough_len=rough_len, traj_dt=traj_dt, traj_R=Rm, traj_p=p_w, traj_vw=vw, traj_wb=wb, imu=imu,
+                    rough_len=rough_len, ray_jitter_deg=ray_jitter_deg, traj_dt=traj_dt, traj_R=Rm, traj_p=p_w, traj_vw=vw,
+                    traj_wb=wb, imu=imu,
                     imu_bias_acc=b_a, imu_bias_gyr=b_g)

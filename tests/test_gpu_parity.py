@@ -474,8 +474,8 @@ def test_constant_velocity_vehicle_drive_on_device():
     drift under 0.8 % of the distance travelled, and equals the oracle's trajectory to 1e-9 m"""
     n = 200
     sq = synth.make_path_sequence(n_scans=n, step_m=1.0, static_sweeps=2, ramp_sweeps=10, noise_std=0.01, dropout=0.02,
-                                  wobble_deg=1.0, heave_m=0.03, rough_amp=0.0, n_boxes=400, n_cyls=200, room_size=(280.0, 60.0, 200.0))
-    sq.ray_jitter_deg = 0.3
+                                  wobble_deg=1.0, heave_m=0.03, rough_amp=0.0, n_boxes=400, n_cyls=200, room_size=(280.0, 60.0, 200.0),
+                                  ray_jitter_deg=0.3)
     ref = _threaded_oracle(sq.events(n), max_range=70.0, min_range=1.0, with_ekf=False)
     r = core.SeqRunner(n, sq.H * sq.W, 0, max_range=70.0, min_range=1.0, with_ekf=False)
     for k in range(n):

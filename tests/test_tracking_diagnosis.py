@@ -98,8 +98,7 @@ def test_fixed_point_against_a_ground_truth_map_is_centimetres_off():
 def _vehicle(n, jitter=0.3):
     seq = synth.make_path_sequence(n_scans=n, step_m=1.0, static_sweeps=2, ramp_sweeps=10, noise_std=0.01, dropout=0.02,
                                    wobble_deg=1.0, heave_m=0.03, rough_amp=0.0, n_boxes=400, n_cyls=200,
-                                   room_size=(max(180.0, n + 80.0), 60.0, 200.0))
-    seq.ray_jitter_deg = jitter
+                                   room_size=(max(180.0, n + 80.0), 60.0, 200.0), ray_jitter_deg=jitter)
     gt = seq.gt_poses(0.5)
     return seq, np.array([np.linalg.inv(gt[0]) @ g for g in gt])
 
