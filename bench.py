@@ -182,7 +182,13 @@ def workload_key(args, S):
     """what a PMC pass has to have been collected on to speak for this run"""
     return (f"{args.rows}x{args.cols}_r{args.min_range:g}-{args.max_range:g}_v{(args.voxel_size or args.max_range / 100):g}_"
             f"seed{args.seed_base}_S{S}_W{args.warmup}_K{args.steps}_{'cv' if args.const_velocity else 'imu'}"
-            f"{'' if not args.icp_only else '_icponly'}{'' if not args.gn_lanes else '_L%d' % args.gn_lanes}")
+            f"{'' if not args.icp_only else '_icponly'}{'' if not args.gn_lanes else '_L%d' % args.gn_lanes}"
+            f"{'_free' if free_running(args, S) else ''}")
+
+
+def free_running(args, S):
+    """does this run use the free-running batch driver (one persistent launch, every sequence at its own pace)?"""
+    return S > 1 and not args.lockstep and args.gn_lanes in (0, 8)
 
 
 def main():
@@ -209,6 +215,10 @@ def main():
     ap.add_argument("--gn-wgs", type=int, default=0, help="workgroups of the persistent GN kernel (0 = library default)")
     ap.add_argument("--gn-threads", type=int, default=0)
     ap.add_argument("--gn-lanes", type=int, default=0, help="lanes per source point of the GN kernel: 32 | 8 (0 = the runner's default)")
+    ap.add_argument("--lockstep", action="store_true",
+                    help="batched runs: one launch per stage for all sequences (a step waits for its slowest sequence) instead of "
+                         "the free-running kernel")
+    ap.add_argument("--scans-per-launch", type=int, default=0, help="free-running driver: scans per persistent launch (0 = library default)")
     ap.add_argument("--voxel-size", type=float, default=0.0, help="override the map voxel size (default max_range/100)")
     ap.add_argument("--map-blocks", type=int, default=0, help="voxel-block pool capacity")
     ap.add_argument("--map-table", type=int, default=0, help="map hash-table slots (power of two)")
@@ -307,9 +317,11 @@ def main():
         def results(self, j): return self.r.results()
         def profile(self, **kw): return self.r.profile(**kw)
         def copy_traj(self, j, ptr, n): return self.r.copy_traj(ptr, n)
+    free = free_running(args, S)
     runner = _One() if S == 1 else core.BatchRunner(S, n_total, pps, n_imu, max_range=args.max_range,
                                                     min_range=args.min_range, use_imu_prediction=use_imu,
-                                                    with_ekf=with_ekf, device_id=local_rank, **icp_over)
+                                                    with_ekf=with_ekf, device_id=local_rank, free_running=free,
+                                                    scans_per_launch=args.scans_per_launch, **icp_over)
     for j, sq in enumerate(seqs):
         for k in range(n_total):
             runner.upload_scan(j, k, sq.scan(k))
@@ -354,11 +366,14 @@ def main():
     iters = []
     for o in outs:
         for k, s in enumerate(o["stats"][W:]):
-            if (W + k) % ev_every == 0:  # the launches the HIP events bracketed
+            if free:  # the launch carries the whole pipeline of every scan
+                gn_bytes += scan_bytes(s, pps)
+            elif (W + k) % ev_every == 0:  # the launches the HIP events bracketed
                 gn_bytes += icp_bytes(s)
             gn_bytes_all += icp_bytes(s)
             b_scan += scan_bytes(s, pps)
             iters.append(s["iterations"])
+    seq_clk = [runner.seq_clocks(j) for j in range(S)] if free else None
     n_timed = sum(len(o["stats"]) - W for o in outs)
     assert n_timed == K * S, (n_timed, K, S)
 
@@ -407,7 +422,7 @@ def main():
         ate_r, ate_t = calc_ate(list(est), list(gt_rel[: len(est)]))
         rmse_gt = float(np.sqrt(np.mean(np.sum((est[:, :3, 3] - gt_rel[: len(est), :3, 3]) ** 2, 1))))
         avg_gn_s = (gn_ms / 1e3) / max(gn_n, 1)
-        avg_gn_bytes = gn_bytes / max(gn_n, 1)  # one launch carries the GN loops of all S sequences
+        avg_gn_bytes = gn_bytes / max(gn_n, 1)  # one launch carries the GN loops (free-running: the whole scans) of all S sequences
         achieved = avg_gn_bytes / avg_gn_s if avg_gn_s > 0 else 0.0
         if args.equal_work:
             seeds_txt = f"{args.seed_base}..{args.seed_base + S - 1}" + (", a private copy on every rank (equal work per GPU)" if world > 1 else "")
@@ -427,6 +442,8 @@ def main():
                                    + (f" [{args.workload_name}]" if args.workload_name else ""),
                        "workload_key": wkey,
                        "sequences_per_gpu": S, "sequence_seeds": seeds_txt,
+                       "driver": "single sequence" if S == 1 else
+                                 "free-running (one persistent launch, every sequence at its own pace)" if free else "lockstep (one launch per stage)",
                        "scans_per_sequence": n_total, "parallelism": f"{world} independent sequence shard(s), no data-path collective"},
             "per_rank_scans_per_s": {"values": per_rank, "min": min(per_rank), "mean": float(np.mean(per_rank)), "max": max(per_rank),
                                      "note": "each rank's own K steps / its own wall time; `value` uses the max-over-ranks clock"},
@@ -434,18 +451,31 @@ def main():
                          "frac": achieved / HBM_PEAK, "traffic": pmc[0] if pmc else None,
                          "traffic_source": pmc[1] if pmc else None,
                          "measured_frac": (pmc[0] / avg_gn_s / HBM_PEAK) if (pmc and avg_gn_s > 0) else None,
-                         "kernel": ("k_gn_loop8" if args.gn_lanes == 8 else "k_gn_loop") if S == 1 else ("kx_gn_loop" if args.gn_lanes == 32 else "kx_gn_loop8"),
+                         "kernel": ("k_gn_loop8" if args.gn_lanes == 8 else "k_gn_loop") if S == 1 else
+                                   "kx_seq_run" if free else ("kx_gn_loop" if args.gn_lanes == 32 else "kx_gn_loop8"),
                          "avg_launch_us": 1e6 * avg_gn_s, "algorithmic_bytes_per_launch": avg_gn_bytes,
-                         "launches": gn_n, "timed_launches": f"every {ev_every}th of {K} (HIP events)",
-                         "note": "frac = ALGORITHMIC bytes (SURVEY 8(d): 27 probes x 16 B + every candidate x 12 B + the source, per "
-                                 "iteration) / launch time / peak; measured_frac = PMC HBM bytes of the same workload / launch time / peak"},
+                         "launches": gn_n,
+                         "timed_launches": (f"all {gn_n} persistent launches of the {K} steps (HIP events)" if free else
+                                            f"every {ev_every}th of {K} (HIP events)"),
+                         "note": ("the free-running kernel carries the WHOLE per-scan pipeline of every sequence: frac = B_scan of SURVEY "
+                                  "8(d) (pre-processing + down-sampling + the Gauss-Newton iterations + map update) of all scans of a "
+                                  "launch / launch time / peak; " if free else
+                                  "frac = ALGORITHMIC bytes (SURVEY 8(d): 27 probes x 16 B + every candidate x 12 B + the source, per "
+                                  "iteration) / launch time / peak; ") +
+                                 "measured_frac = PMC HBM bytes of the same workload / launch time / peak"},
             "whole_scan": {"algorithmic_bytes_per_scan": b_scan / max(n_timed, 1),
                            "achieved_GBps": (b_scan * world / dt) / 1e9 if world == 1 else None,
-                           "gn_share_of_wall": (avg_gn_s * K) / dt,
+                           "gn_share_of_wall": ((gn_ms / 1e3) / dt) if free else (avg_gn_s * K) / dt,
                            "mean_gn_iterations": float(np.mean(iters))},
             "map": {"voxels_end": o["stats"][-1]["map_voxels"], "points_end": o["stats"][-1]["map_points"],
                     "n_src_mean": float(np.mean([s["n_src"] for s in o["stats"][W:]])),
                     "n_down_mean": float(np.mean([s["n_down"] for s in o["stats"][W:]]))},
+            "sequence_phases_us_per_scan": None if seq_clk is None else {
+                "columns": ["K0-K4", "wait", "gauss_newton", "wait", "map_update", "filter_workgroup"],
+                "mean": [float(np.mean([c[i] for c in seq_clk])) for i in range(6)],
+                "slowest_sequence_total": float(max(sum(c[:5]) for c in seq_clk)),
+                "mean_sequence_total": float(np.mean([sum(c[:5]) for c in seq_clk])),
+                "note": "100 MHz device clock of workgroup 0 of every sequence (since the cold start); the run lasts as long as its slowest sequence"},
             "accuracy": {"ate_vs_gt_ref_style_rot": ate_r, "ate_vs_gt_ref_style_trans_m2": ate_t,
                          "rmse_vs_gt_m": rmse_gt},
         }

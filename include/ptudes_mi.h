@@ -280,6 +280,19 @@ int ptl_batch_copy_traj(ptl_batch *b, int32_t seq, void *dst_device, int64_t max
 int ptl_batch_gn_phases(ptl_batch *b, int64_t out[8]); /* like ptl_icp_gn_phases, for the shared launch */
 int ptl_batch_icp(ptl_batch *b, int32_t seq, ptl_icp **icp); /* the ICP handle of one sequence (diagnostics, map export) */
 int ptl_batch_profile(ptl_batch *b, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
+/* Which driver advances the batch (choose before the first scan of a run):
+ *   free_running != 0 (the default when gn_lanes_per_point = 8): one persistent launch (kx_seq_run) carries up to
+ *     scans_per_launch scans (0 = keep, default 256) of EVERY sequence; the workgroups of a sequence walk its whole
+ *     per-scan pipeline - reference cli/ekf_bench.py:493-563 - at their own pace, so a sequence whose Gauss-Newton loop
+ *     converges early starts its next scan instead of waiting for the slowest one.  ptl_batch_profile then times these
+ *     launches.  Needs gn_lanes_per_point = 8 and, with a filter, at least two workgroups per sequence.
+ *   free_running == 0: lockstep, one launch per stage for all sequences; a step lasts as long as its slowest sequence.
+ * Same results either way (bit-identical). */
+int ptl_batch_set_driver(ptl_batch *b, int32_t free_running, int64_t scans_per_launch);
+/* phase clocks of sequence s in the free-running kernel, 100 MHz wall-clock ticks summed since the cold start:
+ * workgroup 0's K0-K4 | its wait before the Gauss-Newton loop | the loop | its wait after it | its map update;
+ * out[5] the filter workgroup's step; out[6] scans */
+int ptl_batch_seq_clocks(ptl_batch *b, int32_t seq, int64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -355,12 +355,15 @@ class SeqRunner:
 
 
 class BatchRunner:
-    """Up to 8 independent sequences on one GPU, one XCD each (one launch per stage for all of them; in the persistent
-    Gauss-Newton launch the workgroups with blockIdx & 7 == s own sequence s).  Per-sequence results are bit-identical to
-    `SeqRunner(..., gn_workgroups=G / 8, gn_lanes_per_point=<the batch's>)`."""
+    """Up to 32 independent sequences on one GPU, each on its share of one XCD (the workgroups with blockIdx & 7 == s & 7).
+    Two drivers (`free_running`): True (the default with the 8-lane Gauss-Newton kernel) - one persistent launch carries
+    up to `scans_per_launch` scans of every sequence and each sequence advances at its own pace; False - lockstep, one
+    launch per stage for all sequences, a step lasts as long as its slowest sequence.  Either way the per-sequence
+    results are bit-identical to `SeqRunner(..., gn_workgroups=<workgroups per sequence>, gn_lanes_per_point=<the batch's>)`."""
 
     def __init__(self, n_sequences, n_scans, points_per_scan, n_imu, *, max_range=70.0, min_range=1.0,
-                 use_imu_prediction=False, with_ekf=True, device_id=0, ekf=None, **icp_over):
+                 use_imu_prediction=False, with_ekf=True, device_id=0, ekf=None, free_running=None, scans_per_launch=0,
+                 **icp_over):
         cfg = L.SeqCfg()
         icp_over.setdefault("gn_lanes_per_point", 8)  # a workgroup walks ~200 points per iteration here: the throughput form
         if icp_over["gn_lanes_per_point"] == 8:
@@ -373,6 +376,9 @@ class BatchRunner:
         self.cfg, self.S, self.n_scans = cfg, int(n_sequences), n_scans
         self._h = C.c_void_p()
         L.check(L.lib().ptl_batch_create(C.byref(cfg), self.S, C.byref(self._h)))
+        self.free_running = (cfg.icp.gn_lanes_per_point == 8) if free_running is None else bool(free_running)
+        if free_running is not None or scans_per_launch:
+            L.check(L.lib().ptl_batch_set_driver(self._h, int(self.free_running), int(scans_per_launch)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -428,6 +434,13 @@ class BatchRunner:
         rows = C.c_int64()
         L.check(L.lib().ptl_batch_copy_traj(self._h, s, C.c_void_p(dst_device_ptr), max_rows, C.byref(rows)))
         return rows.value
+
+    def seq_clocks(self, s):
+        """per-scan mean microseconds of sequence s in the free-running kernel: (K0-K4, wait, GN, wait, map update, filter)"""
+        out = (C.c_int64 * 8)()
+        L.check(L.lib().ptl_batch_seq_clocks(self._h, s, out))
+        n = max(out[6], 1)
+        return tuple(out[i] / n / 100.0 for i in range(6))
 
     def profile(self, enable=True, reset=False):
         ms, n = C.c_double(), C.c_int64()

@@ -60,6 +60,8 @@ struct DevState {
     double T_icp[16];
     double dbg_sums[32];
     long long gn_phase_clk[8];  // accumulated s_memtime ticks of WG0: nn, wg-reduce, barrier, grid-reduce, solve
+    long long seq_clk[8];       // free-running kernel, 100 MHz wall-clock ticks summed over scans: workgroup 0's K0-K4 | wait before GN |
+                                // GN | wait after GN | map update; [5] the filter workgroup's step; [6] scans; [7] stage-internal barrier waits of workgroup 0
     // pose history (kiss_icp.KissICP.poses: only first / last two are ever read)
     int n_poses, has_ext_guess;
     double pose_first[16], pose_prev[16], pose_last[16];
@@ -330,9 +332,16 @@ __global__ __launch_bounds__(256) void k_build_lut(int H, int W, const double* a
     }
 }
 
+// A stage body works on block `b` of `nb` blocks of blockDim.x consecutive points: a launch of its own passes
+// (blockIdx.x, gridDim.x); the free-running sequence kernel (kx_seq_run) walks the blocks of a scan with the workgroups
+// of one sequence.  Every thread of the workgroup calls the body (it contains workgroup barriers).
+struct Slice { int b, nb; };
+__device__ __forceinline__ Slice launch_slice() { Slice s; s.b = (int)blockIdx.x; s.nb = (int)gridDim.x; return s; }
+#define STAGE_MAX_WAVES 16  /* blockDim.x <= 1024 */
+
 // ------------------------------------------------------------------------------------------------ K1
-__device__ __forceinline__ void d_deskew_vds1(const Ctx& c) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
+    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
     DevState* st = c.st;
     bool valid = false, keyed = false;
     unsigned long long key = EMPTY_KEY;
@@ -405,8 +414,8 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c) {
 }
 
 // ------------------------------------------------------------------------------------------------ K2
-__device__ __forceinline__ void d_vds2(const Ctx& c) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void d_vds2(const Ctx& c, const Slice sl) {
+    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
     bool w1 = false;
     unsigned long long key = EMPTY_KEY;
     if (i < c.n_in) {
@@ -442,37 +451,40 @@ __device__ __forceinline__ void d_vds2(const Ctx& c) {
         if (i < c.n_in) c.slot2[i] = w1 ? hs : -1;
     }
     const int n1 = __syncthreads_count(w1 ? 1 : 0);
-    if (threadIdx.x == 0) c.bcnt1[blockIdx.x] = n1;
+    if (threadIdx.x == 0) c.bcnt1[sl.b] = n1;
 }
 
 // exclusive prefix of per-block counts + in-block rank (scan order preserved)
+// (integer sums: any grouping gives the same value; red holds 2 * STAGE_MAX_WAVES ints)
 __device__ __forceinline__ int block_offset(const int* bcnt, int b, int* red) {
+    const int nw = (int)blockDim.x >> 6;
     int s = 0;
-    for (int k = threadIdx.x; k < b; k += 256) s += bcnt[k];
+    for (int k = threadIdx.x; k < b; k += (int)blockDim.x) s += bcnt[k];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    const int tot = red[0] + red[1] + red[2] + red[3];
+    int tot = 0;
+    for (int k = 0; k < nw; ++k) tot += red[k];
     __syncthreads();
     return tot;
 }
 __device__ __forceinline__ int block_rank(bool flag, int* red, int& total) {
     const unsigned long long m = __ballot(flag);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     const int within = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) red[4 + wv] = __popcll(m);
+    if (lane == 0) red[STAGE_MAX_WAVES + wv] = __popcll(m);
     __syncthreads();
-    int off = 0;
-    for (int k = 0; k < wv; ++k) off += red[4 + k];
-    total = red[4] + red[5] + red[6] + red[7];
+    int off = 0, tot = 0;
+    for (int k = 0; k < nw; ++k) { const int v = red[STAGE_MAX_WAVES + k]; if (k < wv) off += v; tot += v; }
+    total = tot;
     __syncthreads();
     return off + within;
 }
 
 // ------------------------------------------------------------------------------------------------ K3
-__device__ __forceinline__ void d_compact_fd(const Ctx& c) {
-    __shared__ int red[8];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl) {
+    __shared__ int red[2 * STAGE_MAX_WAVES];
+    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
     bool w1 = false, w2 = false;
     if (i < c.n_in) {
         const int s1 = c.slot1[i];
@@ -482,7 +494,7 @@ __device__ __forceinline__ void d_compact_fd(const Ctx& c) {
             w2 = (s2 >= 0) && (c.vmin2[s2] == (unsigned)i);
         }
     }
-    const int off = block_offset(c.bcnt1, blockIdx.x, red);
+    const int off = block_offset(c.bcnt1, sl.b, red);
     int total;
     const int rk = block_rank(w1, red, total);
     if (w1) {
@@ -495,15 +507,15 @@ __device__ __forceinline__ void d_compact_fd(const Ctx& c) {
     }
     const int n2 = __syncthreads_count(w2 ? 1 : 0);
     if (threadIdx.x == 0) {
-        c.bcnt2[blockIdx.x] = n2;
-        if (blockIdx.x == gridDim.x - 1) c.st->n_down = off + total;
+        c.bcnt2[sl.b] = n2;
+        if (sl.b == sl.nb - 1) c.st->n_down = off + total;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ K4
-__device__ __forceinline__ void d_compact_src(const Ctx& c) {
-    __shared__ int red[8];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void d_compact_src(const Ctx& c, const Slice sl) {
+    __shared__ int red[2 * STAGE_MAX_WAVES];
+    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
     bool w2 = false;
     if (i < c.n_in) {
         const int s1 = c.slot1[i];
@@ -511,14 +523,14 @@ __device__ __forceinline__ void d_compact_src(const Ctx& c) {
         const int s2 = (s1 >= 0) ? c.slot2[i] : -1;
         w2 = (s2 >= 0) && (c.vmin2[s2] == (unsigned)i);
     }
-    const int off = block_offset(c.bcnt2, blockIdx.x, red);
+    const int off = block_offset(c.bcnt2, sl.b, red);
     int total;
     const int rk = block_rank(w2, red, total);
     if (w2) {
         const size_t o = (size_t)(off + rk) * 3;
         c.src0[o] = c.pts[3 * (size_t)i]; c.src0[o + 1] = c.pts[3 * (size_t)i + 1]; c.src0[o + 2] = c.pts[3 * (size_t)i + 2];
     }
-    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) c.st->n_src = off + total;
+    if (threadIdx.x == 0 && sl.b == sl.nb - 1) c.st->n_src = off + total;
 }
 // ------------------------------------------------------------------------------------------------ K5
 // map probe: block id of voxel `key` or -1
@@ -1888,9 +1900,9 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) void k_gn_loop8(Ctx c, int mode) {
 // AddPoints, phase a: world transform, find-or-create the voxel's table entry, join its batch list.
 // `pose` null => points are already in the world frame (stage-level API)
 __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_in, const int* n_ptr, int n_fixed,
-                                                      int use_pose) {
+                                                      int use_pose, const Slice sl) {
     const int n = n_ptr ? *n_ptr : n_fixed;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
     if (i >= n) return;
     DevState* st = c.st;
     V3 p = v3(pts_in[3 * (size_t)i], pts_in[3 * (size_t)i + 1], pts_in[3 * (size_t)i + 2]);
@@ -1936,9 +1948,9 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
     c.nxt[i] = (slot >= 0) ? atomicExch(&c.tab[slot].head, i) : -1;
 }
 // phase b: rank among this batch's points of the same voxel (by scan order) -> slot in the block
-__device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, int n_fixed) {
+__device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, int n_fixed, const Slice sl) {
     const int n = n_ptr ? *n_ptr : n_fixed;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
     if (i >= n) return;
     const int slot = c.pslot[i];
     if (slot < 0) { c.prank[i] = -1; return; }
@@ -1957,9 +1969,9 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
     }
 }
 // phase c: publish the new counts, reset the batch lists
-__device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, int n_fixed) {
+__device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, int n_fixed, const Slice sl) {
     const int n = n_ptr ? *n_ptr : n_fixed;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
     int added = 0;
     if (i < n && c.prank[i] == 0) {
         const int slot = c.pslot[i];
@@ -1984,8 +1996,8 @@ __device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, i
 
 // ------------------------------------------------------------------------------------------------ K10
 // RemovePointsFarFromLocation: a voxel goes when its FIRST point is farther than max_range from the origin
-__device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_xyz, int use_new_pose) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_xyz, int use_new_pose, const Slice sl) {
+    const int b = sl.b * (int)blockDim.x + (int)threadIdx.x;
     DevState* st = c.st;
     if (b >= st->pool_hw) return;  // block ids are handed out low-first: nothing lives above the high-water mark
     int* h = blk_hdr(c, b);
@@ -2009,8 +2021,8 @@ __device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_x
 
 // ------------------------------------------------------------------------------------------------ K11
 // after the table has been reset to EMPTY: re-enter every live voxel
-__device__ __forceinline__ void d_map_rebuild(const Ctx& c) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void d_map_rebuild(const Ctx& c, const Slice sl) {
+    const int b = sl.b * (int)blockDim.x + (int)threadIdx.x;
     if (b >= c.st->pool_hw) return;
     int* h = blk_hdr(c, b);
     if (h[0] <= 0) return;
@@ -2106,12 +2118,19 @@ __global__ __launch_bounds__(1024) void k_range_stats(const unsigned* range, int
 // Every stage exists as a device function d_*(ctx, ...); k_* runs it for one sequence (context by value), kb_* runs
 // it for S sequences in one launch (blockIdx.y = sequence, contexts in device memory): the batched driver
 // amortises every launch and, in the Gauss-Newton loop, every grid barrier over S scans.
+struct EkfState;
 struct SeqCtx {
     Ctx c;
     const float* scan_base;        // sweeps of this sequence, resident in HBM
     long long scan_stride_floats;  // floats between consecutive sweeps
-    int input_is_range, pad;
+    int input_is_range, n_scans;
     double* fd_buf[2];             // frame_down of scan k lives in buffer k & 1: the map update of scan k reads it while K3 of scan k + 1 writes the other
+    // the free-running sequence kernel (seq_kernel.h) also steps the sequence's filter and writes its outputs
+    EkfState* ekf;
+    const double* imu;             // [n_imu][7]
+    const int* imu_end;            // [n_scans] IMU samples that precede scan k
+    double *res_poses, *res_t, *rows;
+    unsigned* bar;                 // [64] the sequence's two workgroup-team barrier counters (word 0 and word 32), zeroed before every launch
 };
 __device__ __forceinline__ Ctx load_seq_ctx(const SeqCtx* a, int s, int scan_k) {
     Ctx c = a[s].c;
@@ -2126,50 +2145,50 @@ __global__ __launch_bounds__(1024) void kb_scan_prologue(const SeqCtx* a, int sc
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
     d_scan_prologue(c);
 }
-__global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) { d_deskew_vds1(c); }
+__global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) { d_deskew_vds1(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_deskew_vds1(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_deskew_vds1(c);
+    d_deskew_vds1(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_vds2(Ctx c) { d_vds2(c); }
+__global__ __launch_bounds__(256) void k_vds2(Ctx c) { d_vds2(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_vds2(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_vds2(c);
+    d_vds2(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_compact_fd(Ctx c) { d_compact_fd(c); }
+__global__ __launch_bounds__(256) void k_compact_fd(Ctx c) { d_compact_fd(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_compact_fd(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_compact_fd(c);
+    d_compact_fd(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_compact_src(Ctx c) { d_compact_src(c); }
+__global__ __launch_bounds__(256) void k_compact_src(Ctx c) { d_compact_src(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_compact_src(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_compact_src(c);
+    d_compact_src(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_in, const int* n_ptr, int n_fixed, int use_pose) { d_map_insert_a(c, pts_in, n_ptr, n_fixed, use_pose); }
+__global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_in, const int* n_ptr, int n_fixed, int use_pose) { d_map_insert_a(c, pts_in, n_ptr, n_fixed, use_pose, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_insert_a(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_insert_a(c, c.fd, &c.st->n_down_ins, 0, 1);
+    d_map_insert_a(c, c.fd, &c.st->n_down_ins, 0, 1, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_map_insert_b(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_b(c, n_ptr, n_fixed); }
+__global__ __launch_bounds__(256) void k_map_insert_b(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_b(c, n_ptr, n_fixed, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_insert_b(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_insert_b(c, &c.st->n_down_ins, 0);
+    d_map_insert_b(c, &c.st->n_down_ins, 0, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_map_insert_c(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_c(c, n_ptr, n_fixed); }
+__global__ __launch_bounds__(256) void k_map_insert_c(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_c(c, n_ptr, n_fixed, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_insert_c(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_insert_c(c, &c.st->n_down_ins, 0);
+    d_map_insert_c(c, &c.st->n_down_ins, 0, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_xyz, int use_new_pose) { d_map_prune(c, origin_xyz, use_new_pose); }
+__global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_xyz, int use_new_pose) { d_map_prune(c, origin_xyz, use_new_pose, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_prune(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_prune(c, nullptr, 1);
+    d_map_prune(c, nullptr, 1, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_map_rebuild(Ctx c) { d_map_rebuild(c); }
+__global__ __launch_bounds__(256) void k_map_rebuild(Ctx c) { d_map_rebuild(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_rebuild(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_rebuild(c);
+    d_map_rebuild(c, launch_slice());
 }
 
 // ------------------------------------------------------------------------------------------------ batched K5

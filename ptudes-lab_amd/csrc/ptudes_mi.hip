@@ -5,6 +5,7 @@
 #include "../../include/ptudes_mi.h"
 #include "ekf_kernels.h"
 #include "icp_kernels.h"
+#include "seq_kernel.h"
 
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
@@ -1262,8 +1263,11 @@ extern "C" int ptl_seq_profile(ptl_seq* s, int enable, double* gn_ms_total, int6
 }
 
 // ================================================================================================ batched runner
-// S independent sequences on ONE GPU advanced in lockstep: every stage is one launch for all S scans
-// (blockIdx.y = sequence) and the S Gauss-Newton loops share one persistent launch and its grid barrier.
+// S independent sequences on ONE GPU.  Two drivers over the same stage bodies:
+//   free-running (default with gn_lanes_per_point = 8): one persistent launch (kx_seq_run, seq_kernel.h) carries up to
+//     scans_per_launch scans of every sequence; each sequence's workgroups walk its pipeline at their own pace;
+//   lockstep: every stage is one launch for all S scans (blockIdx.y = sequence), the S Gauss-Newton loops share one
+//     persistent launch, and a step lasts as long as its slowest sequence.
 struct ptl_batch {
     ptl_seq_cfg cfg;
     int S;
@@ -1277,6 +1281,10 @@ struct ptl_batch {
     ptl_ekf* ekf[GN_MAX_SEQ];
     float* d_scans[GN_MAX_SEQ];
     double* d_imu[GN_MAX_SEQ];
+    int* d_imu_end[GN_MAX_SEQ];
+    unsigned* d_bar;            // [GN_MAX_SEQ][64] team barrier counters of the free-running kernel
+    bool free_running;
+    int64_t scans_per_launch;
     std::vector<int64_t> imu_end[GN_MAX_SEQ];
     double *d_res_poses[GN_MAX_SEQ], *d_res_t[GN_MAX_SEQ], *d_rows[GN_MAX_SEQ];
     unsigned char is_range;
@@ -1292,17 +1300,44 @@ struct ptl_batch {
     int64_t gn_launches;
 };
 
+// launch geometry of the free-running kernel: workgroups per sequence (GC template instance) as in kx_assign
+static int batch_gseq(const ptl_batch* b) { return (b->cfg.icp.gn_workgroups / 8) / (b->S <= 8 ? 1 : b->S <= 16 ? 2 : 4); }
+template <int GC>
+static hipError_t seq_run_occupancy(bool p20, int threads, int* per_cu) {
+    return p20 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kx_seq_run<20, GC>, threads, 0)
+               : hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kx_seq_run<0, GC>, threads, 0);
+}
+// every workgroup of the persistent launch has to be resident (they wait for each other); a team needs a workgroup
+// beside the filter's
+static int batch_check_seq_run(ptl_batch* b) {
+    const ptl_icp_cfg& ic = b->cfg.icp;
+    if (ic.gn_lanes_per_point != 8) return set_err(PTL_ERR_ARG, "free-running batches use the 8-lane Gauss-Newton kernel (gn_lanes_per_point = 8)");
+    const int gseq = batch_gseq(b);
+    if (gseq < 2 && b->cfg.with_ekf) return set_err(PTL_ERR_ARG, "free-running batches with a filter need at least 2 workgroups per sequence");
+    if (gseq < 1) return set_err(PTL_ERR_ARG, "gn_workgroups too small for %d sequences", b->S);
+    int per_cu = 0, cus = 0;
+    const bool p20 = ic.max_points_per_voxel == 20;
+    hipError_t e = gseq == 32 ? seq_run_occupancy<32>(p20, ic.gn_threads, &per_cu) : gseq == 16 ? seq_run_occupancy<16>(p20, ic.gn_threads, &per_cu)
+                 : gseq == 8 ? seq_run_occupancy<8>(p20, ic.gn_threads, &per_cu) : seq_run_occupancy<0>(p20, ic.gn_threads, &per_cu);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ic.device_id);
+    if (e != hipSuccess) return set_err(PTL_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
+    if ((int64_t)per_cu * cus < ic.gn_workgroups)
+        return set_err(PTL_ERR_STATE, "free-running batch: %d workgroups x %d threads cannot be co-resident on device %d (%d CUs x %d per CU): lower gn_workgroups",
+                       ic.gn_workgroups, ic.gn_threads, ic.device_id, cus, per_cu);
+    return PTL_OK;
+}
 extern "C" int ptl_batch_destroy(ptl_batch* b) {
     if (!b) return PTL_OK;
     (void)hipSetDevice(b->cfg.icp.device_id);
     for (int s = 0; s < b->S; ++s) {
         if (b->icp[s]) icp_free(b->icp[s]);
         if (b->ekf[s]) ptl_ekf_destroy(b->ekf[s]);
-        void* ptrs[] = {b->d_scans[s], b->d_imu[s], b->d_res_poses[s], b->d_res_t[s], b->d_rows[s]};
+        void* ptrs[] = {b->d_scans[s], b->d_imu[s], b->d_res_poses[s], b->d_res_t[s], b->d_rows[s], b->d_imu_end[s]};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
     if (b->d_ctx) (void)hipFree(b->d_ctx);
+    if (b->d_bar) (void)hipFree(b->d_bar);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->ev_gn) (void)hipEventDestroy(b->ev_gn);
     if (b->ev_side) (void)hipEventDestroy(b->ev_side);
@@ -1321,10 +1356,12 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     ptl_batch* b = new ptl_batch();
     b->cfg = *cfg;
     b->S = n_sequences;
-    b->stream = nullptr; b->d_ctx = nullptr; b->lut = nullptr; b->is_range = 0;
+    b->stream = nullptr; b->d_ctx = nullptr; b->lut = nullptr; b->is_range = 0; b->d_bar = nullptr;
+    b->free_running = cfg->icp.gn_lanes_per_point == 8;
+    b->scans_per_launch = 256;
     b->next_scan = 0; b->n_out = 0; b->ctx_dirty = true; b->prof = false; b->ev_used = 0; b->gn_ms = 0; b->gn_launches = 0;
     for (int s = 0; s < GN_MAX_SEQ; ++s) {
-        b->icp[s] = nullptr; b->ekf[s] = nullptr; b->d_scans[s] = nullptr; b->d_imu[s] = nullptr;
+        b->icp[s] = nullptr; b->ekf[s] = nullptr; b->d_scans[s] = nullptr; b->d_imu[s] = nullptr; b->d_imu_end[s] = nullptr;
         b->d_res_poses[s] = nullptr; b->d_res_t[s] = nullptr; b->d_rows[s] = nullptr; b->imu_pos[s] = 0;
     }
     int rc = PTL_OK;
@@ -1345,11 +1382,15 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
         if (rc == PTL_OK &&
             (hipMalloc((void**)&b->d_scans[s], (size_t)cfg->n_scans * cfg->points_per_scan * 12) != hipSuccess ||
              dalloc(&b->d_imu[s], nim * 7) != hipSuccess || dalloc(&b->d_res_poses[s], (size_t)cfg->n_scans * 16) != hipSuccess ||
-             dalloc(&b->d_res_t[s], (size_t)cfg->n_scans) != hipSuccess || dalloc(&b->d_rows[s], (size_t)cfg->n_scans * 8) != hipSuccess))
+             dalloc(&b->d_res_t[s], (size_t)cfg->n_scans) != hipSuccess || dalloc(&b->d_rows[s], (size_t)cfg->n_scans * 8) != hipSuccess ||
+             dalloc(&b->d_imu_end[s], (size_t)cfg->n_scans) != hipSuccess))
             rc = set_err(PTL_ERR_HIP, "batch allocation failed");
+        if (rc == PTL_OK && hipMemset(b->d_imu_end[s], 0, (size_t)cfg->n_scans * sizeof(int)) != hipSuccess) rc = set_err(PTL_ERR_HIP, "memset failed");
         b->imu_end[s].assign((size_t)cfg->n_scans, 0);
     }
-    if (rc == PTL_OK && dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess) rc = set_err(PTL_ERR_HIP, "batch allocation failed");
+    if (rc == PTL_OK && (dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess || dalloc(&b->d_bar, (size_t)GN_MAX_SEQ * 64) != hipSuccess))
+        rc = set_err(PTL_ERR_HIP, "batch allocation failed");
+    if (rc == PTL_OK && b->free_running) rc = batch_check_seq_run(b);
     if (rc) { ptl_batch_destroy(b); return rc; }
     *out = b;
     return PTL_OK;
@@ -1389,6 +1430,9 @@ extern "C" int ptl_batch_upload_imu(ptl_batch* b, int32_t s, const double* imu, 
         if (b->cfg.with_ekf && k && imu_end[k] == imu_end[k - 1]) return set_err(PTL_ERR_ARG, "batched runs need at least one IMU sample between consecutive scans (scan %lld)", (long long)k);
         b->imu_end[s][(size_t)k] = imu_end[k];
     }
+    std::vector<int> e32((size_t)b->cfg.n_scans);
+    for (int64_t k = 0; k < b->cfg.n_scans; ++k) e32[(size_t)k] = (int)imu_end[k];
+    HIPCHK(hipMemcpy(b->d_imu_end[s], e32.data(), e32.size() * sizeof(int), hipMemcpyHostToDevice));
     return PTL_OK;
 }
 static int batch_push_ctx(ptl_batch* b) {
@@ -1406,7 +1450,11 @@ static int batch_push_ctx(ptl_batch* b) {
         h[s].scan_base = b->d_scans[s];
         h[s].scan_stride_floats = (long long)b->cfg.points_per_scan * 3;
         h[s].input_is_range = b->is_range;
+        h[s].n_scans = (int)b->cfg.n_scans;
         h[s].fd_buf[0] = b->icp[s]->fd_buf[0]; h[s].fd_buf[1] = b->icp[s]->fd_buf[1];
+        h[s].ekf = b->ekf[s]->st; h[s].imu = b->d_imu[s]; h[s].imu_end = b->d_imu_end[s];
+        h[s].res_poses = b->d_res_poses[s]; h[s].res_t = b->d_res_t[s]; h[s].rows = b->d_rows[s];
+        h[s].bar = b->d_bar + (size_t)s * 64;
     }
     HIPCHK(hipMemcpyAsync(b->d_ctx, h, sizeof h, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1428,10 +1476,69 @@ static int batch_reset(ptl_batch* b) {
     b->ev_side_valid = false;
     return PTL_OK;
 }
+// free-running driver: the scans [next_scan, next_scan + n) of every sequence in launches of up to scans_per_launch scans
+static int batch_enqueue_free(ptl_batch* b, int64_t n) {
+    const bool with_ekf = b->cfg.with_ekf != 0;
+    const int S = b->S;
+    const ptl_icp_cfg& ic = b->cfg.icp;
+    hipStream_t st = b->stream;
+    const int64_t end = b->next_scan + n;
+    while (b->next_scan < end) {
+        const int64_t k0 = b->next_scan, k1 = (end - k0 > b->scans_per_launch) ? k0 + b->scans_per_launch : end;
+        if (with_ekf) {  // IMU samples before the first scan of the launch that the filter has not seen (a run's first scan)
+            EkfBatchArgs ea;
+            memset(&ea, 0, sizeof ea);
+            bool any = false;
+            for (int s = 0; s < S; ++s) {
+                ea.e[s] = b->ekf[s]->st; ea.imu[s] = b->d_imu[s];
+                ea.i0[s] = (int)b->imu_pos[s]; ea.i1[s] = (int)b->imu_end[s][(size_t)k0];
+                any = any || ea.i1[s] > ea.i0[s];
+                if (b->imu_end[s][(size_t)k0] > b->imu_pos[s]) b->imu_pos[s] = b->imu_end[s][(size_t)k0];
+            }
+            if (any) kb_ekf_step<<<S, 384, 0, st>>>(ea);
+        }
+        HIPCHK(hipMemsetAsync(b->d_bar, 0, (size_t)GN_MAX_SEQ * 64 * sizeof(unsigned), st));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (b->prof) {
+            if (b->ev_used + 2 > b->ev.size())
+                for (int q = 0; q < 2; ++q) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); b->ev.push_back(e); }
+            e0 = b->ev[b->ev_used++]; e1 = b->ev[b->ev_used++];
+            HIPCHK(hipEventRecord(e0, st));
+        }
+        SeqRun r;
+        r.S = S; r.k0 = (int)k0; r.k1 = (int)k1; r.with_ekf = with_ekf ? 1 : 0; r.rebuild_every = ic.rebuild_every;
+        const int gseq = batch_gseq(b);
+        const bool p20 = ic.max_points_per_voxel == 20;
+#define KXR(GC) do { if (p20) kx_seq_run<20, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r); \
+                     else kx_seq_run<0, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r); } while (0)
+        if (gseq == 32) KXR(32); else if (gseq == 16) KXR(16); else if (gseq == 8) KXR(8); else KXR(0);
+#undef KXR
+        if (b->prof) HIPCHK(hipEventRecord(e1, st));
+        for (int s = 0; s < S; ++s) {
+            if (with_ekf) b->imu_pos[s] = (k1 < b->cfg.n_scans) ? b->imu_end[s][(size_t)k1] : b->imu_end[s][(size_t)k1 - 1];
+            b->icp[s]->scans_done += (k1 - k0);
+            b->icp[s]->last_n = b->cfg.points_per_scan;
+        }
+        b->n_out += k1 - k0;
+        b->next_scan = k1;
+    }
+    HIPCHK(hipGetLastError());
+    return PTL_OK;
+}
+extern "C" int ptl_batch_set_driver(ptl_batch* b, int32_t free_running, int64_t scans_per_launch) {
+    if (!b || scans_per_launch < 0) return set_err(PTL_ERR_ARG, "bad argument");
+    if (b->next_scan != 0) return set_err(PTL_ERR_STATE, "choose the driver before the first scan of a run");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    if (scans_per_launch > 0) b->scans_per_launch = scans_per_launch;
+    if (free_running) { int rc = batch_check_seq_run(b); if (rc) return rc; }
+    b->free_running = free_running != 0;
+    return PTL_OK;
+}
 extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
     if (!b || n < 0 || b->next_scan + n > b->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
     if (b->ctx_dirty) { int rc = batch_push_ctx(b); if (rc) return rc; }
+    if (b->free_running) return batch_enqueue_free(b, n);
     const bool with_ekf = b->cfg.with_ekf != 0;
     const int S = b->S;
     const int64_t pps = b->cfg.points_per_scan;
@@ -1580,6 +1687,15 @@ extern "C" int ptl_batch_copy_traj(ptl_batch* b, int32_t s, void* dst_device, in
 extern "C" int ptl_batch_icp(ptl_batch* b, int32_t s, ptl_icp** icp) {
     if (!b || !icp || s < 0 || s >= b->S) return set_err(PTL_ERR_ARG, "bad argument");
     *icp = b->icp[s];
+    return PTL_OK;
+}
+extern "C" int ptl_batch_seq_clocks(ptl_batch* b, int32_t s, int64_t out[8]) {
+    if (!b || !out || s < 0 || s >= b->S) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    long long h[8];
+    HIPCHK(hipMemcpy(h, (char*)b->icp[s]->c.st + offsetof(DevState, seq_clk), sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out[i] = h[i];
     return PTL_OK;
 }
 extern "C" int ptl_batch_gn_phases(ptl_batch* b, int64_t out[8]) {

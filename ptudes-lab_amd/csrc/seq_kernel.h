@@ -1,0 +1,158 @@
+// seq_kernel.h -- the free-running sequence kernel: ONE persistent launch carries a run of scans of every sequence of a
+// batch, and every sequence advances at its own pace.
+//
+// The lockstep driver (ptl_batch_enqueue, one launch per stage for all sequences) makes every step wait for the
+// sequence whose Gauss-Newton loop takes longest: over 16 sequences the slowest loop of a step runs 1.8 x the mean
+// number of iterations (tools/lockstep.py), and the workgroups of the other sequences idle meanwhile.  Here the
+// workgroups of one sequence (its share of one XCD, kx_assign) form a TEAM that walks the whole per-scan pipeline by
+// itself - reference cli/ekf_bench.py:493-563 loop body = kiss.py:83-131 + ESEKF.processPose / processImu:
+//
+//     team \ {filter wg}:  K0 prologue | K1 deskew + vds1 | K2 vds2 | K3 compact fd | K4 compact src
+//     whole team:          --- barrier ---  K5 Gauss-Newton loop (gn8_body)  --- barrier ---
+//     filter wg:           ES-EKF: update with the scan's pose, predict through the IMU samples before the next scan
+//     team \ {filter wg}:  K7-K9 map insert a | b | c | K10 prune [| table reset | K11 rebuild]
+//
+// with team barriers where the lockstep driver has kernel boundaries.  Nothing is shared between teams, so a
+// sequence whose loop converges early simply starts its next scan.  Stage bodies, reduction trees and the exchange are
+// the ones of the per-stage kernels: results are bit-identical to the lockstep run and to the single-sequence run with
+// as many Gauss-Newton workgroups.
+#pragma once
+#include "ekf_kernels.h"
+#include "icp_kernels.h"
+
+// Barrier of the `n` workgroups of a team on a counter in device memory (zeroed by the host before the launch): the
+// k-th barrier is passed when the counter reaches k n (`target`, kept by the caller; only thread 0's copy counts).
+// Agent-scope release before the arrival and acquire after the last one: the stages exchange their data through plain
+// global memory.  A wait that exceeds TEAM_BAR_TICKS, or sees the sequence's abort word, raises ERR_GN_TIMEOUT and
+// returns false: the caller leaves the kernel (and so does, at its next barrier, every other workgroup of the team).
+#define TEAM_BAR_TICKS 300000000ll /* of the 100 MHz wall clock: 3 s */
+__device__ __forceinline__ bool team_sync(unsigned* word, unsigned n, unsigned& target, DevState* st) {
+    __shared__ int s_bad;
+    __syncthreads();
+    target += n;
+    if (threadIdx.x == 0) {
+        int bad = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = (long long)wall_clock64();
+        unsigned polls = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++polls & 255u) == 0u && (gn_abort_seen(&st->gn_abort) || (long long)wall_clock64() - t0 > TEAM_BAR_TICKS)) { bad = 1; break; }
+        }
+        if (bad) gn_raise_abort(st);
+        s_bad = bad;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return s_bad == 0;
+}
+
+// The stages are separate (not inlined) functions: the Gauss-Newton loop and the filter step each need the whole register
+// file of a wavefront, and inlined into one body they spill into each other's loops.  Each loads the scan's context from
+// the sequence table itself (scalar loads), like the per-stage kernels.
+#define SEQ_FAIL 0xFFFFFFFFu
+// K0-K4 of scan k by the team's `nw` working workgroups (this one is number `wg`); returns the barrier target, SEQ_FAIL on abort
+__device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target) {
+    const Ctx c = load_seq_ctx(a, s, k);
+    DevState* st = c.st;
+    unsigned* word = a[s].bar + 32;
+    const int BS = (int)blockDim.x, nbs = (c.n_in + BS - 1) / BS;
+    Slice sl;
+    sl.nb = nbs;
+    if (wg == 0) d_scan_prologue(c);
+    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_deskew_vds1(c, sl);
+    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_vds2(c, sl);
+    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_fd(c, sl);
+    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_src(c, sl);
+    return target;
+}
+// K7-K11 of scan k
+__device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, int rebuild) {
+    const Ctx c = load_seq_ctx(a, s, k);
+    DevState* st = c.st;
+    unsigned* word = a[s].bar + 32;
+    const int BS = (int)blockDim.x, nbd = (st->n_down_ins + BS - 1) / BS;
+    Slice sl;
+    sl.nb = nbd;
+    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_a(c, c.fd, &st->n_down_ins, 0, 1, sl);
+    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_b(c, &st->n_down_ins, 0, sl);
+    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_c(c, &st->n_down_ins, 0, sl);
+    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    const int nbp = (st->pool_hw + BS - 1) / BS;
+    sl.nb = nbp;
+    for (sl.b = wg; sl.b < nbp; sl.b += nw) d_map_prune(c, nullptr, 1, sl);
+    if (rebuild) {  // drop the tombstones: empty table, re-enter the live voxels
+        if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+        unsigned long long* tw = (unsigned long long*)c.tab;
+        const size_t nwords = ((size_t)c.tmask + 1) * (sizeof(TabEnt) / 8);
+        for (size_t i = (size_t)wg * BS + threadIdx.x; i < nwords; i += (size_t)nw * BS) tw[i] = ~0ull;
+        if (wg == 0 && threadIdx.x == 0) st->tab_used = 0u;
+        if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+        for (sl.b = wg; sl.b < nbp; sl.b += nw) d_map_rebuild(c, sl);
+    }
+    return target;
+}
+template <int PC, int GC>
+__device__ __noinline__ void sq_gauss_newton(const SeqCtx* a, int s, int k, int G, int wg) {
+    const Ctx c = load_seq_ctx(a, s, k);
+    gn8_body<PC, GC>(c, 0, G, wg);
+}
+// the filter step that follows scan k: update with its pose, predict through the IMU samples before scan k + 1
+__device__ __noinline__ void sq_filter(const SeqCtx* my, int k) {
+    const int i0 = my->imu_end[k], i1 = (k + 1 < my->n_scans) ? my->imu_end[k + 1] : i0;
+    d_ekf_step(my->ekf, my->imu, i0, i1, my->c.traj + 16 * (size_t)k, nullptr, my->res_poses + 16 * (size_t)k,
+               my->res_t + k, my->rows + 8 * (size_t)k, 1);
+}
+
+struct SeqRun { int S, k0, k1, with_ekf, rebuild_every; };
+
+template <int PC, int GC>
+__global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, SeqRun r) {
+    int s, G, wg;
+    if (!kx_assign(r.S, s, G, wg)) return;
+    const SeqCtx* my = a + s;
+    DevState* st = my->c.st;
+    // with a filter, the team's last workgroup is the filter workgroup: it only joins the two barriers around the
+    // Gauss-Newton loop, steps the filter after it and is back, waiting, long before the others have updated the map
+    // and prepared the next scan
+    const bool fwg = r.with_ekf && wg == G - 1;
+    const int nw = r.with_ekf ? G - 1 : G;
+    unsigned t_all = 0u, t_work = 0u;
+    const bool clk0 = wg == 0 && threadIdx.x == 0, clkf = fwg && threadIdx.x == 0;  // who keeps the phase clocks (st->seq_clk)
+    long long ph[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = r.k0; k < r.k1; ++k) {
+        const long long c0 = (long long)wall_clock64();
+        if (!fwg) {
+            t_work = sq_prepare(a, s, k, wg, nw, t_work);
+            if (t_work == SEQ_FAIL) return;
+        }
+        const long long c1 = (long long)wall_clock64();
+        if (!team_sync(my->bar, (unsigned)G, t_all, st)) return;  // source ready; the previous scan's map update and filter step complete
+        const long long c2 = (long long)wall_clock64();
+        sq_gauss_newton<PC, GC>(a, s, k, G, wg);
+        if (gn_abort_seen(&st->gn_abort)) return;
+        const long long c3 = (long long)wall_clock64();
+        if (!team_sync(my->bar, (unsigned)G, t_all, st)) return;  // new pose, trajectory row
+        const long long c4 = (long long)wall_clock64();
+        if (fwg) {
+            sq_filter(my, k);
+        } else {
+            t_work = sq_map_update(a, s, k, wg, nw, t_work, (r.rebuild_every > 0 && ((k + 1) % r.rebuild_every) == 0) ? 1 : 0);
+            if (t_work == SEQ_FAIL) return;
+        }
+        const long long c5 = (long long)wall_clock64();
+        ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
+    }
+    if (clk0) {
+        for (int i = 0; i < 5; ++i) st->seq_clk[i] += ph[i];
+        st->seq_clk[6] += r.k1 - r.k0;
+    }
+    if (clkf) st->seq_clk[5] += ph[4];
+}

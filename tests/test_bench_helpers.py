@@ -22,7 +22,7 @@ def _bench():
 
 def _args(**over):
     a = dict(rows=128, cols=1024, min_range=1.0, max_range=70.0, voxel_size=0.0, seed_base=1000, warmup=20, steps=200,
-             const_velocity=False, icp_only=False, gn_lanes=0)
+             const_velocity=False, icp_only=False, gn_lanes=0, lockstep=False)
     a.update(over)
     return types.SimpleNamespace(**a)
 
@@ -32,6 +32,9 @@ def test_roofline_traffic_only_from_a_pmc_pass_of_the_same_workload(tmp_path, mo
     k16, k8 = b.workload_key(_args(), 16), b.workload_key(_args(), 8)
     assert k16 != k8 and b.workload_key(_args(steps=60), 16) != k16 and b.workload_key(_args(voxel_size=0.1), 16) != k16
     assert b.workload_key(_args(gn_lanes=8), 1) != b.workload_key(_args(), 1)
+    # the driver is part of the workload: counters of the lockstep Gauss-Newton launches say nothing about the free-running kernel
+    assert k16.endswith("_free") and b.workload_key(_args(lockstep=True), 16) == k16[:-len("_free")]
+    assert not b.workload_key(_args(), 1).endswith("_free") and not b.workload_key(_args(gn_lanes=32), 16).endswith("_free")
     prof = tmp_path / "profiles"
     prof.mkdir()
     (prof / "r09_x_pmc_hbm_traffic_a.json").write_text(json.dumps({"workload_key": k8, "traffic_bytes_per_launch": 1.0e9}))

@@ -1,6 +1,6 @@
-"""Batched runner: S sequences on one GPU, one XCD each (kx_gn_loop: the workgroups with blockIdx & 7 == s run sequence s's
-Gauss-Newton loop with one-hop exchange inside the XCD) == S independent device-resident runs with gn_workgroups / 8
-workgroups each, bit for bit."""
+"""Batched runner: S sequences on one GPU, each on its share of one XCD (the workgroups with blockIdx & 7 == s & 7), in
+either driver - the free-running kernel (kx_seq_run: one persistent launch, every sequence at its own pace) or lockstep
+(one launch per stage) - == S independent device-resident runs with as many Gauss-Newton workgroups each, bit for bit."""
 import numpy as np
 import pytest
 
@@ -10,18 +10,25 @@ from ptudes_lab_amd import core, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("use_imu,S,lanes", [(True, 3, 8), (False, 3, 8), (True, 8, 8), (True, 3, 32), (True, 12, 8), (True, 20, 8)])
-def test_batch_equals_independent_runs(use_imu, S, lanes):
+@pytest.mark.parametrize("use_imu,S,lanes,driver", [(True, 3, 8, "free"), (False, 3, 8, "free"), (True, 8, 8, "free"), (True, 3, 32, "lockstep"),
+                                                    (True, 12, 8, "free"), (True, 20, 8, "free"), (True, 3, 8, "lockstep"),
+                                                    (True, 12, 8, "lockstep"), (True, 5, 8, "free3")])
+def test_batch_equals_independent_runs(use_imu, S, lanes, driver):
     n = 10 if S <= 8 else 6
     seqs = [synth.make_sequence(seed=1010 + s, n_scans=n) for s in range(S)]
     n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
-    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=use_imu, with_ekf=True, gn_lanes_per_point=lanes, gn_threads=512 if lanes == 8 else 1024)
+    # "free3": launches of 3 scans (several per run) and a hash-table rebuild every 4 scans inside the kernel
+    more = dict(scans_per_launch=3) if driver == "free3" else {}
+    rebuild = dict(rebuild_every=4) if driver == "free3" else {}
+    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=use_imu, with_ekf=True, gn_lanes_per_point=lanes,
+                         gn_threads=512 if lanes == 8 else 1024, free_running=driver != "lockstep", **more, **rebuild)
+    assert b.free_running == (driver != "lockstep")
     singles = []
     for s, sq in enumerate(seqs):
         # one sequence of the batch runs on 256 / 8 = 32 workgroups (16 / 8 when two / four sequences share an XCD): the
         # independent run it must equal uses as many
         r = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=use_imu, with_ekf=True, gn_workgroups=32 if S <= 8 else 16 if S <= 16 else 8,
-                           gn_lanes_per_point=lanes, gn_threads=512 if lanes == 8 else 1024)
+                           gn_lanes_per_point=lanes, gn_threads=512 if lanes == 8 else 1024, **rebuild)
         ends = [sq.imu_range_for_scan(k)[1] for k in range(n)]
         for k in range(n):
             x = sq.scan(k)
@@ -42,6 +49,61 @@ def test_batch_equals_independent_runs(use_imu, S, lanes):
         assert out["stats"] == singles[s]["stats"]
     # sequences differ from each other (the batch is not computing one thing S times)
     assert not np.array_equal(b.results(0)["kiss_poses"], b.results(1)["kiss_poses"])
+
+
+@pytest.mark.parametrize("free", [True, False])
+def test_batch_icp_only_equals_independent_runs(free):
+    """no filter (BASELINE config 2): every workgroup of a team works on the scan, constant-velocity guess"""
+    S, n = 3, 8
+    seqs = [synth.make_sequence(seed=1040 + s, n_scans=n) for s in range(S)]
+    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, 0, with_ekf=False, free_running=free)
+    for s, sq in enumerate(seqs):
+        r = core.SeqRunner(n, sq.H * sq.W, 0, with_ekf=False, gn_workgroups=32, gn_lanes_per_point=8, gn_threads=512)
+        for k in range(n):
+            b.upload_scan(s, k, sq.scan(k))
+            r.upload_scan(k, sq.scan(k))
+        b.upload_imu(s, np.zeros((0, 7)), [0] * n)
+        r.upload_imu(np.zeros((0, 7)), [0] * n)
+        r.run()
+        seqs[s] = r.results()
+    b.run()
+    for s in range(S):
+        out = b.results(s)
+        assert np.array_equal(out["kiss_poses"], seqs[s]["kiss_poses"]), s
+        assert out["stats"] == seqs[s]["stats"]
+
+
+def test_free_running_kernel_leaves_when_a_workgroup_never_arrives():
+    """a workgroup of one team that skips the Gauss-Newton loop (test hook): the team's polls run out, the abort word goes
+    up, every workgroup of that team leaves the persistent kernel and the host gets the time-out flag - no hang; the
+    other sequence of the batch finishes its scans"""
+    import ctypes as C
+    import time
+    from ptudes_lab_amd import _lib as L
+    S, n = 2, 4
+    seqs = [synth.make_sequence(seed=1050 + s, n_scans=n) for s in range(S)]
+    n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
+    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=True, with_ekf=True)
+    for s, sq in enumerate(seqs):
+        for k in range(n):
+            b.upload_scan(s, k, sq.scan(k))
+        b.upload_imu(s, sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
+    b.run(2)
+    h = C.c_void_p()
+    L.check(L.lib().ptl_batch_icp(b._h, 1, C.byref(h)))
+    L.check(L.lib().ptl_icp_debug_stall_workgroup(h, 3))
+    t0 = time.perf_counter()
+    b.enqueue(2)
+    with pytest.raises(RuntimeError, match="sequence 1.*0x10"):
+        b.wait()
+    assert time.perf_counter() - t0 < 120.0
+    assert all(st["iterations"] > 0 for st in b.results(0)["stats"][1:n])  # sequence 0 went through all four scans (the first one meets an empty map)
+
+
+def test_free_running_needs_the_8_lane_kernel():
+    with pytest.raises(ValueError):
+        core.BatchRunner(2, 3, 1024, 4, with_ekf=True, max_points_per_scan=1024, scan_cols=64, gn_lanes_per_point=32, gn_threads=1024,
+                         free_running=True)
 
 
 def test_batch_rejects_missing_imu():

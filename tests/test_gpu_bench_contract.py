@@ -71,8 +71,9 @@ def test_bench_launches_its_own_ranks_on_distinct_sequences(tmp_path):
 
 @pytest.mark.gpu
 def test_bench_default_is_the_batched_runner():
-    """no flags but short: 16 independent sequences on the GPU (seeds 1000..1015, two per XCD), the per-XCD Gauss-Newton
-    kernel dominant, `value` = 16 scans per step, sequence 0 checked against the oracle inside the run"""
+    """no flags but short: 16 independent sequences on the GPU (seeds 1000..1015, two per XCD) in the free-running kernel
+    (one persistent launch for the timed steps), `value` = 16 scans per step, sequence 0 checked against the oracle inside
+    the run"""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "8", "--cpu-budget", "3"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -81,11 +82,25 @@ def test_bench_default_is_the_batched_runner():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 16 and d["config"]["sequence_seeds"].startswith("1000..1015")
     assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert d["roofline"]["kernel"] == "kx_gn_loop8" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["launches"] == 16
+    assert d["roofline"]["kernel"] == "kx_seq_run" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["launches"] == 1
+    assert d["config"]["driver"].startswith("free-running") and d["config"]["workload_key"].endswith("_free")
+    ph = d["sequence_phases_us_per_scan"]
+    assert ph["slowest_sequence_total"] >= ph["mean_sequence_total"] > 0
     assert d["roofline"]["traffic"] is None  # no PMC pass was collected on THIS workload (16 + 8 sweeps)
     assert d["cpu_baseline"]["value"] > 0 and d["parity_vs_oracle"]["max_dpos_m"] < 1e-9
     one = d["single_sequence"]  # k sequences per GPU and one - sequence 0 alone through the latency pipeline
     assert one["value"] > 0 and one["kernel"] == "k_gn_loop" and one["max_dpos_vs_batched_m"] < 1e-9
+
+
+@pytest.mark.gpu
+def test_bench_lockstep_driver_line():
+    """--lockstep: the per-stage driver, the per-XCD Gauss-Newton launch dominant (one launch per step)"""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "6", "--seqs-per-gpu", "8",
+                          "--lockstep", "--no-cpu-baseline", "--no-single-sequence"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
+    assert d["roofline"]["kernel"] == "kx_gn_loop8" and d["roofline"]["launches"] == 12 and d["config"]["driver"].startswith("lockstep")
+    assert not d["config"]["workload_key"].endswith("_free") and d["sequence_phases_us_per_scan"] is None
 
 
 @pytest.mark.gpu

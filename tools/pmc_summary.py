@@ -6,7 +6,9 @@ BENCH_LINE.json is the line bench.py printed in the FETCH_SIZE pass: its config.
 reports `roofline.traffic` only from a summary whose key equals the run's own.
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  On gfx950 FETCH_SIZE tallies 128-B requests at 64 B for
 wide coalesced reads (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): the fetch side is doubled (an upper
-bound for this kernel's 8-byte gathers, an uncalibrated width) and WRITE_SIZE is taken as reported."""
+bound for this kernel's 8-byte gathers, an uncalibrated width) and WRITE_SIZE is taken as reported.
+The per-launch figure of the dominant kernel is the mean over its launches of the TIMED region - the last `steps`
+launches (the free-running kernel: the last `roofline.launches`, a launch carries many scans) - not the warm-up's."""
 import collections
 import csv
 import glob
@@ -19,26 +21,34 @@ try:
     out["workload_key"] = line["config"]["workload_key"]
     out["dominant_kernel"] = line["roofline"]["kernel"]
     out["bench_value_under_profiler"] = line["value"]
+    n_timed = line["roofline"]["launches"] if line["roofline"]["kernel"] == "kx_seq_run" else line["steps"]
 except Exception as e:  # noqa: BLE001
     out["workload_key"] = None
     out["error"] = f"no bench line: {e!r}"
+    n_timed = 0
+dom = out.get("dominant_kernel") or "k_gn_loop"
 for arg in sys.argv[3:]:
     name, d = arg.split("=")
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(lambda: [0, 0.0])
+    per_dispatch = collections.defaultdict(float)  # the dominant kernel: one value per dispatch (a counter row per XCD / dimension is summed)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != name:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][0] += 1
         acc[k][1] += float(r["Counter_Value"])
+        if k.startswith(dom):
+            per_dispatch[int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     out[name] = {k: {"launches": v[0], "mean_per_launch_KB": v[1] / v[0]} for k, v in acc.items()}
-dom = out.get("dominant_kernel") or "k_gn_loop"
-gn = [k for k in out.get("FETCH_SIZE", {}) if k.startswith(dom)]
-if gn:
-    fk = sum(out["FETCH_SIZE"][k]["mean_per_launch_KB"] * out["FETCH_SIZE"][k]["launches"] for k in gn) / sum(out["FETCH_SIZE"][k]["launches"] for k in gn) * 1024
-    wk_n = sum(out.get("WRITE_SIZE", {}).get(k, {}).get("launches", 0) for k in gn)
-    wk = (sum(out["WRITE_SIZE"][k]["mean_per_launch_KB"] * out["WRITE_SIZE"][k]["launches"] for k in gn if k in out.get("WRITE_SIZE", {})) / wk_n * 1024) if wk_n else 0.0
+    vals = [per_dispatch[d] for d in sorted(per_dispatch)]
+    if n_timed and len(vals) >= n_timed:
+        vals = vals[-n_timed:]
+    out[name + "_timed"] = {"launches": len(vals), "mean_per_launch_KB": (sum(vals) / len(vals)) if vals else None}
+ft, wt = out.get("FETCH_SIZE_timed", {}), out.get("WRITE_SIZE_timed", {})
+if ft.get("mean_per_launch_KB") is not None:
+    fk = ft["mean_per_launch_KB"] * 1024
+    wk = (wt.get("mean_per_launch_KB") or 0.0) * 1024
     out["hbm_bytes_per_launch"] = {"kernel": dom, "fetch_reported": fk, "fetch_x2_gfx950": 2 * fk, "write_reported": wk,
                                    "total_corrected": 2 * fk + wk}
     out["traffic_bytes_per_launch"] = 2 * fk + wk  # what bench.py reports as roofline.traffic for this workload
