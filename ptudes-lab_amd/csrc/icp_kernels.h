@@ -123,7 +123,7 @@ struct Ctx {
     const double* ext_guess;  // device 4x4 or null
     unsigned long long* pc_key;  // [n_max]      multi-pass probe cache: voxel key of source point i at its last probe
     int* pc_pb;                  // [n_max][32]  and the 27 probe results (block id | count << 24, -1 = absent)
-    double* pc_ans;              // [n_max][8]   8-lane kernel: exact answer cache (s0 | t | slack^2 | candidate count)
+    double* pc_ans;              // [n_max][12]  8-lane kernel: exact answer cache (s0 | winner | distance bound of the others | candidate count | runner-up | order ids)
     unsigned long long* gn_rows_ll;  // [2][G][64]      per-workgroup sums as (32 data bits | 32 flag bits) words
     unsigned long long* gn_xsum_ll;  // [2][8][8][64]   per-group sums, one copy per consumer slot
     int overlap_pre;          // the next scan's K0-K4 run beside this scan's map update (own stream): see flush_map_stats
@@ -1275,6 +1275,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
 //   * wavefront reduction by DPP, workgroup reduction through LDS in wavefront order, one 18-entry row per workgroup;
 //     exchange in one hop (<= 64 workgroups: the first wavefront polls every row itself and solves straight away) or in
 //     two hops through 8 group leaders (one sequence over the whole chip).
+#define GN8_ANS_ROW 12        /* doubles per answer row: s0 (3) | winner (3) | bound | candidate count | runner-up (3) | the two order ids */
 #ifndef GN8_SPEC
 #define GN8_SPEC 1            /* first search round takes the two nearest other boxes along (speculatively): 7.14 k against 7.07 k scans/s for 16 sequences */
 #endif
@@ -1309,10 +1310,11 @@ template <int RE> __device__ __forceinline__ int sel_entry(const int (&r)[RE], i
     return v;
 }
 // NV stored voxels against the point with LP lanes: lane l <-> stored points l, l + LP, ... - every load of the call in
-// flight before the first distance is formed.  sd = smallest distance this lane has seen lose.
+// flight before the first distance is formed.  (bd, border, bp) / (b2d, b2o, b2p): the best and the second-best candidate
+// this lane has seen; sd = the smallest distance it has seen lose to both.
 template <int PC, int LP, int NV, class CT>
 __device__ __forceinline__ void scan_voxelsL(const CT& c, const int (&pb)[NV], const int (&vx)[NV], V3 s, int laneL, double& bd, double& sd,
-                                             unsigned& border, V3& bp) {
+                                             unsigned& border, V3& bp, double& b2d, unsigned& b2o, V3& b2p) {
     const int P = (PC > 0) ? PC : c.P;
     constexpr int NCH = (PC > 0) ? (PC + LP - 1) / LP : 24 / LP;  // chunks of LP stored points (P <= 24 when not compile-time)
     if (P <= 24) {
@@ -1339,8 +1341,12 @@ __device__ __forceinline__ void scan_voxelsL(const CT& c, const int (&pb)[NV], c
                     const double dx = q[v][k][0] - s.x, dy = q[v][k][1] - s.y, dz = q[v][k][2] - s.z;
                     const double d2 = dx * dx + dy * dy + dz * dz;
                     const unsigned id = (unsigned)(vx[v] * 32 + LP * k + laneL);
-                    if (d2 < bd || (d2 == bd && id < border)) { sd = fmin(sd, bd); bd = d2; border = id; bp = v3(q[v][k][0], q[v][k][1], q[v][k][2]); }
-                    else sd = fmin(sd, d2);
+                    if (d2 < bd || (d2 == bd && id < border)) {
+                        sd = fmin(sd, b2d); b2d = bd; b2o = border; b2p = bp;
+                        bd = d2; border = id; bp = v3(q[v][k][0], q[v][k][1], q[v][k][2]);
+                    } else if (d2 < b2d || (d2 == b2d && id < b2o)) {
+                        sd = fmin(sd, b2d); b2d = d2; b2o = id; b2p = v3(q[v][k][0], q[v][k][1], q[v][k][2]);
+                    } else sd = fmin(sd, d2);
                 }
     } else {
 #pragma unroll
@@ -1354,8 +1360,12 @@ __device__ __forceinline__ void scan_voxelsL(const CT& c, const int (&pb)[NV], c
                     const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
                     const double d2 = dx * dx + dy * dy + dz * dz;
                     const unsigned id = (unsigned)(vx[v] * 32 + idx);
-                    if (d2 < bd || (d2 == bd && id < border)) { sd = fmin(sd, bd); bd = d2; border = id; bp = v3(qx, qy, qz); }
-                    else sd = fmin(sd, d2);
+                    if (d2 < bd || (d2 == bd && id < border)) {
+                        sd = fmin(sd, b2d); b2d = bd; b2o = border; b2p = bp;
+                        bd = d2; border = id; bp = v3(qx, qy, qz);
+                    } else if (d2 < b2d || (d2 == b2d && id < b2o)) {
+                        sd = fmin(sd, b2d); b2d = d2; b2o = id; b2p = v3(qx, qy, qz);
+                    } else sd = fmin(sd, d2);
                 }
             }
         }
@@ -1397,9 +1407,9 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
     const int lv = (lv_raw != 13) ? lv_raw : -1;
     const int pbc = __shfl(r[13 % RE], gb + 13 / RE);  // the point's own voxel
     const int pbl = (lv >= 0) ? __shfl(sel_entry<RE>(r, lv % RE), gb + lv / RE) : -1;
-    double bd = 1.7976931348623157e308, sd = 1.7976931348623157e308;
-    unsigned border = 0xFFFFFFFFu;
-    V3 bp = v3(0, 0, 0);
+    double bd = 1.7976931348623157e308, sd = 1.7976931348623157e308, b2d = 1.7976931348623157e308;
+    unsigned border = 0xFFFFFFFFu, b2o = 0xFFFFFFFFu;
+    V3 bp = v3(0, 0, 0), b2p = v3(0, 0, 0);
     // squared distance from the point to the box of each of this lane's (stored) neighbour voxels: known before any load
     double gap2[RE];
     {
@@ -1445,10 +1455,10 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
             }
         }
         const int pb4[4] = {pbc, pbl, psel[0], psel[1]}, vx4[4] = {13, lv, vsel[0], vsel[1]};
-        scan_voxelsL<PC, LP, 4>(c, pb4, vx4, s, laneL, bd, sd, border, bp);
+        scan_voxelsL<PC, LP, 4>(c, pb4, vx4, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
     } else {
         const int pb2[2] = {pbc, pbl}, vx2[2] = {13, lv};
-        scan_voxelsL<PC, LP, 2>(c, pb2, vx2, s, laneL, bd, sd, border, bp);
+        scan_voxelsL<PC, LP, 2>(c, pb2, vx2, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
     }
     // the other voxels: dropped when their box lies farther than the best distance so far (exact, see nn_scan32)
     unsigned mine = 0u;
@@ -1465,6 +1475,9 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
         unsigned cand = mine ? (unsigned)(RE * laneL + __ffs(mine) - 1) : 0xFFu;
         const unsigned v0 = group_minL<LP>(cand);
         if (v0 == 0xFFu) break;  // uniform over the group
+#ifdef GN_PHASE_CLOCKS
+        if (laneL == 0) atomicAdd((unsigned long long*)&c.wg_clk[41], 1ull);  // survivor rounds (wg_clk[40]: searches)
+#endif
         if ((int)(v0 / RE) == laneL) mine &= mine - 1u;
         cand = mine ? (unsigned)(RE * laneL + __ffs(mine) - 1) : 0xFFu;
         const unsigned v1 = group_minL<LP>(cand);
@@ -1472,8 +1485,11 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
         const int p0 = __shfl(sel_entry<RE>(r, (int)(v0 % RE)), gb + (int)(v0 / RE));
         const int p1 = (v1 != 0xFFu) ? __shfl(sel_entry<RE>(r, (int)(v1 % RE)), gb + (int)((v1 / RE) & (LP - 1))) : -1;
         const int pb2[2] = {p0, p1}, vx2[2] = {(int)v0, (int)v1};
-        scan_voxelsL<PC, LP, 2>(c, pb2, vx2, s, laneL, bd, sd, border, bp);
+        scan_voxelsL<PC, LP, 2>(c, pb2, vx2, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
     }
+#ifdef GN_PHASE_CLOCKS
+    if (laneL == 0) { atomicAdd((unsigned long long*)&c.wg_clk[40], 1ull); if (!same_voxel) atomicAdd((unsigned long long*)&c.wg_clk[42], 1ull); }
+#endif
     m = group_minL<LP>(bd);
     found = m < 1.7976931348623157e308;
     const unsigned bo = group_minL<LP>((bd == m) ? border : 0xFFFFFFFFu);
@@ -1481,22 +1497,35 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
     t = v3(group_bcastL<LP>(win ? bp.x : 0.0), group_bcastL<LP>(win ? bp.y : 0.0), group_bcastL<LP>(win ? bp.z : 0.0));
     const int lv_new = found ? (int)(bo >> 5) : -1;
     if (laneL == 27 / RE && lv_new != lv_raw) c.pc_pb[32 * (size_t)i + 27] = lv_new;
-    // the answer row: everybody else is at least sqrt(D2) away
-    const double D2 = group_minL<LP>(fmin(win ? sd : bd, gdrop));
+    // The answer row keeps the TWO nearest candidates (the runner-up bounded 93 % of the rows when only the winner was kept,
+    // and the dropped boxes usually allow much more): second = the best of what is left after the winner - the winning
+    // lane offers its second-best, the others their best.  Everybody else - the lanes' remaining candidates, what lost to
+    // both inside a lane, the boxes of the dropped voxels - is at least sqrt(D2) away from s.
+    const double od = win ? b2d : bd;
+    const unsigned oo = win ? b2o : border;
+    const double m2 = group_minL<LP>(od);
+    const unsigned o2 = group_minL<LP>((od == m2) ? oo : 0xFFFFFFFFu);
+    const bool has2 = m2 < 1.7976931348623157e308;
+    const bool win2 = has2 && od == m2 && oo == o2;
+    const double rest = (win || win2) ? ((win && win2) ? sd : b2d) : bd;
+    const double D2 = group_minL<LP>(fmin(rest, gdrop));
     double sl2 = -1.0;
-    if (found && D2 < 1.0e300) {
-        const double slack = 0.5 * (sqrt(D2) - sqrt(m)) * (1.0 - 1e-6);
-        if (slack > 1e-6) sl2 = slack * slack;
-    } else if (found) {
-        sl2 = 1.0e300;  // the only candidate in reach of this voxel
-    }
+    if (found && D2 < 1.0e300) sl2 = sqrt(D2) * (1.0 - 1e-6) - 1e-9;  // (a little less is stored: the margin of the test)
+    else if (found) sl2 = 1.0e300;  // nobody else in reach of this voxel
     const double row8[8] = {s.x, s.y, s.z, t.x, t.y, t.z, sl2, (double)ctot};
 #pragma unroll
     for (int k = 0; k < 8 / LP; ++k) {
         double av = row8[0];
 #pragma unroll
         for (int e = 1; e < 8; ++e) av = ((8 / LP) * laneL + k == e) ? row8[e] : av;
-        c.pc_ans[8 * (size_t)i + (8 / LP) * laneL + k] = av;
+        c.pc_ans[GN8_ANS_ROW * (size_t)i + (8 / LP) * laneL + k] = av;
+    }
+    // entries 8..11: the runner-up and the two order ids (bo | o2 << 32; o2 = ~0: there is no runner-up)
+    if (win2 || (!has2 && laneL == 0)) {
+        const V3 p2 = win ? b2p : bp;
+        double* rw = c.pc_ans + GN8_ANS_ROW * (size_t)i + 8;
+        rw[0] = p2.x; rw[1] = p2.y; rw[2] = p2.z;
+        rw[3] = __longlong_as_double((long long)((unsigned long long)bo | ((unsigned long long)(has2 ? o2 : 0xFFFFFFFFu) << 32)));
     }
 }
 
@@ -1607,12 +1636,17 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
         for (int qb = 0; qb < my_blocks; qb += NW) {
             // ---- phase A, ONE LANE PER POINT (one pass, one memory round trip): apply the increment, look at the point's
-            // answer row.  The last full search of the point (at s0, same voxel => same 27-voxel candidate set) found t at
-            // distance d0 and every other candidate - scanned, or inside a dropped voxel's box - at >= D.  After a move by
-            // delta = |s - s0| the triangle inequality leaves t the strict winner while d0 + delta < D - delta, and then a
-            // full search would return exactly t: the pair goes straight into this lane's sums.  Row: s0 (3) | t (3) |
-            // ((D - d0) / 2)^2 with a safety factor, < 0 = no answer | candidate count of the 27 voxels.  The distance, the
-            // gate and the weight come from the current s either way - same values as after a search.
+            // answer row.  The last full search of the point (at s0, same voxel => same 27-voxel candidate set) found t and
+            // every other candidate - scanned, or inside a dropped voxel's box - at >= D from s0.  After a move by
+            // delta = |s - s0| every other candidate is still >= D - delta away (triangle inequality), so t is the strict
+            // winner while |s - t| < D - delta, and then a full search would return exactly t: the pair goes straight into
+            // this lane's sums.  The test uses the CURRENT distance to t: Gauss-Newton moves a point towards its neighbour
+            // more often than away from it, and a move towards t costs no margin at all (with the distance at s0 instead,
+            // d0 + 2 delta < D, 88 % of the repeated searches returned the neighbour they already had).  The row keeps the
+            // two nearest candidates of the search, "t" is whichever of them is nearer NOW (the search's own comparison,
+            // order ids included) and D bounds everybody else.  Row: s0 (3) | winner (3) | D less a safety margin, < 0 =
+            // no answer | candidate count of the 27 voxels | runner-up (3) | order ids.  The distance, the gate and the
+            // weight come from the current s either way - same values as after a search.
             {
                 const int q = qb + (tid >> 6), i = ((q * G + wg) << 6) + (tid & 63);
                 int miss = -1;
@@ -1626,18 +1660,28 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     miss = i;
                     if (it > 0) {
                         const unsigned long long old_key = c.pc_key[i];
-                        const double2* row = (const double2*)(c.pc_ans + 8 * (size_t)i);
-                        const double2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];  // s0.xy | s0.z t.x | t.yz | slack^2, count
+                        const double2* row = (const double2*)(c.pc_ans + GN8_ANS_ROW * (size_t)i);
+                        const double2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];  // s0.xy | s0.z t.x | t.yz | bound, count
+                        const double2 r4 = row[4], r5 = row[5];                            // t2.xy | t2.z, order ids
                         const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
                         const double ex = s.x - r0.x, ey = s.y - r0.y, ez = s.z - r1.x;
                         const double delta2 = ex * ex + ey * ey + ez * ez;
-                        if (old_key == pack_key(kx, ky, kz) && delta2 < r3.x) {  // (slack^2 < 0: never)
-                            const V3 t = v3(r1.y, r2.x, r2.y);
+                        if (old_key == pack_key(kx, ky, kz)) {
+                            V3 t = v3(r1.y, r2.x, r2.y);
                             const double dx = t.x - s.x, dy = t.y - s.y, dz = t.z - s.z;
-                            const double m = dx * dx + dy * dy + dz * dz;  // the expression the search evaluates for this candidate
-                            M[17] += r3.y;
-                            if (m < gate2) gn8_accumulate(M, s, t, kern, k2);
-                            miss = -1;
+                            double m = dx * dx + dy * dy + dz * dz;  // the expression the search evaluates for this candidate
+                            {   // the runner-up of the last search may have become the nearer one: same comparison as the search's
+                                const unsigned long long ids = (unsigned long long)__double_as_longlong(r5.y);
+                                const unsigned o1 = (unsigned)ids, o2 = (unsigned)(ids >> 32);
+                                const double ux = r4.x - s.x, uy = r4.y - s.y, uz = r5.x - s.z;
+                                const double mu = ux * ux + uy * uy + uz * uz;
+                                if (o2 != 0xFFFFFFFFu && (mu < m || (mu == m && o2 < o1))) { m = mu; t = v3(r4.x, r4.y, r5.x); }
+                            }
+                            if (sqrt(m) + sqrt(delta2) < r3.x) {  // (bound < 0: no answer stored)
+                                M[17] += r3.y;
+                                if (m < gate2) gn8_accumulate(M, s, t, kern, k2);
+                                miss = -1;
+                            }
                         }
                     }
                 }
@@ -1676,7 +1720,24 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     double m;
                     bool found;
                     int ctot;
+#ifdef GN_PHASE_CLOCKS
+                    // why did the answer row not settle this point?  (wg 0, iterations > 0): voxel changed | same neighbour again | another one
+                    double old_t[3] = {0, 0, 0}, old_sl = -1.0;
+                    bool old_same_key = false;
+                    if (wg == 0 && it > 0 && laneL == 0) {
+                        const int kx0 = voxel_index(s.x, c.vs, inv_vs), ky0 = voxel_index(s.y, c.vs, inv_vs), kz0 = voxel_index(s.z, c.vs, inv_vs);
+                        old_same_key = c.pc_key[i] == pack_key(kx0, ky0, kz0);
+                        old_t[0] = c.pc_ans[GN8_ANS_ROW * (size_t)i + 3]; old_t[1] = c.pc_ans[GN8_ANS_ROW * (size_t)i + 4]; old_t[2] = c.pc_ans[GN8_ANS_ROW * (size_t)i + 5];
+                        old_sl = c.pc_ans[GN8_ANS_ROW * (size_t)i + 6];
+                    }
+#endif
                     gn8_search<PC, LPB>(c, i, it, s, inv_vs, laneL, gb, t, m, found, ctot);
+#ifdef GN_PHASE_CLOCKS
+                    if (wg == 0 && it > 0 && laneL == 0) {
+                        const int cat = !old_same_key ? 5 : (old_sl < 0.0) ? 6 : (found && t.x == old_t[0] && t.y == old_t[1] && t.z == old_t[2]) ? 7 : 4;
+                        atomicAdd(&st->dbg_sums[cat], 1.0);  // 5 voxel changed | 6 no answer stored | 7 same neighbour | 4 another neighbour
+                    }
+#endif
                     if (laneL == 0) {
                         M[17] += (double)ctot;
                         if (found && m < gate2) gn8_accumulate(M, s, t, kern, k2);
@@ -1882,7 +1943,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         st->gn_phase_clk[5] += iters;
         st->gn_phase_clk[6] += ph_miss; st->gn_phase_clk[7] += ph_a;
 #ifdef GN_PHASE_CLOCKS
-        for (int k = 0; k < 5; ++k) st->dbg_sums[k] += (double)pb_t[k];
+        for (int k = 0; k < 4; ++k) st->dbg_sums[k] += (double)pb_t[k];
 #endif
         gn_post(c, st, false, mode == 0);
     }

@@ -245,7 +245,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= dalloc(&c.tab, (size_t)cfg->map_table_capacity) == hipSuccess;
     ok &= hipMalloc((void**)&c.blocks, (size_t)c.pool_cap * c.bstride) == hipSuccess;
     ok &= dalloc(&c.free_stack, c.pool_cap) == hipSuccess;
-    ok &= dalloc(&c.pc_key, n) == hipSuccess && dalloc(&c.pc_pb, 32 * n) == hipSuccess && dalloc(&c.pc_ans, 8 * n) == hipSuccess;
+    ok &= dalloc(&c.pc_key, n) == hipSuccess && dalloc(&c.pc_pb, 32 * n) == hipSuccess && dalloc(&c.pc_ans, GN8_ANS_ROW * n) == hipSuccess;
     ok &= hipHostMalloc((void**)&h->n_src_hint, sizeof(int)) == hipSuccess;
     if (h->n_src_hint) *h->n_src_hint = 0;
     ok &= dalloc(&c.gn_rows_ll, (size_t)2 * c.G * 64) == hipSuccess && hipMemset(c.gn_rows_ll, 0, (size_t)2 * c.G * 64 * 8) == hipSuccess;

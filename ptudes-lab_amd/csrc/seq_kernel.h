@@ -52,6 +52,15 @@ __device__ __forceinline__ bool team_sync(unsigned* word, unsigned n, unsigned& 
 // file of a wavefront, and inlined into one body they spill into each other's loops.  Each loads the scan's context from
 // the sequence table itself (scalar loads), like the per-stage kernels.
 #define SEQ_FAIL 0xFFFFFFFFu
+// make STAGES=1: workgroup 0 of every sequence adds the wall-clock ticks of every stage and of every barrier wait to
+// st->dbg_sums[0..19] (tools/free_vs_lockstep.py prints them)
+#ifdef SEQ_STAGE_CLOCKS
+#define SQ_CLK_DECL long long sq_t = (long long)wall_clock64(); const bool sq_me = wg == 0 && threadIdx.x == 0
+#define SQ_CLK(i) do { const long long n_ = (long long)wall_clock64(); if (sq_me) st->dbg_sums[i] += (double)(n_ - sq_t); sq_t = n_; } while (0)
+#else
+#define SQ_CLK_DECL do { } while (0)
+#define SQ_CLK(i) do { } while (0)
+#endif
 // K0-K4 of scan k by the team's `nw` working workgroups (this one is number `wg`); returns the barrier target, SEQ_FAIL on abort
 __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target) {
     const Ctx c = load_seq_ctx(a, s, k);
@@ -60,15 +69,25 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     const int BS = (int)blockDim.x, nbs = (c.n_in + BS - 1) / BS;
     Slice sl;
     sl.nb = nbs;
+    SQ_CLK_DECL;
     if (wg == 0) d_scan_prologue(c);
+    SQ_CLK(0);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    SQ_CLK(1);
     for (sl.b = wg; sl.b < nbs; sl.b += nw) d_deskew_vds1(c, sl);
+    SQ_CLK(2);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    SQ_CLK(3);
     for (sl.b = wg; sl.b < nbs; sl.b += nw) d_vds2(c, sl);
+    SQ_CLK(4);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    SQ_CLK(5);
     for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_fd(c, sl);
+    SQ_CLK(6);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    SQ_CLK(7);
     for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_src(c, sl);
+    SQ_CLK(8);
     return target;
 }
 // K7-K11 of scan k
@@ -79,15 +98,23 @@ __device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, in
     const int BS = (int)blockDim.x, nbd = (st->n_down_ins + BS - 1) / BS;
     Slice sl;
     sl.nb = nbd;
+    SQ_CLK_DECL;
     for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_a(c, c.fd, &st->n_down_ins, 0, 1, sl);
+    SQ_CLK(10);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    SQ_CLK(11);
     for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_b(c, &st->n_down_ins, 0, sl);
+    SQ_CLK(12);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    SQ_CLK(13);
     for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_c(c, &st->n_down_ins, 0, sl);
+    SQ_CLK(14);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    SQ_CLK(15);
     const int nbp = (st->pool_hw + BS - 1) / BS;
     sl.nb = nbp;
     for (sl.b = wg; sl.b < nbp; sl.b += nw) d_map_prune(c, nullptr, 1, sl);
+    SQ_CLK(16);
     if (rebuild) {  // drop the tombstones: empty table, re-enter the live voxels
         if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
         unsigned long long* tw = (unsigned long long*)c.tab;

@@ -36,6 +36,14 @@ for free in (True, False):
         print("  per scan, us (mean over sequences | min | max):  K0-K4 %s  wait %s  GN %s  wait %s  map %s  filter %s" % tuple(
             "%.0f|%.0f|%.0f" % (clk[:, i].mean(), clk[:, i].min(), clk[:, i].max()) for i in range(6)))
         print("  per-sequence total us/scan:", np.round(clk[:, :5].sum(1)).astype(int).tolist())
+        import ctypes as C
+        from ptudes_lab_amd import _lib as L
+        icp = C.c_void_p(); L.check(L.lib().ptl_batch_icp(b._h, 0, C.byref(icp)))
+        ds = (C.c_double * 32)(); L.check(L.lib().ptl_icp_debug_sums(icp, ds))
+        d = np.array(list(ds)) / n / 100.0
+        if d[:20].sum() > 0:  # built with make STAGES=1
+            names = ["prologue", "w", "deskew+vds1", "w", "vds2", "w", "compact_fd", "w", "compact_src", "-", "insert_a", "w", "insert_b", "w", "insert_c", "w", "prune"]
+            print("  stages of sequence 0, us/scan:", "  ".join("%s %.0f" % (nm, v) for nm, v in zip(names, d[:17])))
     b.close()
 worst = 0.0
 for s in range(S):

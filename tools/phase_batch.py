@@ -24,6 +24,8 @@ try:
     w = np.array(list(wc), dtype=float)
     print("point loop per workgroup, ticks/iter:", np.round(w[:G] / it).astype(int).tolist())
     print("misses per workgroup per iter:", np.round(w[G:2 * G] / it, 1).tolist())
+    if w[40] > 0:
+        print("searches (all workgroups of sequence 0): %.0f per scan, survivor rounds per search %.2f, row rebuilt (voxel changed / first iteration) %.1f %%" % (w[40] / n, w[41] / w[40], 100 * w[42] / w[40]))
 except Exception as e:
     print("no per-wg clocks:", e)
 
@@ -38,6 +40,8 @@ try:
     d = np.array(list(ds)); n = max(d[4], 1)
     nscan = max(sum(1 for st in b.results(0)["stats"] if st["iterations"] > 0), 1)
     print("misses of workgroup 0 by iteration index (mean per scan):", np.round(d[8:32] / nscan, 1).tolist())
-    print("phase B per pass (wg 0, group 0): load row/key %.0f | first round %.0f | survivors %.0f | tail %.0f  ticks; passes/iter %.2f" % (d[0]/n, d[1]/n, d[2]/n, d[3]/n, d[4]/it))
+    tot = max(d[4] + d[5] + d[6] + d[7], 1)
+    print("searches of workgroup 0 after iteration 0: %.0f per scan; voxel changed %.1f %%, no answer stored %.1f %%, SAME neighbour again %.1f %%, another neighbour %.1f %%"
+          % (tot / nscan, 100 * d[5] / tot, 100 * d[6] / tot, 100 * d[7] / tot, 100 * d[4] / tot))
 except Exception as e:
     print("no sub-steps:", e)
