@@ -106,7 +106,7 @@ struct Ctx {
     unsigned vmask;
     int *bcnt1, *bcnt2;
     double *fd, *src0, *src_cur, *fdw;
-    double* coltab;  // [W][12] per-column deskew transforms (R row-major 9, t 3)
+    double* coltab;  // [12][W] per-column deskew transforms (R row-major 9, t 3), entry-major
     int *pslot, *nxt, *prank, *plen;
     // map
     TabEnt* tab;
@@ -301,9 +301,9 @@ __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
             double x[6];
             for (int k = 0; k < 6; ++k) x[k] = sft * xi[k];
             const Rt M = se3_exp(x);
-            double* o = c.coltab + 12 * (size_t)j;
-            for (int k = 0; k < 9; ++k) o[k] = M.R[k];
-            for (int k = 0; k < 3; ++k) o[9 + k] = M.t[k];
+            double* o = c.coltab + (size_t)j;  // entry k of column j at [k W + j]: neighbouring lanes of K1 read neighbouring words
+            for (int k = 0; k < 9; ++k) o[(size_t)k * c.W] = M.R[k];
+            for (int k = 0; k < 3; ++k) o[(size_t)(9 + k) * c.W] = M.t[k];
         }
     }
 }
@@ -332,99 +332,206 @@ __global__ __launch_bounds__(256) void k_build_lut(int H, int W, const double* a
     }
 }
 
-// A stage body works on block `b` of `nb` blocks of blockDim.x consecutive points: a launch of its own passes
-// (blockIdx.x, gridDim.x); the free-running sequence kernel (kx_seq_run) walks the blocks of a scan with the workgroups
-// of one sequence.  Every thread of the workgroup calls the body (it contains workgroup barriers).
+// A stage body works on block `b` of `nb` blocks of U * blockDim.x consecutive points (thread t holds the points
+// base + u blockDim.x + t, u < U): a launch of its own passes (blockIdx.x, gridDim.x) and U = 1; the free-running sequence
+// kernel (kx_seq_run) walks the blocks of a scan with the workgroups of one sequence and U = 4 - a workgroup that owns a
+// CU alone hides memory latency only with independent accesses of its own, so the U points of a thread go through every
+// step together: U loads in flight, then U hash probes, then U atomics.  Every thread of the workgroup calls the body (it
+// contains workgroup barriers).
 struct Slice { int b, nb; };
 __device__ __forceinline__ Slice launch_slice() { Slice s; s.b = (int)blockIdx.x; s.nb = (int)gridDim.x; return s; }
 #define STAGE_MAX_WAVES 16  /* blockDim.x <= 1024 */
+#define STAGE_MAX_U 4
+
+// U find-or-claims in a per-scan VDS table with their probes in flight together: the hashed slot of each (one load; one
+// compare-and-swap where it was empty), and whatever that does not settle (a collision) goes through vds_claim
+template <int U>
+__device__ __forceinline__ void vds_claim_u(unsigned long long* keys, unsigned mask, const unsigned long long (&key)[U], const bool (&want)[U],
+                                            int (&slot)[U]) {
+    unsigned s0[U];
+    unsigned long long cur[U], old[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        s0[u] = (unsigned)mix64(key[u]) & mask;
+        cur[u] = want[u] ? keys[s0[u]] : key[u];
+        slot[u] = -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        old[u] = key[u];
+        if (want[u] && cur[u] == EMPTY_KEY) old[u] = atomicCAS(&keys[s0[u]], EMPTY_KEY, key[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!want[u]) continue;
+        if (cur[u] == key[u] || (cur[u] == EMPTY_KEY && (old[u] == EMPTY_KEY || old[u] == key[u]))) slot[u] = (int)s0[u];
+        else slot[u] = vds_claim(keys, mask, key[u]);
+    }
+}
+// the claimed slots' bids: slot value = the smallest point index that maps to the voxel
+template <int U>
+__device__ __forceinline__ void vds_bid_u(unsigned* vmin, const int (&slot)[U], const bool (&want)[U], const int (&idx)[U], int* err_flags) {
+    unsigned cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = (want[u] && slot[u] >= 0) ? vmin[slot[u]] : 0u;  // plain read: a stale (larger) value only costs a redundant atomicMin
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!want[u]) continue;
+        if (slot[u] < 0) atomicOr(err_flags, ERR_VDS_TABLE);
+        else if (cur[u] > (unsigned)idx[u]) atomicMin(&vmin[slot[u]], (unsigned)idx[u]);  // the slot's value only ever decreases: a smaller one seen = nothing to do
+    }
+}
+// number of set flags over the workgroup's U * blockDim.x points (every thread gets it)
+template <int U>
+__device__ __forceinline__ int block_count_u(const bool (&f)[U]) {
+    __shared__ int cnt[STAGE_MAX_WAVES];
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) mine += __popcll(__ballot(f[u]));
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    int tot = 0;
+    for (int k = 0; k < ((int)blockDim.x >> 6); ++k) tot += cnt[k];
+    __syncthreads();
+    return tot;
+}
 
 // ------------------------------------------------------------------------------------------------ K1
+#ifdef SEQ_STAGE_CLOCKS
+#define K1_CLK(i) do { __builtin_amdgcn_s_waitcnt(0); const long long n_ = (long long)wall_clock64(); if (k1_me) st->dbg_sums[i] += (double)(n_ - k1_t); k1_t = n_; } while (0)
+#else
+#define K1_CLK(i) do { } while (0)
+#endif
+template <int U>
 __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
-    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     DevState* st = c.st;
-    bool valid = false, keyed = false;
-    unsigned long long key = EMPTY_KEY;
-    if (i < st->prev_n_in) {  // release the previous scan's pass-2 slot this point won (K4 still read them)
-        const int s2 = c.slot2[i];
-        if (s2 >= 0 && c.vmin2[s2] == (unsigned)i) { c.vkey2[s2] = EMPTY_KEY; c.vmin2[s2] = 0xFFFFFFFFu; }
-    }
-    if (i >= c.n_in && i < st->prev_n_in) c.slot2[i] = -1;
-    if (i < c.n_in) {
-        V3 p;
-        if (c.in_range) {
-            unsigned rg = c.in_range[i];
-            if (c.row_mask && !c.row_mask[i / c.W]) rg = 0;
-            const double r = (double)rg;
-            const double* d = c.lut_dir + 3 * (size_t)i;
-            const double* o = c.lut_off + 3 * (size_t)i;
-            p = rg ? v3(r * d[0] + o[0], r * d[1] + o[1], r * d[2] + o[2]) : v3(0.0, 0.0, 0.0);
-        } else if (c.in_f32) {
-            p = v3((double)c.in_f32[3 * (size_t)i], (double)c.in_f32[3 * (size_t)i + 1], (double)c.in_f32[3 * (size_t)i + 2]);
-        } else {
-            p = v3(c.in_f64[3 * (size_t)i], c.in_f64[3 * (size_t)i + 1], c.in_f64[3 * (size_t)i + 2]);
+#ifdef SEQ_STAGE_CLOCKS
+    long long k1_t = (long long)wall_clock64();
+    const bool k1_me = U > 1 && sl.b % 15 == 0 && threadIdx.x == 0;  // (workgroup 0 of a team of 15 workers)
+#endif
+    const int prev_n_in = st->prev_n_in, do_deskew = st->do_deskew;
+    int idx[U];
+    bool valid[U], keyed[U];
+    unsigned long long key[U];
+    V3 p[U];
+    {   // release the previous scan's pass-2 slots: after K3 slot2[i] >= 0 marks exactly the winner of its slot (K4 still read them)
+        int s2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s2[u] = (idx[u] < prev_n_in) ? c.slot2[idx[u]] : -1; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s2[u] >= 0) { c.vkey2[s2[u]] = EMPTY_KEY; c.vmin2[s2[u]] = 0xFFFFFFFFu; }
+            if (idx[u] >= c.n_in && idx[u] < prev_n_in) c.slot2[idx[u]] = -1;
         }
-        if (st->do_deskew) {
-            if (c.t01) {
-                const double s = c.t01[i] - 0.5;
-                double x[6];
-                for (int k = 0; k < 6; ++k) x[k] = s * st->xi[k];
-                p = rt_apply(se3_exp(x), p);
+    }
+    K1_CLK(20);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = idx[u];
+        p[u] = v3(0.0, 0.0, 0.0);
+        if (i < c.n_in) {
+            if (c.in_range) {
+                unsigned rg = c.in_range[i];
+                if (c.row_mask && !c.row_mask[i / c.W]) rg = 0;
+                const double r = (double)rg;
+                const double* d = c.lut_dir + 3 * (size_t)i;
+                const double* o = c.lut_off + 3 * (size_t)i;
+                p[u] = rg ? v3(r * d[0] + o[0], r * d[1] + o[1], r * d[2] + o[2]) : v3(0.0, 0.0, 0.0);
+            } else if (c.in_f32) {
+                p[u] = v3((double)c.in_f32[3 * (size_t)i], (double)c.in_f32[3 * (size_t)i + 1], (double)c.in_f32[3 * (size_t)i + 2]);
             } else {
-                const double* m = c.coltab + 12 * (size_t)(i % c.W);
-                Rt M;
-                for (int k = 0; k < 9; ++k) M.R[k] = m[k];
-                for (int k = 0; k < 3; ++k) M.t[k] = m[9 + k];
-                p = rt_apply(M, p);
+                p[u] = v3(c.in_f64[3 * (size_t)i], c.in_f64[3 * (size_t)i + 1], c.in_f64[3 * (size_t)i + 2]);
             }
         }
-        const double r = sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
-        valid = (r < c.max_range) && (r > c.min_range);
-        if (valid) {
-            c.pts[3 * (size_t)i] = p.x; c.pts[3 * (size_t)i + 1] = p.y; c.pts[3 * (size_t)i + 2] = p.z;
-            int kx, ky, kz;
-            keyed = vox_key(p, c.vds1, key, kx, ky, kz);
-            if (!keyed) atomicOr(&st->err_flags, ERR_KEY_RANGE);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = idx[u];
+        valid[u] = false; keyed[u] = false; key[u] = EMPTY_KEY;
+        if (i < c.n_in) {
+            if (do_deskew) {
+                if (c.t01) {
+                    const double s = c.t01[i] - 0.5;
+                    double x[6];
+                    for (int k = 0; k < 6; ++k) x[k] = s * st->xi[k];
+                    p[u] = rt_apply(se3_exp(x), p[u]);
+                } else {
+                    const double* m = c.coltab + (size_t)(i % c.W);
+                    Rt M;
+                    for (int k = 0; k < 9; ++k) M.R[k] = m[(size_t)k * c.W];
+                    for (int k = 0; k < 3; ++k) M.t[k] = m[(size_t)(9 + k) * c.W];
+                    p[u] = rt_apply(M, p[u]);
+                }
+            }
+            const double r = sqrt(p[u].x * p[u].x + p[u].y * p[u].y + p[u].z * p[u].z);
+            valid[u] = (r < c.max_range) && (r > c.min_range);
+            if (valid[u]) {
+                c.pts[3 * (size_t)i] = p[u].x; c.pts[3 * (size_t)i + 1] = p[u].y; c.pts[3 * (size_t)i + 2] = p[u].z;
+                int kx, ky, kz;
+                keyed[u] = vox_key(p[u], c.vds1, key[u], kx, ky, kz);
+                if (!keyed[u]) atomicOr(&st->err_flags, ERR_KEY_RANGE);
+            }
         }
     }
     // Neighbours along a beam fall into the same voxel in long runs (hundreds of returns close to the sensor), and
     // same-address atomics serialise at the memory side.  Only the first lane of each run of equal keys within the
     // wavefront - the lowest index of the run, the only one that can win - claims the slot and bids for it; the others
     // take the slot from it.
+    K1_CLK(21);
     {
         const int lane = threadIdx.x & 63;
-        const unsigned long long prev = __shfl_up(key, 1);
-        const bool prev_keyed = __shfl_up(keyed ? 1 : 0, 1) != 0;
-        const bool head = keyed && (lane == 0 || !prev_keyed || prev != key);
-        int slot = -1;
-        if (head) {
-            slot = vds_claim(c.vkey1, c.vmask, key);
-            if (slot < 0) atomicOr(&st->err_flags, ERR_VDS_TABLE);
-            else if (c.vmin1[slot] > (unsigned)i)  // plain read: a stale (larger) value only costs a redundant atomicMin
-                atomicMin(&c.vmin1[slot], (unsigned)i);  // the slot's value only ever decreases: a smaller one seen = nothing to do
+        bool head[U];
+        int slot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long prev = __shfl_up(key[u], 1);
+            const bool prev_keyed = __shfl_up(keyed[u] ? 1 : 0, 1) != 0;
+            head[u] = keyed[u] && (lane == 0 || !prev_keyed || prev != key[u]);
         }
-        const unsigned long long heads = __ballot(head);
-        const unsigned long long below = heads & (~0ull >> (63 - lane));
-        const int my_head = below ? 63 - __clzll((long long)below) : lane;
-        const int hs = __shfl(slot, my_head);
-        if (i < c.n_in) c.slot1[i] = keyed ? hs : -1;
+        vds_claim_u<U>(c.vkey1, c.vmask, key, head, slot);
+        K1_CLK(22);
+        vds_bid_u<U>(c.vmin1, slot, head, idx, &st->err_flags);
+        K1_CLK(23);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long heads = __ballot(head[u]);
+            const unsigned long long below = heads & (~0ull >> (63 - lane));
+            const int my_head = below ? 63 - __clzll((long long)below) : lane;
+            const int hs = __shfl(slot[u], my_head);
+            if (idx[u] < c.n_in) c.slot1[idx[u]] = keyed[u] ? hs : -1;
+        }
     }
-    const int nv = __syncthreads_count(valid ? 1 : 0);
+    K1_CLK(24);
+    const int nv = block_count_u<U>(valid);
     if (threadIdx.x == 0 && nv) atomicAdd(&st->n_valid, nv);
+    K1_CLK(25);
 }
 
 // ------------------------------------------------------------------------------------------------ K2
+template <int U>
 __device__ __forceinline__ void d_vds2(const Ctx& c, const Slice sl) {
-    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
-    bool w1 = false;
-    unsigned long long key = EMPTY_KEY;
-    if (i < c.n_in) {
-        const int s1 = c.slot1[i];
-        w1 = (s1 >= 0) && (c.vmin1[s1] == (unsigned)i);
-        if (w1) {
-            V3 p = v3(c.pts[3 * (size_t)i], c.pts[3 * (size_t)i + 1], c.pts[3 * (size_t)i + 2]);
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
+    int idx[U], s1[U];
+    bool w1[U];
+    unsigned long long key[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s1[u] = (idx[u] < c.n_in) ? c.slot1[idx[u]] : -1; }
+    {
+        unsigned vm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vm[u] = (s1[u] >= 0) ? c.vmin1[s1[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) w1[u] = (s1[u] >= 0) && (vm[u] == (unsigned)idx[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        key[u] = EMPTY_KEY;
+        if (w1[u]) {
+            const size_t i = (size_t)idx[u];
+            V3 p = v3(c.pts[3 * i], c.pts[3 * i + 1], c.pts[3 * i + 2]);
             int kx, ky, kz;
-            vox_key(p, c.vds2, key, kx, ky, kz);
+            vox_key(p, c.vds2, key[u], kx, ky, kz);
         }
     }
     // As in pass 1, runs: consecutive pass-1 winners of a wavefront mostly share the coarser voxel.  Only the first winner
@@ -432,31 +539,35 @@ __device__ __forceinline__ void d_vds2(const Ctx& c, const Slice sl) {
     // others take the slot from it.
     {
         const int lane = threadIdx.x & 63;
-        const unsigned long long winners = __ballot(w1);
-        const unsigned long long before = winners & ((1ull << lane) - 1ull);          // winners in lower lanes
-        const int prev_lane = before ? 63 - __clzll((long long)before) : lane;
-        const unsigned long long prev_key = __shfl(key, prev_lane);
-        const bool head = w1 && (!before || prev_key != key);
-        int slot = -1;
-        if (head) {
-            slot = vds_claim(c.vkey2, c.vmask, key);
-            if (slot < 0) atomicOr(&c.st->err_flags, ERR_VDS_TABLE);
-            else if (c.vmin2[slot] > (unsigned)i)
-                atomicMin(&c.vmin2[slot], (unsigned)i);
+        bool head[U];
+        int slot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long winners = __ballot(w1[u]);
+            const unsigned long long before = winners & ((1ull << lane) - 1ull);          // winners in lower lanes
+            const int prev_lane = before ? 63 - __clzll((long long)before) : lane;
+            const unsigned long long prev_key = __shfl(key[u], prev_lane);
+            head[u] = w1[u] && (!before || prev_key != key[u]);
         }
-        const unsigned long long heads = __ballot(head);
-        const unsigned long long below = heads & (~0ull >> (63 - lane));               // heads at or below this lane
-        const int my_head = below ? 63 - __clzll((long long)below) : lane;
-        const int hs = __shfl(slot, my_head);
-        if (i < c.n_in) c.slot2[i] = w1 ? hs : -1;
+        vds_claim_u<U>(c.vkey2, c.vmask, key, head, slot);
+        vds_bid_u<U>(c.vmin2, slot, head, idx, &c.st->err_flags);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long heads = __ballot(head[u]);
+            const unsigned long long below = heads & (~0ull >> (63 - lane));               // heads at or below this lane
+            const int my_head = below ? 63 - __clzll((long long)below) : lane;
+            const int hs = __shfl(slot[u], my_head);
+            if (idx[u] < c.n_in) c.slot2[idx[u]] = w1[u] ? hs : -1;
+        }
     }
-    const int n1 = __syncthreads_count(w1 ? 1 : 0);
+    const int n1 = block_count_u<U>(w1);
     if (threadIdx.x == 0) c.bcnt1[sl.b] = n1;
 }
 
 // exclusive prefix of per-block counts + in-block rank (scan order preserved)
-// (integer sums: any grouping gives the same value; red holds 2 * STAGE_MAX_WAVES ints)
-__device__ __forceinline__ int block_offset(const int* bcnt, int b, int* red) {
+// (integer sums: any grouping gives the same value)
+__device__ __forceinline__ int block_offset(const int* bcnt, int b) {
+    __shared__ int red[STAGE_MAX_WAVES];
     const int nw = (int)blockDim.x >> 6;
     int s = 0;
     for (int k = threadIdx.x; k < b; k += (int)blockDim.x) s += bcnt[k];
@@ -468,44 +579,71 @@ __device__ __forceinline__ int block_offset(const int* bcnt, int b, int* red) {
     __syncthreads();
     return tot;
 }
-__device__ __forceinline__ int block_rank(bool flag, int* red, int& total) {
-    const unsigned long long m = __ballot(flag);
+// rank of each flagged point among the block's flagged points in point order (sub-block u before u + 1, threads in order)
+template <int U>
+__device__ __forceinline__ void block_rank_u(const bool (&f)[U], int (&rk)[U], int& total) {
+    __shared__ int red[STAGE_MAX_U][STAGE_MAX_WAVES];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
-    const int within = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) red[STAGE_MAX_WAVES + wv] = __popcll(m);
+    int within[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned long long m = __ballot(f[u]);
+        within[u] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) red[u][wv] = __popcll(m);
+    }
     __syncthreads();
-    int off = 0, tot = 0;
-    for (int k = 0; k < nw; ++k) { const int v = red[STAGE_MAX_WAVES + k]; if (k < wv) off += v; tot += v; }
-    total = tot;
+    int running = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int off = 0, tot = 0;
+        for (int k = 0; k < nw; ++k) { const int v = red[u][k]; if (k < wv) off += v; tot += v; }
+        rk[u] = running + off + within[u];
+        running += tot;
+    }
+    total = running;
     __syncthreads();
-    return off + within;
 }
 
 // ------------------------------------------------------------------------------------------------ K3
+template <int U>
 __device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl) {
-    __shared__ int red[2 * STAGE_MAX_WAVES];
-    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
-    bool w1 = false, w2 = false;
-    if (i < c.n_in) {
-        const int s1 = c.slot1[i];
-        w1 = (s1 >= 0) && (c.vmin1[s1] == (unsigned)i);
-        if (w1) {
-            const int s2 = c.slot2[i];
-            w2 = (s2 >= 0) && (c.vmin2[s2] == (unsigned)i);
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
+    int idx[U], s2[U], rk[U];
+    bool w1[U], w2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s2[u] = (idx[u] < c.n_in) ? c.slot2[idx[u]] : -1; }  // K2: slot2 >= 0 <=> pass-1 winner
+    {
+        unsigned vm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { w1[u] = s2[u] >= 0; vm[u] = w1[u] ? c.vmin2[s2[u]] : 0u; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) w2[u] = w1[u] && (vm[u] == (unsigned)idx[u]);
+    }
+    const int off = block_offset(c.bcnt1, sl.b);
+    int total;
+    block_rank_u<U>(w1, rk, total);
+    {
+        int s1[U];
+        double q[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = (size_t)idx[u];
+            s1[u] = w1[u] ? c.slot1[i] : -1;
+            if (w1[u]) { q[u][0] = c.pts[3 * i]; q[u][1] = c.pts[3 * i + 1]; q[u][2] = c.pts[3 * i + 2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!w1[u]) continue;
+            const size_t o = (size_t)(off + rk[u]) * 3;
+            c.fd[o] = q[u][0]; c.fd[o + 1] = q[u][1]; c.fd[o + 2] = q[u][2];
+            // release the pass-1 slot for the next scan (only its winner touches it)
+            c.vkey1[s1[u]] = EMPTY_KEY;
+            c.vmin1[s1[u]] = 0xFFFFFFFFu;
+            // from here on slot2 >= 0 marks the pass-2 winners only (K4, and the next scan's K1 which releases their slots)
+            if (!w2[u]) c.slot2[idx[u]] = -1;
         }
     }
-    const int off = block_offset(c.bcnt1, sl.b, red);
-    int total;
-    const int rk = block_rank(w1, red, total);
-    if (w1) {
-        const size_t o = (size_t)(off + rk) * 3;
-        c.fd[o] = c.pts[3 * (size_t)i]; c.fd[o + 1] = c.pts[3 * (size_t)i + 1]; c.fd[o + 2] = c.pts[3 * (size_t)i + 2];
-        // release the pass-1 slot for the next scan (only its winner touches it)
-        const int s1 = c.slot1[i];
-        c.vkey1[s1] = EMPTY_KEY;
-        c.vmin1[s1] = 0xFFFFFFFFu;
-    }
-    const int n2 = __syncthreads_count(w2 ? 1 : 0);
+    const int n2 = block_count_u<U>(w2);
     if (threadIdx.x == 0) {
         c.bcnt2[sl.b] = n2;
         if (sl.b == sl.nb - 1) c.st->n_down = off + total;
@@ -513,22 +651,21 @@ __device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl) {
 }
 
 // ------------------------------------------------------------------------------------------------ K4
+template <int U>
 __device__ __forceinline__ void d_compact_src(const Ctx& c, const Slice sl) {
-    __shared__ int red[2 * STAGE_MAX_WAVES];
-    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
-    bool w2 = false;
-    if (i < c.n_in) {
-        const int s1 = c.slot1[i];
-        // pass-1 slot was already released by its winner; winners are exactly the points with slot2 >= 0
-        const int s2 = (s1 >= 0) ? c.slot2[i] : -1;
-        w2 = (s2 >= 0) && (c.vmin2[s2] == (unsigned)i);
-    }
-    const int off = block_offset(c.bcnt2, sl.b, red);
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
+    int idx[U], rk[U];
+    bool w2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; w2[u] = (idx[u] < c.n_in) && c.slot2[idx[u]] >= 0; }  // K3: slot2 >= 0 <=> pass-2 winner
+    const int off = block_offset(c.bcnt2, sl.b);
     int total;
-    const int rk = block_rank(w2, red, total);
-    if (w2) {
-        const size_t o = (size_t)(off + rk) * 3;
-        c.src0[o] = c.pts[3 * (size_t)i]; c.src0[o + 1] = c.pts[3 * (size_t)i + 1]; c.src0[o + 2] = c.pts[3 * (size_t)i + 2];
+    block_rank_u<U>(w2, rk, total);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!w2[u]) continue;
+        const size_t i = (size_t)idx[u], o = (size_t)(off + rk[u]) * 3;
+        c.src0[o] = c.pts[3 * i]; c.src0[o + 1] = c.pts[3 * i + 1]; c.src0[o + 2] = c.pts[3 * i + 2];
     }
     if (threadIdx.x == 0 && sl.b == sl.nb - 1) c.st->n_src = off + total;
 }
@@ -1579,6 +1716,7 @@ template <int PC, int GC>
 __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt, const int wg) {
     const int G = GC > 0 ? GC : G_rt;
     __shared__ int missq[GN8_MAX_THREADS];            // points of this chunk whose answer row did not settle them, compacted
+    __shared__ double miss_s[3][GN8_MAX_THREADS];     // ... and where they are now (phase A has just computed it)
     __shared__ int wsum[GN8_MAX_THREADS / 64];
     __shared__ double part[GN8_ROW_ENTRIES][16];
     __shared__ double redL8[64][GN8_ROW_ENTRIES];     // everybody's rows (G != 32)
@@ -1635,6 +1773,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
 #pragma unroll
         for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
         for (int qb = 0; qb < my_blocks; qb += NW) {
+            V3 sA;  // this lane's point of phase A
             // ---- phase A, ONE LANE PER POINT (one pass, one memory round trip): apply the increment, look at the point's
             // answer row.  The last full search of the point (at s0, same voxel => same 27-voxel candidate set) found t and
             // every other candidate - scanned, or inside a dropped voxel's box - at >= D from s0.  After a move by
@@ -1650,6 +1789,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             {
                 const int q = qb + (tid >> 6), i = ((q * G + wg) << 6) + (tid & 63);
                 int miss = -1;
+                sA = v3(0.0, 0.0, 0.0);
                 if (q < my_blocks && i < n) {
                     Rt E;
                     for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
@@ -1657,6 +1797,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     const double* sp0 = (it == 0) ? c.src0 : c.src_cur;
                     const V3 s = rt_apply(E, v3(sp0[3 * (size_t)i], sp0[3 * (size_t)i + 1], sp0[3 * (size_t)i + 2]));
                     c.src_cur[3 * (size_t)i] = s.x; c.src_cur[3 * (size_t)i + 1] = s.y; c.src_cur[3 * (size_t)i + 2] = s.z;
+                    sA = s;
                     miss = i;
                     if (it > 0) {
                         const unsigned long long old_key = c.pc_key[i];
@@ -1704,7 +1845,11 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 ph_miss += total; ph_a += GN_CLK() - c0;
                 if (wg == 0 && tid == 0 && it < 24) st->dbg_sums[8 + it] += (double)total;  // misses by iteration index
 #endif
-                if (cnt) missq[woff + incl - 1] = mine1;  // (a slot at or below the own one: everybody has read its slot)
+                if (cnt) {  // (a slot at or below the own one: everybody has read its slot)
+                    const int pos = woff + incl - 1;
+                    missq[pos] = mine1;
+                    miss_s[0][pos] = sA.x; miss_s[1][pos] = sA.y; miss_s[2][pos] = sA.z;
+                }
                 __syncthreads();
             }
             // ---- phase B, GN8_LPB LANES PER POINT: the full search of the noted points (gn8_search)
@@ -1715,7 +1860,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                   if (k < nmiss) {
                     const long long b0 = GN_CLK();
                     const int i = missq[k];
-                    const V3 s = v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]);
+                    const V3 s = v3(miss_s[0][k], miss_s[1][k], miss_s[2][k]);  // (= src_cur[i], without the round trip)
                     V3 t;
                     double m;
                     bool found;
@@ -2206,25 +2351,25 @@ __global__ __launch_bounds__(1024) void kb_scan_prologue(const SeqCtx* a, int sc
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
     d_scan_prologue(c);
 }
-__global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) { d_deskew_vds1(c, launch_slice()); }
+__global__ __launch_bounds__(256) void k_deskew_vds1(Ctx c) { d_deskew_vds1<1>(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_deskew_vds1(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_deskew_vds1(c, launch_slice());
+    d_deskew_vds1<1>(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_vds2(Ctx c) { d_vds2(c, launch_slice()); }
+__global__ __launch_bounds__(256) void k_vds2(Ctx c) { d_vds2<1>(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_vds2(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_vds2(c, launch_slice());
+    d_vds2<1>(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_compact_fd(Ctx c) { d_compact_fd(c, launch_slice()); }
+__global__ __launch_bounds__(256) void k_compact_fd(Ctx c) { d_compact_fd<1>(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_compact_fd(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_compact_fd(c, launch_slice());
+    d_compact_fd<1>(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_compact_src(Ctx c) { d_compact_src(c, launch_slice()); }
+__global__ __launch_bounds__(256) void k_compact_src(Ctx c) { d_compact_src<1>(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_compact_src(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_compact_src(c, launch_slice());
+    d_compact_src<1>(c, launch_slice());
 }
 __global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_in, const int* n_ptr, int n_fixed, int use_pose) { d_map_insert_a(c, pts_in, n_ptr, n_fixed, use_pose, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_insert_a(const SeqCtx* a, int scan_k) {

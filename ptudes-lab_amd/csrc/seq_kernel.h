@@ -52,6 +52,9 @@ __device__ __forceinline__ bool team_sync(unsigned* word, unsigned n, unsigned& 
 // file of a wavefront, and inlined into one body they spill into each other's loops.  Each loads the scan's context from
 // the sequence table itself (scalar loads), like the per-stage kernels.
 #define SEQ_FAIL 0xFFFFFFFFu
+#ifndef SEQ_U
+#define SEQ_U 4  /* points per thread and pass in K1-K4 (see Slice) */
+#endif
 // make STAGES=1: workgroup 0 of every sequence adds the wall-clock ticks of every stage and of every barrier wait to
 // st->dbg_sums[0..19] (tools/free_vs_lockstep.py prints them)
 #ifdef SEQ_STAGE_CLOCKS
@@ -66,7 +69,7 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     const Ctx c = load_seq_ctx(a, s, k);
     DevState* st = c.st;
     unsigned* word = a[s].bar + 32;
-    const int BS = (int)blockDim.x, nbs = (c.n_in + BS - 1) / BS;
+    const int BS = (int)blockDim.x * SEQ_U, nbs = (c.n_in + BS - 1) / BS;
     Slice sl;
     sl.nb = nbs;
     SQ_CLK_DECL;
@@ -74,19 +77,19 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     SQ_CLK(0);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
     SQ_CLK(1);
-    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_deskew_vds1(c, sl);
+    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_deskew_vds1<SEQ_U>(c, sl);
     SQ_CLK(2);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
     SQ_CLK(3);
-    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_vds2(c, sl);
+    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_vds2<SEQ_U>(c, sl);
     SQ_CLK(4);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
     SQ_CLK(5);
-    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_fd(c, sl);
+    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_fd<SEQ_U>(c, sl);
     SQ_CLK(6);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
     SQ_CLK(7);
-    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_src(c, sl);
+    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_src<SEQ_U>(c, sl);
     SQ_CLK(8);
     return target;
 }

@@ -44,6 +44,7 @@ for free in (True, False):
         if d[:20].sum() > 0:  # built with make STAGES=1
             names = ["prologue", "w", "deskew+vds1", "w", "vds2", "w", "compact_fd", "w", "compact_src", "-", "insert_a", "w", "insert_b", "w", "insert_c", "w", "prune"]
             print("  stages of sequence 0, us/scan:", "  ".join("%s %.0f" % (nm, v) for nm, v in zip(names, d[:17])))
+            print("  inside K1 (thread 0 of workgroup 0, its own waits): release %.0f | load + deskew + store %.0f | claim %.0f | bid %.0f | slot1 %.0f | count %.0f" % tuple(d[20:26]))
     b.close()
 worst = 0.0
 for s in range(S):
