@@ -196,10 +196,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seqs-per-gpu", type=int, default=16,
-                    help="independent sequences per GPU (SURVEY.md 8(e), second level), batched runner: 8 = one per XCD, 16 "
-                         "(default) / 32 = two / four per XCD - one Gauss-Newton loop alone leaves an XCD latency-bound, a "
-                         "second one fills the gaps; 1 = the single-sequence latency pipeline (one sequence over the whole chip)")
+    ap.add_argument("--seqs-per-gpu", type=int, default=32,
+                    help="independent sequences per GPU (SURVEY.md 8(e), second level), batched runner: 8 = one per XCD, 16 / 32 "
+                         "(default) = two / four per XCD - one Gauss-Newton loop alone leaves an XCD latency-bound, more of them "
+                         "fill the gaps (5.6k / 9.5k / 11.3k scans/s for 8 / 16 / 32); 1 = the single-sequence latency pipeline "
+                         "(one sequence over the whole chip)")
     ap.add_argument("--seed-base", type=int, default=1000, help="sequence s of SURVEY.md 8(d) uses seed seed_base + s")
     ap.add_argument("--equal-work", action="store_true",
                     help="every rank registers its own copy of sequences seed_base .. seed_base + S - 1 (equal work per GPU) "

@@ -1690,6 +1690,7 @@ __device__ __forceinline__ double sums_from_moments(int e, const double* M) {
 }
 
 #define GN8_ROW_ENTRIES 18   /* 16 moments, pair count, candidate count */
+#define GN8_QCAP (2 * GN8_MAX_THREADS)  /* queue of points awaiting the full search: the misses of several phase-A chunks share the search passes */
 #ifndef GN8_LPB
 #define GN8_LPB 8             /* lanes per point of the full search (8 or 4) */
 #endif
@@ -1715,9 +1716,9 @@ __device__ __forceinline__ void gn8_accumulate(double (&M)[GN8_ROW_ENTRIES], V3 
 template <int PC, int GC>
 __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt, const int wg) {
     const int G = GC > 0 ? GC : G_rt;
-    __shared__ int missq[GN8_MAX_THREADS];            // points of this chunk whose answer row did not settle them, compacted
-    __shared__ double miss_s[3][GN8_MAX_THREADS];     // ... and where they are now (phase A has just computed it)
-    __shared__ int wsum[GN8_MAX_THREADS / 64];
+    __shared__ int missq[GN8_QCAP];                   // points whose answer row did not settle them, in point order
+    __shared__ double miss_s[3][GN8_QCAP];            // ... and where they are now (phase A has just computed it)
+    __shared__ int wsum2[2][GN8_MAX_THREADS / 64];
     __shared__ double part[GN8_ROW_ENTRIES][16];
     __shared__ double redL8[64][GN8_ROW_ENTRIES];     // everybody's rows (G != 32)
     __shared__ double mom[GN8_ROW_ENTRIES];
@@ -1727,8 +1728,8 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     __shared__ int flag_done2[2];
     __shared__ long long cand_total_sh;
     DevState* st = c.st;
-    const int tid = threadIdx.x, lane8 = tid & 7, grp8 = tid >> 3, lane32 = tid & 31, grp32 = tid >> 5;
-    const int NT = blockDim.x, NG8 = blockDim.x >> 3, NG32 = blockDim.x >> 5, NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane32 = tid & 31, grp32 = tid >> 5;
+    const int NT = blockDim.x, NG32 = blockDim.x >> 5, NW = blockDim.x >> 6;
     const int n = st->n_src;
     const unsigned epoch = st->gn_epoch;
     if (wg == 0 && tid == 0 && mode == 0) flush_map_stats(c, st);
@@ -1763,7 +1764,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     const int nblk = (n + 63) >> 6;
     const int my_blocks = (nblk - wg + G - 1) / G;  // blocks wg, wg + G, ...
     int iters = 0;
-    long long ph_miss = 0, ph_a = 0, pb_t[5] = {0, 0, 0, 0, 0};
+    [[maybe_unused]] long long ph_miss = 0, ph_a = 0, pb_t[5] = {0, 0, 0, 0, 0};
     long long ph[5] = {0, 0, 0, 0, 0};  // (only with -DGN_PHASE_CLOCKS) point loop | wg reduce + publish | exchange | - | totals + solve
     for (int it = 0; it < c.max_iter; ++it) {
         const long long c0 = GN_CLK();
@@ -1772,8 +1773,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         double M[GN8_ROW_ENTRIES];
 #pragma unroll
         for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
+        int nq = 0;  // queued points (uniform over the workgroup)
         for (int qb = 0; qb < my_blocks; qb += NW) {
-            V3 sA;  // this lane's point of phase A
+            V3 sA;         // this lane's point of phase A
+            int missA = -1;  // ... and its index when the answer row did not settle it
             // ---- phase A, ONE LANE PER POINT (one pass, one memory round trip): apply the increment, look at the point's
             // answer row.  The last full search of the point (at s0, same voxel => same 27-voxel candidate set) found t and
             // every other candidate - scanned, or inside a dropped voxel's box - at >= D from s0.  After a move by
@@ -1826,13 +1829,14 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                         }
                     }
                 }
-                missq[tid] = miss;
+                missA = miss;
             }
-            __syncthreads();
-            // compaction of the noted points in point order (deterministic): wavefront scan, wavefront offsets
-            int nmiss;
+            // the noted points join the queue in point order (deterministic): wavefront scan, wavefront offsets.  A
+            // workgroup with more points than threads (four sequences per XCD) walks them in chunks; the chunks' misses
+            // share the search passes below - a pass costs its memory round trips whether 9 or 64 points ride on it.
             {
-                const int mine1 = missq[tid], cnt = mine1 >= 0 ? 1 : 0;
+                const int cnt = missA >= 0 ? 1 : 0;
+                int* wsum = wsum2[(qb / NW) & 1];  // (alternating: one barrier per chunk is enough)
                 int incl = cnt;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if ((tid & 63) >= o) incl += u; }
@@ -1840,25 +1844,28 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 __syncthreads();
                 int woff = 0, total = 0;
                 for (int w = 0; w < NW; ++w) { const int v = wsum[w]; if (w < (tid >> 6)) woff += v; total += v; }
-                nmiss = total;
 #ifdef GN_PHASE_CLOCKS
                 ph_miss += total; ph_a += GN_CLK() - c0;
                 if (wg == 0 && tid == 0 && it < 24) st->dbg_sums[8 + it] += (double)total;  // misses by iteration index
 #endif
-                if (cnt) {  // (a slot at or below the own one: everybody has read its slot)
-                    const int pos = woff + incl - 1;
-                    missq[pos] = mine1;
+                if (cnt) {
+                    const int pos = nq + woff + incl - 1;
+                    missq[pos] = missA;
                     miss_s[0][pos] = sA.x; miss_s[1][pos] = sA.y; miss_s[2][pos] = sA.z;
                 }
-                __syncthreads();
+                nq += total;
             }
-            // ---- phase B, GN8_LPB LANES PER POINT: the full search of the noted points (gn8_search)
+            if (qb + NW < my_blocks && nq + NT <= GN8_QCAP) continue;  // room for another chunk's misses
+            __syncthreads();
+            const int nmiss = nq;
+            nq = 0;
+            // ---- phase B, GN8_LPB LANES PER POINT: the full search of the queued points (gn8_search)
             {
                 constexpr int LPB = GN8_LPB;
                 const int laneL = tid & (LPB - 1), gb = (tid & 63) & ~(LPB - 1);
                 for (int k = tid / LPB; __any(k < nmiss); k += NT / LPB) {
                   if (k < nmiss) {
-                    const long long b0 = GN_CLK();
+                    [[maybe_unused]] const long long b0 = GN_CLK();
                     const int i = missq[k];
                     const V3 s = v3(miss_s[0][k], miss_s[1][k], miss_s[2][k]);  // (= src_cur[i], without the round trip)
                     V3 t;
