@@ -196,11 +196,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seqs-per-gpu", type=int, default=32,
-                    help="independent sequences per GPU (SURVEY.md 8(e), second level), batched runner: 8 = one per XCD, 16 / 32 "
-                         "(default) = two / four per XCD - one Gauss-Newton loop alone leaves an XCD latency-bound, more of them "
-                         "fill the gaps (5.6k / 9.5k / 11.3k scans/s for 8 / 16 / 32); 1 = the single-sequence latency pipeline "
-                         "(one sequence over the whole chip)")
+    ap.add_argument("--seqs-per-gpu", type=int, default=48,
+                    help="independent sequences per GPU (SURVEY.md 8(e), second level), batched runner.  The sequences s = x (mod 8) "
+                         "live on XCD x; up to 8 / 16 sequences: one / two teams of workgroups per XCD, one sequence each; more "
+                         "(default 48, up to 64): four teams per XCD that take the sequences' scans as they come free, so the "
+                         "sequences advance evenly (5.6k / 9.9k / 12.9k / 14.1k scans/s for 8 / 16 / 32 / 48).  One Gauss-Newton "
+                         "loop alone leaves an XCD latency-bound, more of them fill the gaps.  1 = the single-sequence latency "
+                         "pipeline (one sequence over the whole chip)")
     ap.add_argument("--seed-base", type=int, default=1000, help="sequence s of SURVEY.md 8(d) uses seed seed_base + s")
     ap.add_argument("--equal-work", action="store_true",
                     help="every rank registers its own copy of sequences seed_base .. seed_base + S - 1 (equal work per GPU) "
@@ -245,8 +247,8 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    if args.seqs_per_gpu < 1 or args.seqs_per_gpu > 32:
-        sys.exit("bench.py: --seqs-per-gpu must be in [1, 32]")
+    if args.seqs_per_gpu < 1 or args.seqs_per_gpu > 64:
+        sys.exit("bench.py: --seqs-per-gpu must be in [1, 64]")
     multi = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # a rank of a multi-process run
     dist = None
     torch = None

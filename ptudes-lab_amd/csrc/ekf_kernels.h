@@ -390,7 +390,7 @@ __global__ __launch_bounds__(384) void k_ekf_pose_value(EkfState* e, EkfPoseArg 
     d_ekf_step(e, nullptr, 0, 0, sp, a.has_cov ? sp + 16 : nullptr, nullptr, nullptr, nullptr, 0);
 }
 // S filters in one launch (blockIdx.x = sequence)
-#define EKF_MAX_SEQ 32
+#define EKF_MAX_SEQ 64
 struct EkfBatchArgs {
     EkfState* e[EKF_MAX_SEQ];
     const double* imu[EKF_MAX_SEQ];

@@ -1526,11 +1526,34 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
     const bool same_voxel = it > 0 && c.pc_key[i] == key;
     if (!same_voxel) {  // uniform over the group: probe this lane's neighbour voxels, rebuild the row
         int cs = 0;
+        {   // this lane's RE probes with their first table reads in flight together; a collision walks on by itself
+            unsigned long long kq[RE];
+            unsigned sq[RE];
+            TabEnt eq[RE];
 #pragma unroll
-        for (int q = 0; q < RE; ++q) {
-            const int ee = RE * laneL + q;
-            r[q] = (ee < 27) ? map_find(c, pack_key(kx + ee / 9 - 1, ky + (ee / 3) % 3 - 1, kz + ee % 3 - 1)) : -1;
-            cs += (r[q] < 0) ? 0 : (int)((unsigned)r[q] >> 24);
+            for (int q = 0; q < RE; ++q) {
+                const int ee = RE * laneL + q;
+                kq[q] = pack_key(kx + ee / 9 - 1, ky + (ee / 3) % 3 - 1, kz + ee % 3 - 1);
+                sq[q] = (unsigned)mix64(kq[q]) & c.tmask;
+                eq[q].key = EMPTY_KEY; eq[q].blk = -1; eq[q].head = -1;
+                if (ee < 27) eq[q] = c.tab[sq[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < RE; ++q) {
+                int b = -1;
+                if (eq[q].key == kq[q]) b = eq[q].blk;
+                else if (eq[q].key != EMPTY_KEY) {  // occupied by another voxel (or a tombstone): linear probing from the next slot
+                    unsigned sp = (sq[q] + 1) & c.tmask;
+                    for (unsigned probe = 1; probe <= c.tmask; ++probe) {
+                        const TabEnt e = c.tab[sp];
+                        if (e.key == kq[q]) { b = e.blk; break; }
+                        if (e.key == EMPTY_KEY) break;
+                        sp = (sp + 1) & c.tmask;
+                    }
+                }
+                r[q] = b;
+                cs += (b < 0) ? 0 : (int)((unsigned)b >> 24);
+            }
         }
         cs = group_sumL<LP>(cs);
         if (laneL == 28 / RE) r[28 % RE] = cs;  // entry 28: candidates of the 27 voxels (entry 27: no last winner yet = -1)
@@ -2343,7 +2366,6 @@ struct SeqCtx {
     const double* imu;             // [n_imu][7]
     const int* imu_end;            // [n_scans] IMU samples that precede scan k
     double *res_poses, *res_t, *rows;
-    unsigned* bar;                 // [64] the sequence's two workgroup-team barrier counters (word 0 and word 32), zeroed before every launch
 };
 __device__ __forceinline__ Ctx load_seq_ctx(const SeqCtx* a, int s, int scan_k) {
     Ctx c = a[s].c;
@@ -2411,7 +2433,7 @@ __global__ __launch_bounds__(256) void kb_map_rebuild(const SeqCtx* a, int scan_
 // its workgroups meet through the one-hop exchange of gn_loop_body<XL = true> - nothing crosses the chip - and it leaves
 // the loop on its own convergence.  Per sequence the point -> workgroup assignment, the reduction trees and the
 // arithmetic are those of k_gn_loop launched alone with gridDim / 8 workgroups: bit-identical results.
-#define GN_MAX_SEQ 32  /* up to four sequences per XCD */
+#define GN_MAX_SEQ 64  /* lockstep: up to four sequences per XCD (32); free-running: up to eight, served by up to four teams */
 // S <= 8: sequence s <-> XCD s with all gridDim / 8 workgroups of that XCD.  S > 8: the XCD's workgroups are split evenly
 // among the sequences s, s + 8, s + 16, ... it hosts (spx of them, a power of two): one sequence alone leaves an XCD
 // latency-bound and mostly idle (it costs the same per iteration as eight on eight), a second and a fourth loop fill

@@ -1282,7 +1282,8 @@ struct ptl_batch {
     float* d_scans[GN_MAX_SEQ];
     double* d_imu[GN_MAX_SEQ];
     int* d_imu_end[GN_MAX_SEQ];
-    unsigned* d_bar;            // [GN_MAX_SEQ][64] team barrier counters of the free-running kernel
+    unsigned* d_bar;            // [32 teams][64] barrier counters and job words of the free-running kernel's teams
+    SeqSched* d_sched;          // [8] its per-XCD scan schedulers
     bool free_running;
     int64_t scans_per_launch;
     std::vector<int64_t> imu_end[GN_MAX_SEQ];
@@ -1315,6 +1316,7 @@ static int batch_check_seq_run(ptl_batch* b) {
     const int gseq = batch_gseq(b);
     if (gseq < 2 && b->cfg.with_ekf) return set_err(PTL_ERR_ARG, "free-running batches with a filter need at least 2 workgroups per sequence");
     if (gseq < 1) return set_err(PTL_ERR_ARG, "gn_workgroups too small for %d sequences", b->S);
+    if (b->S > 8 * SEQ_SLOTS) return set_err(PTL_ERR_ARG, "at most %d sequences", 8 * SEQ_SLOTS);
     int per_cu = 0, cus = 0;
     const bool p20 = ic.max_points_per_voxel == 20;
     hipError_t e = gseq == 32 ? seq_run_occupancy<32>(p20, ic.gn_threads, &per_cu) : gseq == 16 ? seq_run_occupancy<16>(p20, ic.gn_threads, &per_cu)
@@ -1338,6 +1340,7 @@ extern "C" int ptl_batch_destroy(ptl_batch* b) {
     }
     if (b->d_ctx) (void)hipFree(b->d_ctx);
     if (b->d_bar) (void)hipFree(b->d_bar);
+    if (b->d_sched) (void)hipFree(b->d_sched);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->ev_gn) (void)hipEventDestroy(b->ev_gn);
     if (b->ev_side) (void)hipEventDestroy(b->ev_side);
@@ -1356,7 +1359,7 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     ptl_batch* b = new ptl_batch();
     b->cfg = *cfg;
     b->S = n_sequences;
-    b->stream = nullptr; b->d_ctx = nullptr; b->lut = nullptr; b->is_range = 0; b->d_bar = nullptr;
+    b->stream = nullptr; b->d_ctx = nullptr; b->lut = nullptr; b->is_range = 0; b->d_bar = nullptr; b->d_sched = nullptr;
     b->free_running = cfg->icp.gn_lanes_per_point == 8;
     b->scans_per_launch = 256;
     b->next_scan = 0; b->n_out = 0; b->ctx_dirty = true; b->prof = false; b->ev_used = 0; b->gn_ms = 0; b->gn_launches = 0;
@@ -1388,7 +1391,7 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
         if (rc == PTL_OK && hipMemset(b->d_imu_end[s], 0, (size_t)cfg->n_scans * sizeof(int)) != hipSuccess) rc = set_err(PTL_ERR_HIP, "memset failed");
         b->imu_end[s].assign((size_t)cfg->n_scans, 0);
     }
-    if (rc == PTL_OK && (dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess || dalloc(&b->d_bar, (size_t)GN_MAX_SEQ * 64) != hipSuccess))
+    if (rc == PTL_OK && (dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess || dalloc(&b->d_bar, (size_t)GN_MAX_SEQ * 64) != hipSuccess || dalloc(&b->d_sched, (size_t)8) != hipSuccess))
         rc = set_err(PTL_ERR_HIP, "batch allocation failed");
     if (rc == PTL_OK && b->free_running) rc = batch_check_seq_run(b);
     if (rc) { ptl_batch_destroy(b); return rc; }
@@ -1454,7 +1457,6 @@ static int batch_push_ctx(ptl_batch* b) {
         h[s].fd_buf[0] = b->icp[s]->fd_buf[0]; h[s].fd_buf[1] = b->icp[s]->fd_buf[1];
         h[s].ekf = b->ekf[s]->st; h[s].imu = b->d_imu[s]; h[s].imu_end = b->d_imu_end[s];
         h[s].res_poses = b->d_res_poses[s]; h[s].res_t = b->d_res_t[s]; h[s].rows = b->d_rows[s];
-        h[s].bar = b->d_bar + (size_t)s * 64;
     }
     HIPCHK(hipMemcpyAsync(b->d_ctx, h, sizeof h, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1498,6 +1500,7 @@ static int batch_enqueue_free(ptl_batch* b, int64_t n) {
             if (any) kb_ekf_step<<<S, 384, 0, st>>>(ea);
         }
         HIPCHK(hipMemsetAsync(b->d_bar, 0, (size_t)GN_MAX_SEQ * 64 * sizeof(unsigned), st));
+        k_sched_init<<<1, 64, 0, st>>>(b->d_sched, S, (int)k0, (int)k1);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (b->prof) {
             if (b->ev_used + 2 > b->ev.size())
@@ -1509,8 +1512,8 @@ static int batch_enqueue_free(ptl_batch* b, int64_t n) {
         r.S = S; r.k0 = (int)k0; r.k1 = (int)k1; r.with_ekf = with_ekf ? 1 : 0; r.rebuild_every = ic.rebuild_every;
         const int gseq = batch_gseq(b);
         const bool p20 = ic.max_points_per_voxel == 20;
-#define KXR(GC) do { if (p20) kx_seq_run<20, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r); \
-                     else kx_seq_run<0, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r); } while (0)
+#define KXR(GC) do { if (p20) kx_seq_run<20, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r, b->d_sched, b->d_bar); \
+                     else kx_seq_run<0, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r, b->d_sched, b->d_bar); } while (0)
         if (gseq == 32) KXR(32); else if (gseq == 16) KXR(16); else if (gseq == 8) KXR(8); else KXR(0);
 #undef KXR
         if (b->prof) HIPCHK(hipEventRecord(e1, st));
@@ -1539,6 +1542,7 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
     if (b->ctx_dirty) { int rc = batch_push_ctx(b); if (rc) return rc; }
     if (b->free_running) return batch_enqueue_free(b, n);
+    if (b->S > 32) return set_err(PTL_ERR_ARG, "the lockstep driver serves up to 32 sequences (four per XCD); %d need the free-running one", b->S);
     const bool with_ekf = b->cfg.with_ekf != 0;
     const int S = b->S;
     const int64_t pps = b->cfg.points_per_scan;

@@ -16,6 +16,12 @@
 // sequence whose loop converges early simply starts its next scan.  Stage bodies, reduction trees and the exchange are
 // the ones of the per-stage kernels: results are bit-identical to the lockstep run and to the single-sequence run with
 // as many Gauss-Newton workgroups.
+//
+// Teams are not tied to sequences: the sequences s = x (mod 8) belong to XCD x (their maps stay in its L2), the XCD's
+// teams (1, 2 or 4) serve them scan by scan - a team that finishes a scan takes the next scan of the sequence of its
+// XCD that is furthest behind and not being worked on (SeqSched).  With more sequences than teams the sequences advance
+// evenly although their scans cost up to 40 % more or less than the average, and the run does not end with most
+// of the chip waiting for the slowest one.
 #pragma once
 #include "ekf_kernels.h"
 #include "icp_kernels.h"
@@ -65,10 +71,9 @@ __device__ __forceinline__ bool team_sync(unsigned* word, unsigned n, unsigned& 
 #define SQ_CLK(i) do { } while (0)
 #endif
 // K0-K4 of scan k by the team's `nw` working workgroups (this one is number `wg`); returns the barrier target, SEQ_FAIL on abort
-__device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target) {
+__device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, unsigned* word) {
     const Ctx c = load_seq_ctx(a, s, k);
     DevState* st = c.st;
-    unsigned* word = a[s].bar + 32;
     const int BS = (int)blockDim.x * SEQ_U, nbs = (c.n_in + BS - 1) / BS;
     Slice sl;
     sl.nb = nbs;
@@ -94,10 +99,9 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     return target;
 }
 // K7-K11 of scan k
-__device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, int rebuild) {
+__device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, int rebuild, unsigned* word) {
     const Ctx c = load_seq_ctx(a, s, k);
     DevState* st = c.st;
-    unsigned* word = a[s].bar + 32;
     const int BS = (int)blockDim.x, nbd = (st->n_down_ins + BS - 1) / BS;
     Slice sl;
     sl.nb = nbd;
@@ -143,46 +147,105 @@ __device__ __noinline__ void sq_filter(const SeqCtx* my, int k) {
 
 struct SeqRun { int S, k0, k1, with_ekf, rebuild_every; };
 
+// scheduler state of one XCD's sequences (slot q <-> sequence x + 8 q): the next scan of each and whether a team is on it
+#define SEQ_SLOTS 8
+struct SeqSched { int next_scan[SEQ_SLOTS]; int busy[SEQ_SLOTS]; int pad[16]; };  // 128 B
+__global__ void k_sched_init(SeqSched* sc, int S, int k0, int k1) {
+    const int x = threadIdx.x >> 3, q = threadIdx.x & 7;
+    if (x >= 8) return;
+    sc[x].next_scan[q] = (x + 8 * q < S) ? k0 : k1;
+    sc[x].busy[q] = 0;
+}
+// The team leader's choice: the sequence of this XCD with the fewest scans done that nobody is working on, or -1 when
+// every sequence has reached k1 (or nothing came free for TEAM_BAR_TICKS: a team that left its sequence marked busy).
+__device__ __forceinline__ int sched_pick(SeqSched* sc, int k1, int* scan_out) {
+    const long long t0 = (long long)wall_clock64();
+    for (;;) {
+        int best = -1, bestk = 0x7FFFFFFF;
+        bool pending = false;
+#pragma unroll
+        for (int q = 0; q < SEQ_SLOTS; ++q) {
+            const int k = __hip_atomic_load(&sc->next_scan[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k >= k1) continue;
+            pending = true;
+            if (__hip_atomic_load(&sc->busy[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && k < bestk) { best = q; bestk = k; }
+        }
+        if (!pending) return -1;
+        if (best >= 0 && atomicCAS(&sc->busy[best], 0, 1) == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the team that ran the previous scan wrote
+            const int k = __hip_atomic_load(&sc->next_scan[best], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k < k1) { *scan_out = k; return best; }
+            __hip_atomic_store(&sc->busy[best], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (finished meanwhile)
+            continue;
+        }
+        if ((long long)wall_clock64() - t0 > TEAM_BAR_TICKS) return -1;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+__device__ __forceinline__ void sched_release(SeqSched* sc, int q, int next_scan) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(&sc->next_scan[q], next_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sc->busy[q], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// bar: per team 64 words - [0] barrier of the whole team, [32] of its working workgroups, [40], [41] the leader's job (sequence, scan)
 template <int PC, int GC>
-__global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, SeqRun r) {
-    int s, G, wg;
-    if (!kx_assign(r.S, s, G, wg)) return;
-    const SeqCtx* my = a + s;
-    DevState* st = my->c.st;
-    // with a filter, the team's last workgroup is the filter workgroup: it only joins the two barriers around the
-    // Gauss-Newton loop, steps the filter after it and is back, waiting, long before the others have updated the map
-    // and prepared the next scan
+__global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, SeqRun r, SeqSched* sched, unsigned* bar) {
+    const int x = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3), J = (int)(gridDim.x >> 3);
+    const int G = GC > 0 ? GC : J / (r.S <= 8 ? 1 : (r.S <= 16 ? 2 : 4));
+    const int t = j / G, wg = j % G;
+    if (x >= r.S || (t + 1) * G > J) return;  // no sequence on this XCD / a workgroup beyond the last whole team
+    unsigned* tb = bar + (size_t)(x + 8 * t) * 64;
+    SeqSched* sc = sched + x;
+    // with a filter, the team's last workgroup is the filter workgroup: it only joins the barriers around the
+    // Gauss-Newton loop and at the end of the scan, steps the filter after the loop and is back, waiting, long before the
+    // others have updated the map
     const bool fwg = r.with_ekf && wg == G - 1;
     const int nw = r.with_ekf ? G - 1 : G;
     unsigned t_all = 0u, t_work = 0u;
-    const bool clk0 = wg == 0 && threadIdx.x == 0, clkf = fwg && threadIdx.x == 0;  // who keeps the phase clocks (st->seq_clk)
-    long long ph[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = r.k0; k < r.k1; ++k) {
+    const bool lead = wg == 0 && threadIdx.x == 0, clkf = fwg && threadIdx.x == 0;
+    DevState* st = a[x].c.st;  // (any state of this XCD for the abort word of the first barrier)
+    int q_mine = -1, k_mine = 0;
+    for (;;) {
+        if (lead) {  // hand the finished scan back, take the next job
+            if (q_mine >= 0) sched_release(sc, q_mine, k_mine + 1);
+            int k = 0;
+            const int q = sched_pick(sc, r.k1, &k);
+            q_mine = q; k_mine = k;
+            __hip_atomic_store(&tb[40], (unsigned)(q < 0 ? 0xFFFFFFFFu : (unsigned)(x + 8 * q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&tb[41], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!team_sync(tb, (unsigned)G, t_all, st)) return;
+        const unsigned job = __hip_atomic_load(&tb[40], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (job == 0xFFFFFFFFu) return;
+        const int s = (int)job, k = (int)__hip_atomic_load(&tb[41], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const SeqCtx* my = a + s;
+        st = my->c.st;
         const long long c0 = (long long)wall_clock64();
         if (!fwg) {
-            t_work = sq_prepare(a, s, k, wg, nw, t_work);
+            t_work = sq_prepare(a, s, k, wg, nw, t_work, tb + 32);
             if (t_work == SEQ_FAIL) return;
         }
         const long long c1 = (long long)wall_clock64();
-        if (!team_sync(my->bar, (unsigned)G, t_all, st)) return;  // source ready; the previous scan's map update and filter step complete
+        if (!team_sync(tb, (unsigned)G, t_all, st)) return;  // source ready (map and filter: complete since the scan before)
         const long long c2 = (long long)wall_clock64();
         sq_gauss_newton<PC, GC>(a, s, k, G, wg);
         if (gn_abort_seen(&st->gn_abort)) return;
         const long long c3 = (long long)wall_clock64();
-        if (!team_sync(my->bar, (unsigned)G, t_all, st)) return;  // new pose, trajectory row
+        if (!team_sync(tb, (unsigned)G, t_all, st)) return;  // new pose, trajectory row
         const long long c4 = (long long)wall_clock64();
         if (fwg) {
             sq_filter(my, k);
         } else {
-            t_work = sq_map_update(a, s, k, wg, nw, t_work, (r.rebuild_every > 0 && ((k + 1) % r.rebuild_every) == 0) ? 1 : 0);
+            t_work = sq_map_update(a, s, k, wg, nw, t_work, (r.rebuild_every > 0 && ((k + 1) % r.rebuild_every) == 0) ? 1 : 0, tb + 32);
             if (t_work == SEQ_FAIL) return;
         }
         const long long c5 = (long long)wall_clock64();
-        ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4;
+        if (lead) {
+            st->seq_clk[0] += c1 - c0; st->seq_clk[1] += c2 - c1; st->seq_clk[2] += c3 - c2; st->seq_clk[3] += c4 - c3; st->seq_clk[4] += c5 - c4;
+            st->seq_clk[6] += 1;
+        }
+        if (clkf) st->seq_clk[5] += c5 - c4;
+        if (!team_sync(tb, (unsigned)G, t_all, st)) return;  // the scan is complete: the sequence may go to another team
     }
-    if (clk0) {
-        for (int i = 0; i < 5; ++i) st->seq_clk[i] += ph[i];
-        st->seq_clk[6] += r.k1 - r.k0;
-    }
-    if (clkf) st->seq_clk[5] += ph[4];
 }

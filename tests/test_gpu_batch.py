@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("use_imu,S,lanes,driver", [(True, 3, 8, "free"), (False, 3, 8, "free"), (True, 8, 8, "free"), (True, 3, 32, "lockstep"),
                                                     (True, 12, 8, "free"), (True, 20, 8, "free"), (True, 3, 8, "lockstep"),
-                                                    (True, 12, 8, "lockstep"), (True, 5, 8, "free3")])
+                                                    (True, 12, 8, "lockstep"), (True, 5, 8, "free3"), (True, 43, 8, "free")])
 def test_batch_equals_independent_runs(use_imu, S, lanes, driver):
-    n = 10 if S <= 8 else 6
+    # (43 sequences: more than the 32 teams of the chip - five or six per XCD, whose four teams take the scans as they come free)
+    n = 10 if S <= 8 else 6 if S <= 32 else 5
     seqs = [synth.make_sequence(seed=1010 + s, n_scans=n) for s in range(S)]
     n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
     # "free3": launches of 3 scans (several per run) and a hash-table rebuild every 4 scans inside the kernel
@@ -98,6 +99,14 @@ def test_free_running_kernel_leaves_when_a_workgroup_never_arrives():
         b.wait()
     assert time.perf_counter() - t0 < 120.0
     assert all(st["iterations"] > 0 for st in b.results(0)["stats"][1:n])  # sequence 0 went through all four scans (the first one meets an empty map)
+
+
+def test_lockstep_serves_at_most_32_sequences():
+    b = core.BatchRunner(33, 2, 1024, 2, with_ekf=True, max_points_per_scan=1024, scan_cols=64, free_running=False)
+    for s in range(33):
+        b.upload_imu(s, np.zeros((2, 7)), [1, 2])
+    with pytest.raises(ValueError, match="lockstep"):
+        b.run(1)
 
 
 def test_free_running_needs_the_8_lane_kernel():

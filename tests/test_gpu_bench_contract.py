@@ -71,17 +71,17 @@ def test_bench_launches_its_own_ranks_on_distinct_sequences(tmp_path):
 
 @pytest.mark.gpu
 def test_bench_default_is_the_batched_runner():
-    """no flags but short: 32 independent sequences on the GPU (seeds 1000..1031, four per XCD) in the free-running kernel
-    (one persistent launch for the timed steps), `value` = 32 scans per step, sequence 0 checked against the oracle inside
-    the run"""
+    """no flags but short: 48 independent sequences on the GPU (seeds 1000..1047, six per XCD served by four teams) in the
+    free-running kernel (one persistent launch for the timed steps), `value` = 48 scans per step, sequence 0 checked
+    against the oracle inside the run"""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "8", "--cpu-budget", "3"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 32 and d["config"]["sequence_seeds"].startswith("1000..1031")
-    assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 48 and d["config"]["sequence_seeds"].startswith("1000..1047")
+    assert abs(d["value"] - 48 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["kernel"] == "kx_seq_run" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["launches"] == 1
     assert d["config"]["driver"].startswith("free-running") and d["config"]["workload_key"].endswith("_free")
     ph = d["sequence_phases_us_per_scan"]
