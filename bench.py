@@ -462,7 +462,9 @@ def main():
                                             f"every {ev_every}th of {K} (HIP events)"),
                          "note": ("the free-running kernel carries the WHOLE per-scan pipeline of every sequence: frac = B_scan of SURVEY "
                                   "8(d) (pre-processing + down-sampling + the Gauss-Newton iterations + map update) of all scans of a "
-                                  "launch / launch time / peak; " if free else
+                                  "launch / launch time / peak - it can exceed 1: the answer cache settles most point-iterations "
+                                  "without the 27 probes and the candidate reads the formula charges, and most of the rest hits the "
+                                  "L2; what reaches HBM is `traffic`; " if free else
                                   "frac = ALGORITHMIC bytes (SURVEY 8(d): 27 probes x 16 B + every candidate x 12 B + the source, per "
                                   "iteration) / launch time / peak; ") +
                                  "measured_frac = PMC HBM bytes of the same workload / launch time / peak"},

@@ -255,14 +255,13 @@ int ptl_seq_icp(ptl_seq *s, ptl_icp **icp);
 int ptl_seq_profile(ptl_seq *s, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
 
 /* ------------------------------------------------------------------------------------------------
- * Batched runner: up to 32 independent sequences on ONE GPU - one XCD each up to 8, two / four per XCD (sharing its
- * workgroups evenly) up to 16 / 32.  Every stage is one launch for all
- * sequences; in the persistent Gauss-Newton launch the workgroups with blockIdx & 7 == s own sequence s (its map, probe
- * rows and exchange stay in that XCD's L2; it leaves the loop on its own convergence).  Each sequence's results are
- * bit-identical to running it alone with its share of the workgroups (gn_workgroups / 8, / 16, / 32) and the same
- * gn_lanes_per_point.  cfg describes
- * every sequence (same n_scans / points_per_scan / n_imu; gn_workgroups = 8 x workgroups per sequence); with_ekf
- * requires >= 1 IMU sample between consecutive scans.
+ * Batched runner: up to 64 independent sequences on ONE GPU.  The sequences s = x (mod 8) live on XCD x (their maps,
+ * probe rows and exchange stay in its L2); the workgroups with blockIdx & 7 == x form 1 / 2 / 4 teams of gn_workgroups /
+ * 8, / 16, / 32 workgroups (<= 8 / <= 16 / more sequences).  Two drivers, see ptl_batch_set_driver: the free-running
+ * kernel (default) and lockstep (one launch per stage for all sequences, <= 32 sequences).  Each sequence's results are
+ * bit-identical to running it alone with a team's workgroups (gn_workgroups / 8, / 16, / 32) and the same
+ * gn_lanes_per_point.  cfg describes every sequence (same n_scans / points_per_scan / n_imu; gn_workgroups = 8 x
+ * workgroups per XCD); with_ekf requires >= 1 IMU sample between consecutive scans.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ptl_batch ptl_batch;
 int ptl_batch_create(const ptl_seq_cfg *cfg, int32_t n_sequences, ptl_batch **out);

@@ -82,7 +82,9 @@ def test_bench_default_is_the_batched_runner():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 48 and d["config"]["sequence_seeds"].startswith("1000..1047")
     assert abs(d["value"] - 48 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert d["roofline"]["kernel"] == "kx_seq_run" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["launches"] == 1
+    # (frac = SURVEY 8(d)'s algorithmic bytes / time / peak may exceed 1 here: the answer cache and the L2 keep most of those
+    # bytes from ever being requested - what reaches HBM is `traffic`, from a PMC pass of the same workload)
+    assert d["roofline"]["kernel"] == "kx_seq_run" and d["roofline"]["frac"] > 0 and d["roofline"]["launches"] == 1
     assert d["config"]["driver"].startswith("free-running") and d["config"]["workload_key"].endswith("_free")
     ph = d["sequence_phases_us_per_scan"]
     assert ph["slowest_sequence_total"] >= ph["mean_sequence_total"] > 0
