@@ -29,9 +29,10 @@
 // Barrier of the `n` workgroups of a team on a counter in device memory (zeroed by the host before the launch): the
 // k-th barrier is passed when the counter reaches k n (`target`, kept by the caller; only thread 0's copy counts).
 // Agent-scope release before the arrival and acquire after the last one: the stages exchange their data through plain
-// global memory.  A wait that exceeds TEAM_BAR_TICKS, or sees the sequence's abort word, raises ERR_GN_TIMEOUT and
+// global memory.  A wait that exceeds TEAM_BAR_POLLS, or sees the sequence's abort word, raises ERR_GN_TIMEOUT and
 // returns false: the caller leaves the kernel (and so does, at its next barrier, every other workgroup of the team).
-#define TEAM_BAR_TICKS 300000000ll /* of the 100 MHz wall clock: 3 s */
+#define TEAM_BAR_POLLS (1u << 23) /* polls with an s_sleep between them: several seconds of EXECUTED time (a wall-clock limit would fire
+                                     falsely when the queue is time-sliced with another process's and the team sleeps in between) */
 __device__ __forceinline__ bool team_sync(unsigned* word, unsigned n, unsigned& target, DevState* st) {
     __shared__ int s_bad;
     __syncthreads();
@@ -40,11 +41,10 @@ __device__ __forceinline__ bool team_sync(unsigned* word, unsigned n, unsigned& 
         int bad = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0 = (long long)wall_clock64();
         unsigned polls = 0;
         while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if ((++polls & 255u) == 0u && (gn_abort_seen(&st->gn_abort) || (long long)wall_clock64() - t0 > TEAM_BAR_TICKS)) { bad = 1; break; }
+            if ((++polls & 255u) == 0u && (gn_abort_seen(&st->gn_abort) || polls > TEAM_BAR_POLLS)) { bad = 1; break; }
         }
         if (bad) gn_raise_abort(st);
         s_bad = bad;
@@ -157,9 +157,9 @@ __global__ void k_sched_init(SeqSched* sc, int S, int k0, int k1) {
     sc[x].busy[q] = 0;
 }
 // The team leader's choice: the sequence of this XCD with the fewest scans done that nobody is working on, or -1 when
-// every sequence has reached k1 (or nothing came free for TEAM_BAR_TICKS: a team that left its sequence marked busy).
+// every sequence has reached k1 (or nothing came free for a long time: a team that left its sequence marked busy).
 __device__ __forceinline__ int sched_pick(SeqSched* sc, int k1, int* scan_out) {
-    const long long t0 = (long long)wall_clock64();
+    unsigned polls = 0;
     for (;;) {
         int best = -1, bestk = 0x7FFFFFFF;
         bool pending = false;
@@ -178,7 +178,7 @@ __device__ __forceinline__ int sched_pick(SeqSched* sc, int k1, int* scan_out) {
             __hip_atomic_store(&sc->busy[best], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (finished meanwhile)
             continue;
         }
-        if ((long long)wall_clock64() - t0 > TEAM_BAR_TICKS) return -1;
+        if (++polls > TEAM_BAR_POLLS / 4) return -1;
         __builtin_amdgcn_s_sleep(8);
     }
 }
