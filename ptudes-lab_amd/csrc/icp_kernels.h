@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_build_lut(int H, int W, const double* a
 struct Slice { int b, nb; };
 __device__ __forceinline__ Slice launch_slice() { Slice s; s.b = (int)blockIdx.x; s.nb = (int)gridDim.x; return s; }
 #define STAGE_MAX_WAVES 16  /* blockDim.x <= 1024 */
-#define STAGE_MAX_U 4
+#define STAGE_MAX_U 8
 
 // U find-or-claims in a per-scan VDS table with their probes in flight together: the hashed slot of each (one load; one
 // compare-and-swap where it was empty), and whatever that does not settle (a collision) goes through vds_claim
@@ -1736,6 +1736,30 @@ __device__ __forceinline__ void gn8_accumulate(double (&M)[GN8_ROW_ENTRIES], V3 
 }
 // GC (compile time): the number of cooperating workgroups when it is 32 / 16 / 8 (the batched runner's shares of an XCD:
 // the exchange then unrolls over exactly that many rows), 0 = any (run-time G).
+// What phase A needs from memory for one point: its previous position and (after the first iteration) its voxel key and
+// answer row.  None of it depends on the increment of the iteration, so the loads are issued early - the next chunk's
+// before the current chunk is evaluated, the next iteration's first chunk before the sums are exchanged and the system
+// is solved - and phase A itself does not wait for memory.
+struct Gn8Pre {
+    double px, py, pz;
+    unsigned long long key;
+    double2 r0, r1, r2, r3, r4, r5;  // s0.xy | s0.z t.x | t.yz | bound, count | t2.xy | t2.z, order ids
+};
+__device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, bool first) {
+    Gn8Pre p;
+    p.px = p.py = p.pz = 0.0; p.key = EMPTY_KEY;
+    p.r0 = p.r1 = p.r2 = p.r3 = p.r4 = p.r5 = make_double2(0.0, -1.0);
+    if (valid) {
+        const double* sp0 = first ? c.src0 : c.src_cur;
+        p.px = sp0[3 * (size_t)i]; p.py = sp0[3 * (size_t)i + 1]; p.pz = sp0[3 * (size_t)i + 2];
+        if (!first) {
+            p.key = c.pc_key[i];
+            const double2* row = (const double2*)(c.pc_ans + GN8_ANS_ROW * (size_t)i);
+            p.r0 = row[0]; p.r1 = row[1]; p.r2 = row[2]; p.r3 = row[3]; p.r4 = row[4]; p.r5 = row[5];
+        }
+    }
+    return p;
+}
 template <int PC, int GC>
 __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt, const int wg) {
     const int G = GC > 0 ? GC : G_rt;
@@ -1789,6 +1813,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     int iters = 0;
     [[maybe_unused]] long long ph_miss = 0, ph_a = 0, pb_t[5] = {0, 0, 0, 0, 0};
     long long ph[5] = {0, 0, 0, 0, 0};  // (only with -DGN_PHASE_CLOCKS) point loop | wg reduce + publish | exchange | - | totals + solve
+    // this lane's point of chunk qb: block qb + wavefront of this workgroup, i.e. global block (qb + wavefront) G + wg
+    auto chunk_point = [&](int qb, int& i) -> bool { const int q = qb + (tid >> 6); i = ((q * G + wg) << 6) + (tid & 63); return q < my_blocks && i < n; };
+    Gn8Pre pre;
+    { int i0; const bool v0 = chunk_point(0, i0); pre = gn8_preload(c, i0, v0, true); }
     for (int it = 0; it < c.max_iter; ++it) {
         const long long c0 = GN_CLK();
         const double* Esh = Esh2[(it + 1) & 1];
@@ -1813,23 +1841,27 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             // no answer | candidate count of the 27 voxels | runner-up (3) | order ids.  The distance, the gate and the
             // weight come from the current s either way - same values as after a search.
             {
-                const int q = qb + (tid >> 6), i = ((q * G + wg) << 6) + (tid & 63);
+                int i;
+                const bool valid = chunk_point(qb, i);
+                const Gn8Pre cur = pre;
+                if (qb + NW < my_blocks) {  // the next chunk's loads, in flight while this one is evaluated
+                    int i2;
+                    const bool v2 = chunk_point(qb + NW, i2);
+                    pre = gn8_preload(c, i2, v2, it == 0);
+                }
                 int miss = -1;
                 sA = v3(0.0, 0.0, 0.0);
-                if (q < my_blocks && i < n) {
+                if (valid) {
                     Rt E;
                     for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
                     for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
-                    const double* sp0 = (it == 0) ? c.src0 : c.src_cur;
-                    const V3 s = rt_apply(E, v3(sp0[3 * (size_t)i], sp0[3 * (size_t)i + 1], sp0[3 * (size_t)i + 2]));
+                    const V3 s = rt_apply(E, v3(cur.px, cur.py, cur.pz));
                     c.src_cur[3 * (size_t)i] = s.x; c.src_cur[3 * (size_t)i + 1] = s.y; c.src_cur[3 * (size_t)i + 2] = s.z;
                     sA = s;
                     miss = i;
                     if (it > 0) {
-                        const unsigned long long old_key = c.pc_key[i];
-                        const double2* row = (const double2*)(c.pc_ans + GN8_ANS_ROW * (size_t)i);
-                        const double2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];  // s0.xy | s0.z t.x | t.yz | bound, count
-                        const double2 r4 = row[4], r5 = row[5];                            // t2.xy | t2.z, order ids
+                        const unsigned long long old_key = cur.key;
+                        const double2 r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, r3 = cur.r3, r4 = cur.r4, r5 = cur.r5;
                         const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
                         const double ex = s.x - r0.x, ey = s.y - r0.y, ez = s.z - r1.x;
                         const double delta2 = ex * ex + ey * ey + ez * ez;
@@ -1924,7 +1956,16 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 }
             }
             __syncthreads();  // the queue is reused by the next chunk
+            {   // (queue flushed before the last chunk: its loads are requested again rather than carried across the search;
+                // after the last chunk nothing is loaded - chunk_point says so - and the stale values are dead for the compiler too)
+                int i2;
+                const bool v2 = chunk_point(qb + NW, i2);
+                pre = gn8_preload(c, i2, v2, it == 0);
+            }
         }
+        // the next iteration's first chunk: positions and answer rows as this iteration leaves them (the searches above have
+        // written theirs), requested now - they arrive while the sums are exchanged and the system is solved
+        { int i0; const bool v0 = chunk_point(0, i0); pre = gn8_preload(c, i0, v0, false); }
         const long long c1 = GN_CLK();
         // ---- workgroup reduction, fixed tree: the 64 lanes of a wavefront (DPP inside the rows, two crossbar steps across
         // them), then the wavefronts in order
