@@ -2176,93 +2176,160 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) void k_gn_loop8(Ctx c, int mode) {
 // ------------------------------------------------------------------------------------------------ K7-K9
 // AddPoints, phase a: world transform, find-or-create the voxel's table entry, join its batch list.
 // `pose` null => points are already in the world frame (stage-level API)
+// (U points per thread as in K1-K4: the first table read of each, then the compare-and-swaps, then the list pushes travel together)
+template <int U>
 __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_in, const int* n_ptr, int n_fixed,
                                                       int use_pose, const Slice sl) {
     const int n = n_ptr ? *n_ptr : n_fixed;
-    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
-    if (i >= n) return;
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     DevState* st = c.st;
-    V3 p = v3(pts_in[3 * (size_t)i], pts_in[3 * (size_t)i + 1], pts_in[3 * (size_t)i + 2]);
-    if (use_pose) p = rt_apply(rt_from16(st->new_pose), p);
-    c.fdw[3 * (size_t)i] = p.x; c.fdw[3 * (size_t)i + 1] = p.y; c.fdw[3 * (size_t)i + 2] = p.z;
-    unsigned long long key; int kx, ky, kz;
-    int slot = -1;
-    if (!vox_key(p, c.vs, key, kx, ky, kz)) {
-        atomicOr(&st->err_flags, ERR_KEY_RANGE);
-    } else {
-        unsigned s = (unsigned)mix64(key) & c.tmask;
-        for (unsigned probe = 0; probe <= c.tmask; ++probe) {
-            unsigned long long cur = c.tab[s].key;  // plain read, as in vds_claim: EMPTY -> key is the only change in this kernel
-            if (cur == key) { slot = (int)s; break; }
-            if (cur == EMPTY_KEY) {
-                const unsigned long long old = atomicCAS(&c.tab[s].key, EMPTY_KEY, key);
-                if (old == EMPTY_KEY) {  // created: take a block from the pool
-                    slot = (int)s;
-                    const int top = atomicSub(&st->free_top, 1) - 1;
-                    int b = -1;
-                    if (top >= 0) {
-                        b = c.free_stack[top];
-                        int* h = blk_hdr(c, b);
-                        h[0] = 0;
-                        h[1] = slot;
-                        atomicAdd(&st->n_live, 1);
-                        atomicMax(&st->pool_hw, b + 1);
-                    } else {
-                        atomicOr(&st->err_flags, ERR_POOL);
-                    }
-                    c.tab[s].blk = b;
-                    const unsigned used = atomicAdd(&st->tab_used, 1u) + 1u;
-                    if (used > (c.tmask + 1u) / 4u * 3u) atomicOr(&st->err_flags, ERR_TABLE);
-                    break;
-                }
-                if (old == key) { slot = (int)s; break; }
-            }
-            s = (s + 1) & c.tmask;
-        }
-        if (slot < 0) atomicOr(&st->err_flags, ERR_TABLE);
+    int idx[U], slot[U];
+    bool act[U], keyed[U];
+    unsigned long long key[U], cur[U], old[U];
+    unsigned s0[U];
+    V3 p[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        idx[u] = base + u * BS; act[u] = idx[u] < n;
+        p[u] = v3(0.0, 0.0, 0.0);
+        if (act[u]) { const size_t i = (size_t)idx[u]; p[u] = v3(pts_in[3 * i], pts_in[3 * i + 1], pts_in[3 * i + 2]); }
     }
-    c.pslot[i] = slot;
-    c.nxt[i] = (slot >= 0) ? atomicExch(&c.tab[slot].head, i) : -1;
+    Rt T = rt_identity();
+    if (use_pose) T = rt_from16(st->new_pose);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        slot[u] = -1; keyed[u] = false; key[u] = EMPTY_KEY; s0[u] = 0u; cur[u] = 0ull;
+        if (!act[u]) continue;
+        const size_t i = (size_t)idx[u];
+        if (use_pose) p[u] = rt_apply(T, p[u]);
+        c.fdw[3 * i] = p[u].x; c.fdw[3 * i + 1] = p[u].y; c.fdw[3 * i + 2] = p[u].z;
+        int kx, ky, kz;
+        keyed[u] = vox_key(p[u], c.vs, key[u], kx, ky, kz);
+        if (!keyed[u]) { atomicOr(&st->err_flags, ERR_KEY_RANGE); continue; }
+        s0[u] = (unsigned)mix64(key[u]) & c.tmask;
+        cur[u] = c.tab[s0[u]].key;  // plain read, as in vds_claim: EMPTY -> key is the only change in this kernel
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        old[u] = key[u];
+        if (keyed[u] && cur[u] == EMPTY_KEY) old[u] = atomicCAS(&c.tab[s0[u]].key, EMPTY_KEY, key[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!keyed[u]) continue;
+        unsigned s = s0[u];
+        bool created = false;
+        if (cur[u] == key[u] || (cur[u] == EMPTY_KEY && old[u] == key[u])) slot[u] = (int)s;
+        else if (cur[u] == EMPTY_KEY && old[u] == EMPTY_KEY) { slot[u] = (int)s; created = true; }
+        else {  // occupied by another voxel or a tombstone (or the swap lost to another key): linear probing goes on
+            s = (s + 1) & c.tmask;
+            for (unsigned probe = 1; probe <= c.tmask; ++probe) {
+                const unsigned long long ck = c.tab[s].key;
+                if (ck == key[u]) { slot[u] = (int)s; break; }
+                if (ck == EMPTY_KEY) {
+                    const unsigned long long o = atomicCAS(&c.tab[s].key, EMPTY_KEY, key[u]);
+                    if (o == EMPTY_KEY) { slot[u] = (int)s; created = true; break; }
+                    if (o == key[u]) { slot[u] = (int)s; break; }
+                }
+                s = (s + 1) & c.tmask;
+            }
+        }
+        if (created) {  // take a block from the pool
+            const int top = atomicSub(&st->free_top, 1) - 1;
+            int b = -1;
+            if (top >= 0) {
+                b = c.free_stack[top];
+                int* h = blk_hdr(c, b);
+                h[0] = 0;
+                h[1] = slot[u];
+                atomicAdd(&st->n_live, 1);
+                atomicMax(&st->pool_hw, b + 1);
+            } else {
+                atomicOr(&st->err_flags, ERR_POOL);
+            }
+            c.tab[s].blk = b;
+            const unsigned used = atomicAdd(&st->tab_used, 1u) + 1u;
+            if (used > (c.tmask + 1u) / 4u * 3u) atomicOr(&st->err_flags, ERR_TABLE);
+        }
+        if (slot[u] < 0) atomicOr(&st->err_flags, ERR_TABLE);
+    }
+    int nx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) nx[u] = (slot[u] >= 0) ? atomicExch(&c.tab[slot[u]].head, idx[u]) : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (act[u]) { c.pslot[idx[u]] = slot[u]; c.nxt[idx[u]] = nx[u]; }
 }
 // phase b: rank among this batch's points of the same voxel (by scan order) -> slot in the block
+template <int U>
 __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, int n_fixed, const Slice sl) {
     const int n = n_ptr ? *n_ptr : n_fixed;
-    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
-    if (i >= n) return;
-    const int slot = c.pslot[i];
-    if (slot < 0) { c.prank[i] = -1; return; }
-    int rank = 0, len = 0;
-    for (int j = c.tab[slot].head; j >= 0; j = c.nxt[j]) { ++len; rank += (j < i) ? 1 : 0; }
-    c.prank[i] = rank;
-    c.plen[i] = len;
-    const int pb = c.tab[slot].blk;
-    if (pb < 0) return;
-    const int b = pb & BLK_ID_MASK;
-    const int cnt = blk_hdr(c, b)[0];
-    const int pos = cnt + rank;
-    if (pos < c.P) {
-        double* X = blk_x(c, b);
-        X[pos] = c.fdw[3 * (size_t)i]; X[c.P + pos] = c.fdw[3 * (size_t)i + 1]; X[2 * c.P + pos] = c.fdw[3 * (size_t)i + 2];
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
+    int idx[U], slot[U], j[U], rank[U], len[U], pb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; slot[u] = (idx[u] < n) ? c.pslot[idx[u]] : -1; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        rank[u] = 0; len[u] = 0; j[u] = -1; pb[u] = -1;
+        if (slot[u] >= 0) { const TabEnt e = c.tab[slot[u]]; j[u] = e.head; pb[u] = e.blk; }
+    }
+    for (;;) {  // the U list walks step together: their reads of nxt[] are in flight at the same time
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) any = any || j[u] >= 0;
+        if (!any) break;
+        int nx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) nx[u] = (j[u] >= 0) ? c.nxt[j[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (j[u] >= 0) { ++len[u]; rank[u] += (j[u] < idx[u]) ? 1 : 0; j[u] = nx[u]; }
+    }
+    int cnt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cnt[u] = (slot[u] >= 0 && pb[u] >= 0) ? blk_hdr(c, pb[u] & BLK_ID_MASK)[0] : 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (idx[u] >= n) continue;
+        const size_t i = (size_t)idx[u];
+        if (slot[u] < 0) { c.prank[i] = -1; continue; }
+        c.prank[i] = rank[u];
+        c.plen[i] = len[u];
+        if (pb[u] < 0) continue;
+        const int pos = cnt[u] + rank[u];
+        if (pos < c.P) {
+            double* X = blk_x(c, pb[u] & BLK_ID_MASK);
+            X[pos] = c.fdw[3 * i]; X[c.P + pos] = c.fdw[3 * i + 1]; X[2 * c.P + pos] = c.fdw[3 * i + 2];
+        }
     }
 }
 // phase c: publish the new counts, reset the batch lists
+template <int U>
 __device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, int n_fixed, const Slice sl) {
     const int n = n_ptr ? *n_ptr : n_fixed;
-    const int i = sl.b * (int)blockDim.x + (int)threadIdx.x;
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
+    int idx[U], slot[U], pb[U], pl[U], cnt[U];
+    bool first[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; first[u] = idx[u] < n && c.prank[idx[u]] == 0; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { slot[u] = first[u] ? c.pslot[idx[u]] : -1; pl[u] = first[u] ? c.plen[idx[u]] : 0; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) pb[u] = first[u] ? c.tab[slot[u]].blk : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) cnt[u] = (pb[u] >= 0) ? blk_hdr(c, pb[u] & BLK_ID_MASK)[0] : 0;
     int added = 0;
-    if (i < n && c.prank[i] == 0) {
-        const int slot = c.pslot[i];
-        const int pb = c.tab[slot].blk;
-        c.tab[slot].head = -1;
-        if (pb >= 0) {
-            const int b = pb & BLK_ID_MASK;
-            int* h = blk_hdr(c, b);
-            const int cnt = h[0];
-            int nc = cnt + c.plen[i];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!first[u]) continue;
+        c.tab[slot[u]].head = -1;
+        if (pb[u] >= 0) {
+            const int b = pb[u] & BLK_ID_MASK;
+            int nc = cnt[u] + pl[u];
             if (nc > c.P) nc = c.P;
-            h[0] = nc;
-            c.tab[slot].blk = b | (nc << 24);  // the table entry mirrors the count so a probe returns both
-            added = nc - cnt;
+            blk_hdr(c, b)[0] = nc;
+            c.tab[slot[u]].blk = b | (nc << 24);  // the table entry mirrors the count so a probe returns both
+            added += nc - cnt[u];
         }
     }
     // one atomic per wavefront: tens of thousands of same-address atomics serialise at the memory side (225 us for 8
@@ -2273,26 +2340,41 @@ __device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, i
 
 // ------------------------------------------------------------------------------------------------ K10
 // RemovePointsFarFromLocation: a voxel goes when its FIRST point is farther than max_range from the origin
+template <int U>
 __device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_xyz, int use_new_pose, const Slice sl) {
-    const int b = sl.b * (int)blockDim.x + (int)threadIdx.x;
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     DevState* st = c.st;
-    if (b >= st->pool_hw) return;  // block ids are handed out low-first: nothing lives above the high-water mark
-    int* h = blk_hdr(c, b);
-    const int cnt = h[0];
-    if (cnt <= 0) return;
+    const int hw = st->pool_hw;  // block ids are handed out low-first: nothing lives above the high-water mark
     double ox, oy, oz;
     if (use_new_pose) { ox = st->new_pose[3]; oy = st->new_pose[7]; oz = st->new_pose[11]; }
     else { ox = origin_xyz[0]; oy = origin_xyz[1]; oz = origin_xyz[2]; }
-    const double* X = blk_x(c, b);
-    const double dx = X[0] - ox, dy = X[c.P] - oy, dz = X[2 * c.P] - oz;
-    if (dx * dx + dy * dy + dz * dz > c.max_range * c.max_range) {
-        c.tab[h[1]].key = TOMB_KEY;
-        c.tab[h[1]].blk = -1;
-        h[0] = 0;
-        const int top = atomicAdd(&st->free_top, 1);
-        c.free_stack[top] = b;
-        atomicSub(&st->n_live, 1);
-        atomicAdd((unsigned long long*)&st->map_points, (unsigned long long)(-(long long)cnt));
+    int cnt[U], hs[U];
+    double x0[U], y0[U], z0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int b = base + u * BS;
+        cnt[u] = 0; hs[u] = -1; x0[u] = y0[u] = z0[u] = 0.0;
+        if (b < hw) {
+            const int* h = blk_hdr(c, b);
+            cnt[u] = h[0]; hs[u] = h[1];
+            const double* X = blk_x(c, b);
+            x0[u] = X[0]; y0[u] = X[c.P]; z0[u] = X[2 * c.P];  // (read whether or not the block is live: no dependent round trip)
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (cnt[u] <= 0) continue;
+        const int b = base + u * BS;
+        const double dx = x0[u] - ox, dy = y0[u] - oy, dz = z0[u] - oz;
+        if (dx * dx + dy * dy + dz * dz > c.max_range * c.max_range) {
+            c.tab[hs[u]].key = TOMB_KEY;
+            c.tab[hs[u]].blk = -1;
+            blk_hdr(c, b)[0] = 0;
+            const int top = atomicAdd(&st->free_top, 1);
+            c.free_stack[top] = b;
+            atomicSub(&st->n_live, 1);
+            atomicAdd((unsigned long long*)&st->map_points, (unsigned long long)(-(long long)cnt[u]));
+        }
     }
 }
 
@@ -2441,25 +2523,25 @@ __global__ __launch_bounds__(256) void kb_compact_src(const SeqCtx* a, int scan_
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
     d_compact_src<1>(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_in, const int* n_ptr, int n_fixed, int use_pose) { d_map_insert_a(c, pts_in, n_ptr, n_fixed, use_pose, launch_slice()); }
+__global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_in, const int* n_ptr, int n_fixed, int use_pose) { d_map_insert_a<1>(c, pts_in, n_ptr, n_fixed, use_pose, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_insert_a(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_insert_a(c, c.fd, &c.st->n_down_ins, 0, 1, launch_slice());
+    d_map_insert_a<1>(c, c.fd, &c.st->n_down_ins, 0, 1, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_map_insert_b(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_b(c, n_ptr, n_fixed, launch_slice()); }
+__global__ __launch_bounds__(256) void k_map_insert_b(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_b<1>(c, n_ptr, n_fixed, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_insert_b(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_insert_b(c, &c.st->n_down_ins, 0, launch_slice());
+    d_map_insert_b<1>(c, &c.st->n_down_ins, 0, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_map_insert_c(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_c(c, n_ptr, n_fixed, launch_slice()); }
+__global__ __launch_bounds__(256) void k_map_insert_c(Ctx c, const int* n_ptr, int n_fixed) { d_map_insert_c<1>(c, n_ptr, n_fixed, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_insert_c(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_insert_c(c, &c.st->n_down_ins, 0, launch_slice());
+    d_map_insert_c<1>(c, &c.st->n_down_ins, 0, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_xyz, int use_new_pose) { d_map_prune(c, origin_xyz, use_new_pose, launch_slice()); }
+__global__ __launch_bounds__(256) void k_map_prune(Ctx c, const double* origin_xyz, int use_new_pose) { d_map_prune<1>(c, origin_xyz, use_new_pose, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_prune(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_map_prune(c, nullptr, 1, launch_slice());
+    d_map_prune<1>(c, nullptr, 1, launch_slice());
 }
 __global__ __launch_bounds__(256) void k_map_rebuild(Ctx c) { d_map_rebuild(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_rebuild(const SeqCtx* a, int scan_k) {

@@ -102,26 +102,28 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
 __device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, int rebuild, unsigned* word) {
     const Ctx c = load_seq_ctx(a, s, k);
     DevState* st = c.st;
-    const int BS = (int)blockDim.x, nbd = (st->n_down_ins + BS - 1) / BS;
+    const int BS = (int)blockDim.x, BU = BS * SEQ_U, nbd = (st->n_down_ins + BU - 1) / BU;
     Slice sl;
     sl.nb = nbd;
     SQ_CLK_DECL;
-    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_a(c, c.fd, &st->n_down_ins, 0, 1, sl);
+    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_a<SEQ_U>(c, c.fd, &st->n_down_ins, 0, 1, sl);
     SQ_CLK(10);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
     SQ_CLK(11);
-    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_b(c, &st->n_down_ins, 0, sl);
+    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_b<SEQ_U>(c, &st->n_down_ins, 0, sl);
     SQ_CLK(12);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
     SQ_CLK(13);
-    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_c(c, &st->n_down_ins, 0, sl);
+    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_c<SEQ_U>(c, &st->n_down_ins, 0, sl);
     SQ_CLK(14);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
     SQ_CLK(15);
+    const int nbpu = (st->pool_hw + BU - 1) / BU;
+    sl.nb = nbpu;
+    for (sl.b = wg; sl.b < nbpu; sl.b += nw) d_map_prune<SEQ_U>(c, nullptr, 1, sl);
+    SQ_CLK(16);
     const int nbp = (st->pool_hw + BS - 1) / BS;
     sl.nb = nbp;
-    for (sl.b = wg; sl.b < nbp; sl.b += nw) d_map_prune(c, nullptr, 1, sl);
-    SQ_CLK(16);
     if (rebuild) {  // drop the tombstones: empty table, re-enter the live voxels
         if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
         unsigned long long* tw = (unsigned long long*)c.tab;
