@@ -101,6 +101,30 @@ def test_free_running_kernel_leaves_when_a_workgroup_never_arrives():
     assert all(st["iterations"] > 0 for st in b.results(0)["stats"][1:n])  # sequence 0 went through all four scans (the first one meets an empty map)
 
 
+def test_free_running_equals_lockstep_over_a_longer_run():
+    """24 sequences (three per XCD on its four teams: the scheduler hands sequences from team to team all the time), 60
+    sweeps in launches of 25: every pose, every filter output and every per-scan counter equal to the lockstep run's"""
+    S, n = 24, 60
+    seqs = [synth.make_sequence(seed=1100 + s, n_scans=n) for s in range(S)]
+    n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
+    outs = {}
+    for free in (True, False):
+        b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=True, with_ekf=True, free_running=free,
+                             scans_per_launch=25 if free else 0, gn_workgroups=256)
+        for s, sq in enumerate(seqs):
+            for k in range(n):
+                b.upload_scan(s, k, sq.scan(k))
+            b.upload_imu(s, sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
+        b.run()
+        outs[free] = [b.results(s) for s in range(S)]
+        b.close()
+    for s in range(S):
+        a, c = outs[True][s], outs[False][s]
+        assert np.array_equal(a["kiss_poses"], c["kiss_poses"]) and np.array_equal(a["res_poses"], c["res_poses"]), s
+        assert np.array_equal(a["res_t"], c["res_t"]) and a["stats"] == c["stats"], s
+    # (lockstep with 24 sequences runs four per XCD on 8 workgroups each - the team size of the free-running run)
+
+
 def test_lockstep_serves_at_most_32_sequences():
     b = core.BatchRunner(33, 2, 1024, 2, with_ekf=True, max_points_per_scan=1024, scan_cols=64, free_running=False)
     for s in range(33):
