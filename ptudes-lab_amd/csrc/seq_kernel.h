@@ -4,8 +4,8 @@
 // The lockstep driver (ptl_batch_enqueue, one launch per stage for all sequences) makes every step wait for the
 // sequence whose Gauss-Newton loop takes longest: over 16 sequences the slowest loop of a step runs 1.8 x the mean
 // number of iterations (tools/lockstep.py), and the workgroups of the other sequences idle meanwhile.  Here the
-// workgroups of one sequence (its share of one XCD, kx_assign) form a TEAM that walks the whole per-scan pipeline by
-// itself - reference cli/ekf_bench.py:493-563 loop body = kiss.py:83-131 + ESEKF.processPose / processImu:
+// workgroups of an XCD form TEAMS (1, 2 or 4 of 32, 16 or 8 workgroups), and a team walks the whole per-scan pipeline of
+// one sequence by itself - reference cli/ekf_bench.py:493-563 loop body = kiss.py:83-131 + ESEKF.processPose / processImu:
 //
 //     team \ {filter wg}:  K0 prologue | K1 deskew + vds1 | K2 vds2 | K3 compact fd | K4 compact src
 //     whole team:          --- barrier ---  K5 Gauss-Newton loop (gn8_body)  --- barrier ---
