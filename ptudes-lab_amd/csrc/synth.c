@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef struct {
     int32_t H, W;
@@ -56,9 +57,10 @@ static double vnoise(double x, double y, double z) {
     return c;
 }
 
-/* distance along unit ray (o, d) to the first surface; the origin is inside the room */
+/* distance along unit ray (o, d) to the first surface; the origin is inside the room.
+ * cand (nullable): the objects this ray can meet at all - cand[0] boxes' indices from cand + 2, then cand[1] cylinders' */
 static double cast(const double o[3], const double d[3], const double room[6], const double *boxes, int nb,
-                   const double *cyls, int nc) {
+                   const double *cyls, int nc, const int16_t *cand) {
     double best = 1e300;
     /* room: exit distance of the AABB [x0,x1]x[y0,y1]x[z0,z1] */
     for (int a = 0; a < 3; ++a) {
@@ -71,7 +73,9 @@ static double cast(const double o[3], const double d[3], const double room[6], c
         }
     }
     /* boxes: (cx, cy, cz, hx, hy, hz), slab test, entry point */
-    for (int b = 0; b < nb; ++b) {
+    const int nbc = cand ? cand[0] : nb, ncc = cand ? cand[1] : nc;
+    for (int bi = 0; bi < nbc; ++bi) {
+        const int b = cand ? cand[2 + bi] : bi;
         const double *B = boxes + 6 * b;
         double tn = -1e300, tf = 1e300;
         int miss = 0;
@@ -90,7 +94,8 @@ static double cast(const double o[3], const double d[3], const double room[6], c
         if (!miss && tn > 1e-6 && tn < best) best = tn;
     }
     /* vertical cylinders: (cx, cy, r, h) standing on z = room z0 */
-    for (int c = 0; c < nc; ++c) {
+    for (int ci = 0; ci < ncc; ++ci) {
+        const int c = cand ? cand[2 + nbc + ci] : ci;
         const double *Cy = cyls + 4 * c;
         double ox = o[0] - Cy[0], oy = o[1] - Cy[1], r = Cy[2], z0 = room[4], z1 = room[4] + Cy[3];
         double A = d[0] * d[0] + d[1] * d[1];
@@ -128,6 +133,47 @@ void ptl_synth_render(const double room[6], const double *boxes, int32_t nb, con
     const int H = s->H, W = s->W;
     const double deg = M_PI / 180.0;
     const int nthr = (H * W < 8192) ? 1 : (synth_threads < H ? synth_threads : H);
+    /* All rays of a column leave one origin inside one half-plane (spanned by the column's azimuth direction and the sensor's
+     * up axis), so an object whose bounding sphere does not reach that half-plane cannot be hit by any of them: per column,
+     * the few objects that can (3-6 of 60) are listed once and the H rays of the column test only those.  A culled object
+     * would have reported a miss, so the sweep is bit-identical to the full test.  (Not with per-ray angular jitter.) */
+    const int stride = 2 + nb + nc;
+    int16_t *cands = NULL;
+    double *caz = NULL;
+    if (s->ray_jitter_deg <= 0.0 && nb + nc > 0 && nb + nc < 32000) {
+        cands = (int16_t *)malloc((size_t)W * stride * sizeof(int16_t));
+        caz = (double *)malloc((size_t)W * 2 * sizeof(double));
+    }
+    if (cands && caz) {
+        for (int col = 0; col < W; ++col) {
+            const double az = 2.0 * M_PI * (double)col / (double)W;
+            const double ca = cos(az), sa = sin(az);
+            caz[2 * col] = ca; caz[2 * col + 1] = sa;
+            const double *P = col_poses + 12 * col;
+            /* world-frame forward direction and normal of the column's half-plane */
+            const double f[3] = {P[0] * ca + P[1] * sa, P[3] * ca + P[4] * sa, P[6] * ca + P[7] * sa};
+            const double nn[3] = {-P[0] * sa + P[1] * ca, -P[3] * sa + P[4] * ca, -P[6] * sa + P[7] * ca};
+            int16_t *cd = cands + (size_t)col * stride;
+            int kb = 0, kc = 0;
+            for (int b = 0; b < nb; ++b) {
+                const double *B = boxes + 6 * b;
+                const double rad = sqrt(B[3] * B[3] + B[4] * B[4] + B[5] * B[5]) * (1.0 + 1e-9) + 1e-6;
+                const double dx = B[0] - P[9], dy = B[1] - P[10], dz = B[2] - P[11];
+                if (fabs(nn[0] * dx + nn[1] * dy + nn[2] * dz) <= rad && f[0] * dx + f[1] * dy + f[2] * dz >= -rad) cd[2 + kb++] = (int16_t)b;
+            }
+            for (int c = 0; c < nc; ++c) {
+                const double *Cy = cyls + 4 * c;
+                const double hh = 0.5 * Cy[3];
+                const double rad = sqrt(Cy[2] * Cy[2] + hh * hh) * (1.0 + 1e-9) + 1e-6;
+                const double dx = Cy[0] - P[9], dy = Cy[1] - P[10], dz = room[4] + hh - P[11];
+                if (fabs(nn[0] * dx + nn[1] * dy + nn[2] * dz) <= rad && f[0] * dx + f[1] * dy + f[2] * dz >= -rad) cd[2 + kb + kc++] = (int16_t)c;
+            }
+            cd[0] = (int16_t)kb; cd[1] = (int16_t)kc;
+        }
+    } else {
+        free(cands); free(caz);
+        cands = NULL; caz = NULL;
+    }
 #pragma omp parallel for schedule(static) num_threads(nthr)
     for (int row = 0; row < H; ++row) {
         double el = (H > 1) ? s->el_top_deg + (s->el_bot_deg - s->el_top_deg) * (double)row / (double)(H - 1)
@@ -142,12 +188,13 @@ void ptl_synth_render(const double room[6], const double *boxes, int32_t nb, con
                 az += ja;
                 cej = cos(el * deg + je); sej = sin(el * deg + je);
             }
-            double db[3] = {cej * cos(az), cej * sin(az), sej};
+            const double caz_c = caz ? caz[2 * col] : cos(az), saz_c = caz ? caz[2 * col + 1] : sin(az);
+            double db[3] = {cej * caz_c, cej * saz_c, sej};
             const double *P = col_poses + 12 * col;
             double dw[3] = {P[0] * db[0] + P[1] * db[1] + P[2] * db[2],
                             P[3] * db[0] + P[4] * db[1] + P[5] * db[2],
                             P[6] * db[0] + P[7] * db[1] + P[8] * db[2]};
-            double r = cast(P + 9, dw, room, boxes, nb, cyls, nc);
+            double r = cast(P + 9, dw, room, boxes, nb, cyls, nc, cands ? cands + (size_t)col * stride : NULL);
             if (s->rough_amp > 0.0) {
                 double q = 1.0 / s->rough_len;
                 double hx = (P[9] + r * dw[0]) * q, hy = (P[10] + r * dw[1]) * q, hz = (P[11] + r * dw[2]) * q;
@@ -171,6 +218,8 @@ void ptl_synth_render(const double room[6], const double *boxes, int32_t nb, con
             }
         }
     }
+    free(cands);
+    free(caz);
 }
 
 /* ------------------------------------------------------------------------------------------------
