@@ -1669,6 +1669,16 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
     const bool win2 = has2 && od == m2 && oo == o2;
     const double rest = (win || win2) ? ((win && win2) ? sd : b2d) : bd;
     const double D2 = group_minL<LP>(fmin(rest, gdrop));
+#ifdef GN_PHASE_CLOCKS
+    {   // what bounds everybody else: a candidate that was scanned (the third nearest) or the box of a dropped voxel?
+        const double Dc = group_minL<LP>(rest), Dg = group_minL<LP>(gdrop);
+        if (laneL == 0 && found) {
+            atomicAdd((unsigned long long*)&c.wg_clk[44 + (Dc <= Dg ? 0 : 1)], 1ull);
+            const double q = sqrt(D2 / m);  // bound / distance of the winner: [1,1.2) [1.2,1.5) [1.5,2) [2,3) [3,..)
+            atomicAdd((unsigned long long*)&c.wg_clk[46 + (q < 1.2 ? 0 : q < 1.5 ? 1 : q < 2.0 ? 2 : q < 3.0 ? 3 : 4)], 1ull);
+        }
+    }
+#endif
     double sl2 = -1.0;
     if (found && D2 < 1.0e300) sl2 = sqrt(D2) * (1.0 - 1e-6) - 1e-9;  // (a little less is stored: the margin of the test)
     else if (found) sl2 = 1.0e300;  // nobody else in reach of this voxel

@@ -26,6 +26,9 @@ try:
     print("misses per workgroup per iter:", np.round(w[G:2 * G] / it, 1).tolist())
     if w[40] > 0:
         print("searches (all workgroups of sequence 0): %.0f per scan, survivor rounds per search %.2f, row rebuilt (voxel changed / first iteration) %.1f %%" % (w[40] / n, w[41] / w[40], 100 * w[42] / w[40]))
+    if w[44] + w[45] > 0:
+        print("bound of the others after a search: third-nearest candidate %.1f %%, box of a dropped voxel %.1f %%;  bound / winner's distance in [1,1.2) [1.2,1.5) [1.5,2) [2,3) [3,..): %s %%"
+              % (100 * w[44] / (w[44] + w[45]), 100 * w[45] / (w[44] + w[45]), np.round(100 * w[46:51] / max(w[46:51].sum(), 1), 1).tolist()))
 except Exception as e:
     print("no per-wg clocks:", e)
 
