@@ -7,7 +7,7 @@
 // workgroups of an XCD form TEAMS (1, 2 or 4 of 32, 16 or 8 workgroups), and a team walks the whole per-scan pipeline of
 // one sequence by itself - reference cli/ekf_bench.py:493-563 loop body = kiss.py:83-131 + ESEKF.processPose / processImu:
 //
-//     team \ {filter wg}:  K0 prologue | K1 deskew + vds1 | K2 vds2 | K3 compact fd | K4 compact src
+//     whole team:          K0 prologue | K1 deskew + vds1 | K2 vds2 | K3 compact fd | K4 compact src
 //     whole team:          --- barrier ---  K5 Gauss-Newton loop (gn8_body)  --- barrier ---
 //     filter wg:           ES-EKF: update with the scan's pose, predict through the IMU samples before the next scan
 //     team \ {filter wg}:  K7-K9 map insert a | b | c | K10 prune [| table reset | K11 rebuild]
@@ -199,9 +199,8 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, S
     if (x >= r.S || (t + 1) * G > J) return;  // no sequence on this XCD / a workgroup beyond the last whole team
     unsigned* tb = bar + (size_t)(x + 8 * t) * 64;
     SeqSched* sc = sched + x;
-    // with a filter, the team's last workgroup is the filter workgroup: it only joins the barriers around the
-    // Gauss-Newton loop and at the end of the scan, steps the filter after the loop and is back, waiting, long before the
-    // others have updated the map
+    // with a filter, the team's last workgroup is the filter workgroup: after the Gauss-Newton loop it steps the filter
+    // while the others update the map (and is back, waiting, long before they are done); K0-K4 are everybody's
     const bool fwg = r.with_ekf && wg == G - 1;
     const int nw = r.with_ekf ? G - 1 : G;
     unsigned t_all = 0u, t_work = 0u;
@@ -224,10 +223,8 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, S
         const SeqCtx* my = a + s;
         st = my->c.st;
         const long long c0 = (long long)wall_clock64();
-        if (!fwg) {
-            t_work = sq_prepare(a, s, k, wg, nw, t_work, tb + 32);
-            if (t_work == SEQ_FAIL) return;
-        }
+        t_all = sq_prepare(a, s, k, wg, G, t_all, tb);  // (all G workgroups: the filter workgroup has nothing else to do here)
+        if (t_all == SEQ_FAIL) return;
         const long long c1 = (long long)wall_clock64();
         if (!team_sync(tb, (unsigned)G, t_all, st)) return;  // source ready (map and filter: complete since the scan before)
         const long long c2 = (long long)wall_clock64();
