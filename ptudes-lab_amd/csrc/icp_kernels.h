@@ -73,6 +73,7 @@ struct DevState {
     long long n_samples;
     double model_dev[16];
     int prev_n_in, pending_finish;
+    int pro_next;       // free-running kernel: 1 + the scan whose prologue (K0) has already been run by the filter workgroup beside the previous scan's map update, 0 = none
     int n_src_last;     // n_src of the last registered scan (n_src itself belongs to the next scan's K0-K4 already)
     int n_down_ins;     // frame_down points of the scan whose map update is in flight (n_down belongs to the next scan's K3 already)
     int stats_pending;  // scan whose map_voxels / map_points are still to be recorded once its map update is complete, or -1

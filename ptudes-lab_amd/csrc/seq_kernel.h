@@ -78,7 +78,7 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     Slice sl;
     sl.nb = nbs;
     SQ_CLK_DECL;
-    if (wg == 0) d_scan_prologue(c);
+    if (wg == 0 && st->pro_next != k + 1) d_scan_prologue(c);  // (with a filter it has usually been run already: sq_filter)
     SQ_CLK(0);
     if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
     SQ_CLK(1);
@@ -141,10 +141,20 @@ __device__ __noinline__ void sq_gauss_newton(const SeqCtx* a, int s, int k, int 
     gn8_body<PC, GC>(c, 0, G, wg);
 }
 // the filter step that follows scan k: update with its pose, predict through the IMU samples before scan k + 1
-__device__ __noinline__ void sq_filter(const SeqCtx* my, int k) {
+// ... and, while the others are still updating the map, K0 of scan k + 1: it needs the new pose only (the lockstep driver
+// runs it beside the map update too), and whichever team takes scan k + 1 finds it done
+__device__ __noinline__ void sq_filter(const SeqCtx* a, int s, int k) {
+    const SeqCtx* my = a + s;
     const int i0 = my->imu_end[k], i1 = (k + 1 < my->n_scans) ? my->imu_end[k + 1] : i0;
     d_ekf_step(my->ekf, my->imu, i0, i1, my->c.traj + 16 * (size_t)k, nullptr, my->res_poses + 16 * (size_t)k,
                my->res_t + k, my->rows + 8 * (size_t)k, 1);
+    if (k + 1 < my->n_scans) {
+        __syncthreads();
+        const Ctx c = load_seq_ctx(a, s, k + 1);
+        d_scan_prologue(c);
+        __syncthreads();
+        if (threadIdx.x == 0) c.st->pro_next = k + 2;
+    }
 }
 
 struct SeqRun { int S, k0, k1, with_ekf, rebuild_every; };
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, S
         if (!team_sync(tb, (unsigned)G, t_all, st)) return;  // new pose, trajectory row
         const long long c4 = (long long)wall_clock64();
         if (fwg) {
-            sq_filter(my, k);
+            sq_filter(a, s, k);
         } else {
             t_work = sq_map_update(a, s, k, wg, nw, t_work, (r.rebuild_every > 0 && ((k + 1) % r.rebuild_every) == 0) ? 1 : 0, tb + 32);
             if (t_work == SEQ_FAIL) return;
