@@ -200,7 +200,7 @@ def main():
                     help="independent sequences per GPU (SURVEY.md 8(e), second level), batched runner.  The sequences s = x (mod 8) "
                          "live on XCD x; up to 8 / 16 sequences: one / two teams of workgroups per XCD, one sequence each; more "
                          "(default 48, up to 64): four teams per XCD that take the sequences' scans as they come free, so the "
-                         "sequences advance evenly (6.0k / 9.7k / 13.0k / 14.5k scans/s for 8 / 16 / 32 / 48).  One Gauss-Newton "
+                         "sequences advance evenly (6.0k / 9.9k / 13.0k / 14.8k scans/s for 8 / 16 / 32 / 48).  One Gauss-Newton "
                          "loop alone leaves an XCD latency-bound, more of them fill the gaps.  1 = the single-sequence latency "
                          "pipeline (one sequence over the whole chip)")
     ap.add_argument("--seed-base", type=int, default=1000, help="sequence s of SURVEY.md 8(d) uses seed seed_base + s")
