@@ -88,3 +88,28 @@ def test_controlled_drive_is_what_it_says():
     assert x.shape == (128 * 1024, 3) and (np.linalg.norm(x, axis=1) > 0).mean() > 0.5
     # the lane around the path is clear of obstacles
     assert np.all(np.abs(seq.boxes[:, 1]) - seq.boxes[:, 4] > 3.9) and np.all(np.abs(seq.cyls[:, 1]) - seq.cyls[:, 2] > 3.9)
+
+
+def test_pmc_summary_takes_the_timed_launches_of_the_dominant_kernel(tmp_path):
+    """tools/pmc_summary.py: the free-running kernel has a warm-up launch and the timed one - the per-launch traffic is the
+    timed launch's (the last `roofline.launches` dispatches), fetch side doubled (gfx950), write side as reported"""
+    import subprocess
+    import sys
+    line = {"value": 1.0, "steps": 200, "config": {"workload_key": "K"}, "roofline": {"kernel": "kx_seq_run", "launches": 1}}
+    (tmp_path / "line.json").write_text("some library noise\n" + json.dumps(line) + "\n")
+    for name, vals in (("FETCH_SIZE", (10.0, 100.0)), ("WRITE_SIZE", (4.0, 40.0))):
+        d = tmp_path / name / "x"
+        d.mkdir(parents=True)
+        rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+        rows.append(f'1,"void k_other(int)",{name},7.0')
+        # two rows per dispatch (a counter reported per dimension): summed; dispatch 2 = warm-up, 5 = timed
+        rows += [f'2,"void kx_seq_run<20, 8>(SeqCtx const*, SeqRun)",{name},{vals[0] / 2}'] * 2
+        rows += [f'5,"void kx_seq_run<20, 8>(SeqCtx const*, SeqRun)",{name},{vals[1] / 2}'] * 2
+        (d / "f_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    out = tmp_path / "out.json"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), str(out), str(tmp_path / "line.json"),
+                    f"FETCH_SIZE={tmp_path / 'FETCH_SIZE'}", f"WRITE_SIZE={tmp_path / 'WRITE_SIZE'}"], check=True, capture_output=True)
+    r = json.load(open(out))
+    assert r["workload_key"] == "K" and r["dominant_kernel"] == "kx_seq_run"
+    assert r["FETCH_SIZE_timed"] == {"launches": 1, "mean_per_launch_KB": 100.0}
+    assert r["traffic_bytes_per_launch"] == 2 * 100.0 * 1024 + 40.0 * 1024
