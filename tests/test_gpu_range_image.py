@@ -99,3 +99,35 @@ def test_wrapper_and_runner_take_range_images():
         T = w.register_frame(SimpleNamespace(range=imgs[k], ts=float(k)))
         assert np.array_equal(T, res[k])
     assert len(w._sigmas) == 5
+
+
+@pytest.mark.parametrize("free", [True, False])
+def test_batch_takes_range_images(free):
+    """range images + reduce_active_beams through the batched runner (both drivers: the free-running kernel converts four
+    pixels per thread) == the single-sequence runner on the same images"""
+    S, n = 3, 5
+    seqs = [synth.make_sequence(seed=1060 + s, n_scans=n) for s in range(S)]
+    H, W = seqs[0].H, seqs[0].W
+    alt, az = np.linspace(45.0, -45.0, H), np.zeros(H)
+    lut = core.Lut(H, W, alt, az)
+    b = core.BatchRunner(S, n, H * W, 0, with_ekf=False, free_running=free)
+    b.set_lut(lut, active_beams=64)
+    singles = []
+    for s, sq in enumerate(seqs):
+        r = core.SeqRunner(n, H * W, 0, max_range=70.0, min_range=1.0, with_ekf=False, gn_workgroups=32, gn_lanes_per_point=8, gn_threads=512)
+        r.set_lut(lut, active_beams=64)
+        for k in range(n):
+            x = sq.scan(k).reshape(H, W, 3)
+            img = np.round(np.linalg.norm(x[:, (W - np.arange(W)) % W, :], axis=2) * 1000.0).astype(np.uint32)
+            b.upload_range(s, k, img)
+            r.upload_range(k, img)
+        b.upload_imu(s, np.zeros((0, 7)), [0] * n)
+        r.upload_imu(np.zeros((0, 7)), [0] * n)
+        r.run()
+        singles.append(r.results())
+    b.run()
+    for s in range(S):
+        out = b.results(s)
+        assert np.array_equal(out["kiss_poses"], singles[s]["kiss_poses"]), s
+        assert out["stats"] == singles[s]["stats"]
+        assert 0 < out["stats"][-1]["n_valid"] <= 64 * W
