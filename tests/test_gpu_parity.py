@@ -537,6 +537,25 @@ def test_throughput_kernel_8_lanes_per_point_vs_oracle():
             assert out["stats"][k][key] == ref["stats"][k][key], (k, key)
 
 
+def test_throughput_kernel_with_many_points_per_workgroup_vs_oracle():
+    """the 8-lanes-per-point kernel on 4 workgroups: ~1750 source points each, i.e. four phase-A chunks whose misses share
+    the search queue - which overflows (1024 entries) and is flushed between the chunks in the first iterations"""
+    n = 14
+    sq = synth.make_sequence(seed=1005, n_scans=n)
+    ref = _threaded_oracle(sq.events(n), max_range=70.0, min_range=1.0, use_imu_prediction=True)
+    r = core.SeqRunner(n, sq.H * sq.W, sq.imu_range_for_scan(n - 1)[1], max_range=70.0, min_range=1.0,
+                       use_imu_prediction=True, with_ekf=True, gn_workgroups=4, gn_lanes_per_point=8, gn_threads=512)
+    _upload(sq, r, n)
+    r.run()
+    out = r.results()
+    assert out["stats"][-1]["n_src"] > 4 * 1024
+    d = np.linalg.norm(out["res_poses"][:, :3, 3] - ref["res_poses"][:, :3, 3], axis=1)
+    assert d.max() <= 1e-9, d
+    for k in range(n):
+        for key in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "sum_cand", "map_voxels", "map_points"):
+            assert out["stats"][k][key] == ref["stats"][k][key], (k, key)
+
+
 def test_throughput_kernel_over_the_whole_chip_vs_oracle():
     """the 8-lanes-per-point kernel for ONE sequence on all 256 workgroups (two-hop exchange; the dense-scan form)"""
     n = 24
