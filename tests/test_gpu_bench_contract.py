@@ -70,6 +70,39 @@ def test_bench_launches_its_own_ranks_on_distinct_sequences(tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_ranks_with_free_running_batches_share_the_gpu(tmp_path):
+    """two self-launched ranks, three sequences each (rank r owns the seeds 1000 + r + 2 j) in the free-running kernel: on the
+    1-GPU box the two persistent launches are time-sliced on GPU 0 (their waits are bounded by executed polls, not by wall
+    clock) - both finish, all six trajectories are gathered, and a sequence equals its single-process run"""
+    import numpy as np
+    import ptudes_lab_amd  # noqa: F401
+    from ptudes_lab_amd import core, synth
+    dump = str(tmp_path / "traj.npz")
+    K, W = 8, 4
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(K), "--warmup", str(W),
+                          "--seqs-per-gpu", "3", "--dump-traj", dump], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
+    assert d["n_gpus"] == 2 and d["config"]["driver"].startswith("free-running") and d["config"]["sequences_per_gpu"] == 3
+    assert d["gathered_trajectories"]["sequences"] == 6 and d["gathered_trajectories"]["rows_each"] == [K + W]
+    assert abs(d["value"] - 6 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    got = np.load(dump)
+    seeds = {(int(r), int(j)): int(sd) for r, j, sd in got["seeds"]}
+    assert seeds == {(0, 0): 1000, (0, 1): 1002, (0, 2): 1004, (1, 0): 1001, (1, 1): 1003, (1, 2): 1005}
+    n = K + W
+    sq = synth.make_sequence(seed=1003, n_scans=n)
+    n_imu = sq.imu_range_for_scan(n - 1)[1]
+    run = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=True, with_ekf=True, gn_workgroups=32, gn_lanes_per_point=8, gn_threads=512)
+    for k in range(n):
+        run.upload_scan(k, sq.scan(k))
+    run.upload_imu(sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
+    run.run()
+    o = run.results()
+    rows = got["rank1_seq1"]
+    assert np.array_equal(rows[:, 0], o["res_t"]) and np.array_equal(rows[:, 1:4], o["res_poses"][:, :3, 3])
+
+
+@pytest.mark.gpu
 def test_bench_default_is_the_batched_runner():
     """no flags but short: 48 independent sequences on the GPU (seeds 1000..1047, six per XCD served by four teams) in the
     free-running kernel (one persistent launch for the timed steps), `value` = 48 scans per step, sequence 0 checked
