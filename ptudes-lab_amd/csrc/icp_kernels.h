@@ -2176,12 +2176,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     }
 }
 // one sequence, 8 lanes per point (gn_workgroups <= 64: one-hop exchange; more: two hops through 8 group leaders)
-template <int PC>
+// GC = gridDim.x when that is 32 / 16 / 8 (the host picks the instance), else 0.  The exchange's association is the same
+// in every instance: a batch member equals the single run with as many workgroups.  (One body per kernel: each
+// instance of gn8_body has its own 40 KB of LDS.)
+template <int PC, int GC>
 __global__ __launch_bounds__(GN8_MAX_THREADS) void k_gn_loop8(Ctx c, int mode) {
-    if (gridDim.x == 32) gn8_body<PC, 32>(c, mode, 32, (int)blockIdx.x);       // (the exchange's association is the same
-    else if (gridDim.x == 16) gn8_body<PC, 16>(c, mode, 16, (int)blockIdx.x);  // in every instance: a batch member equals
-    else if (gridDim.x == 8) gn8_body<PC, 8>(c, mode, 8, (int)blockIdx.x);     // the single run with as many workgroups)
-    else gn8_body<PC, 0>(c, mode, (int)gridDim.x, (int)blockIdx.x);
+    gn8_body<PC, GC>(c, mode, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ K7-K9

@@ -178,8 +178,8 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
         const int P20 = cfg->max_points_per_voxel == 20;
         hipError_t e;
         if (cfg->gn_lanes_per_point == 8)
-            e = P20 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop8<20>, cfg->gn_threads, 0)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop8<0>, cfg->gn_threads, 0);
+            e = P20 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop8<20, 0>, cfg->gn_threads, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop8<0, 0>, cfg->gn_threads, 0);  // (the instance with the largest footprint)
         else
             e = P20 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop<20, true>, cfg->gn_threads, 0)
                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gn_loop<0, true>, cfg->gn_threads, 0);
@@ -344,7 +344,11 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     // ends with the post-ICP bookkeeping (kiss.py:116-128).  Dense scans (more source points than 32-lane groups) run the
     // variant that keeps probe results in memory; the previous scan's N_s, copied back without a wait, is the hint
     const bool dense = *h->n_src_hint > (int64_t)c.G * (h->cfg.gn_threads / 32);
-    if (h->cfg.gn_lanes_per_point == 8) { if (c.P == 20) k_gn_loop8<20><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop8<0><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }  // (k_gn_loop8 picks its exchange instance from gridDim)
+    if (h->cfg.gn_lanes_per_point == 8) {
+#define KG8(GC) do { if (c.P == 20) k_gn_loop8<20, GC><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop8<0, GC><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); } while (0)
+        if (c.G == 32) KG8(32); else if (c.G == 16) KG8(16); else if (c.G == 8) KG8(8); else KG8(0);
+#undef KG8
+    }
     else if (c.P == 20) { if (dense) k_gn_loop<20, true><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<20, false><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
     else { if (dense) k_gn_loop<0, true><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); else k_gn_loop<0, false><<<c.G, h->cfg.gn_threads, 0, s>>>(c, 0); }
     if (timed) HIPCHK(hipEventRecord(e1, s));
