@@ -1057,7 +1057,7 @@ __device__ __forceinline__ double gn_ll_join(unsigned half) {
 // In-kernel phase clocks (tools_phase.py, ptl_icp_gn_phases / ptl_icp_gn_wg_clocks) are compiled in only with
 // -DGN_PHASE_CLOCKS (make PHASES=1): eight 64-bit accumulators and the counter reads otherwise compete with the loop's
 // live values for scalar and vector registers (the kernel runs at its 128-VGPR cap and spills).
-#ifdef GN_PHASE_CLOCKS
+#if defined(GN_PHASE_CLOCKS) || defined(GN_IT0_CLOCK)  /* (make IT0=1: only the split first iteration / other iterations of the point loop) */
 #define GN_CLK() ((long long)__builtin_readcyclecounter())
 #else
 #define GN_CLK() (0ll)
@@ -2151,6 +2151,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         __syncthreads();
         const long long c5 = GN_CLK();
         ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += c5 - c3;
+#if defined(GN_PHASE_CLOCKS) || defined(GN_IT0_CLOCK)
+        if (tid == 0 && wg == 0) atomicAdd((unsigned long long*)&c.wg_clk[52 + (it == 0 ? 0 : 1)], (unsigned long long)(c1 - c0));  // point loop of the first iteration / of the others
+#endif
         if (tid == NT - 1) cand_total_sh += (long long)tot[28];
         iters = it + 1;
         if (flag_done2[it & 1]) break;

@@ -10,6 +10,7 @@ for s,sq in enumerate(seqs):
     for k in range(n): b.upload_scan(s,k,sq.scan(k))
     b.upload_imu(s, sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
 b.run()
+nscan_all = n
 out=(C.c_int64*8)(); L.check(L.lib().ptl_batch_gn_phases(b._h,out))
 o=np.array(list(out),dtype=float); it=o[5]
 print("S",S,"grid iters",it,"ticks/iter: nn %.0f wgred %.0f barrier %.0f gridred %.0f solve %.0f"%tuple(o[:5]/it),"total",o[:5].sum()/it, "sum seq iters", sum(sum(st["iterations"] for st in b.results(s)["stats"]) for s in range(S)))
@@ -26,6 +27,8 @@ try:
     print("misses per workgroup per iter:", np.round(w[G:2 * G] / it, 1).tolist())
     if w[40] > 0:
         print("searches (all workgroups of sequence 0): %.0f per scan, survivor rounds per search %.2f, row rebuilt (voxel changed / first iteration) %.1f %%" % (w[40] / n, w[41] / w[40], 100 * w[42] / w[40]))
+    if w[52] > 0:
+        print("point loop of workgroup 0: first iteration %.0f ticks per scan, the others %.0f per iteration" % (w[52] / nscan_all, w[53] / max(it - nscan_all, 1)))
     if w[44] + w[45] > 0:
         print("bound of the others after a search: third-nearest candidate %.1f %%, box of a dropped voxel %.1f %%;  bound / winner's distance in [1,1.2) [1.2,1.5) [1.5,2) [2,3) [3,..): %s %%"
               % (100 * w[44] / (w[44] + w[45]), 100 * w[45] / (w[44] + w[45]), np.round(100 * w[46:51] / max(w[46:51].sum(), 1), 1).tolist()))
