@@ -74,6 +74,33 @@ def test_batch_icp_only_equals_independent_runs(free):
         assert out["stats"] == seqs[s]["stats"]
 
 
+def test_free_running_other_sensor_and_voxel_capacity():
+    """a 64 x 2048 sensor at 100 m range and 12 points per voxel (the kernels' run-time-P instances, another block count per
+    scan, another deskew table width): free-running batch == single runs"""
+    S, n = 3, 6
+    seqs = [synth.make_sequence(seed=1070 + s, n_scans=n, H=64, W=2048, max_range=100.0) for s in range(S)]
+    n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
+    kw = dict(max_range=100.0, min_range=1.0, use_imu_prediction=True, with_ekf=True, max_points_per_voxel=12, scan_cols=2048)
+    b = core.BatchRunner(S, n, 64 * 2048, n_imu, **kw)
+    assert b.free_running
+    for s, sq in enumerate(seqs):
+        r = core.SeqRunner(n, 64 * 2048, n_imu, gn_workgroups=32, gn_lanes_per_point=8, gn_threads=512, **kw)
+        ends = [sq.imu_range_for_scan(k)[1] for k in range(n)]
+        for k in range(n):
+            b.upload_scan(s, k, sq.scan(k))
+            r.upload_scan(k, sq.scan(k))
+        b.upload_imu(s, sq.imu[:n_imu], ends)
+        r.upload_imu(sq.imu[:n_imu], ends)
+        r.run()
+        seqs[s] = r.results()
+    b.run()
+    for s in range(S):
+        out = b.results(s)
+        assert np.array_equal(out["kiss_poses"], seqs[s]["kiss_poses"]) and np.array_equal(out["res_poses"], seqs[s]["res_poses"]), s
+        assert out["stats"] == seqs[s]["stats"]
+        assert out["stats"][-1]["iterations"] > 0 and out["stats"][-1]["map_points"] > 0
+
+
 def test_free_running_kernel_leaves_when_a_workgroup_never_arrives():
     """a workgroup of one team that skips the Gauss-Newton loop (test hook): the team's polls run out, the abort word goes
     up, every workgroup of that team leaves the persistent kernel and the host gets the time-out flag - no hang; the
