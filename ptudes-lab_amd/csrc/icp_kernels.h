@@ -24,6 +24,7 @@
 #pragma once
 #include "devmath.h"
 #include <stdint.h>
+#include <type_traits>
 
 #define EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define TOMB_KEY 0xFFFFFFFFFFFFFFFEull
@@ -1728,6 +1729,9 @@ __device__ __forceinline__ double sums_from_moments(int e, const double* M) {
 #ifndef GN8_LPB
 #define GN8_LPB 8             /* lanes per point of the full search (8 or 4) */
 #endif
+#ifndef GN8_IT0_LP
+#define GN8_IT0_LP 8          /* ... in the first iteration of a scan, where every point searches (make IT0LP=4: tried) */
+#endif
 #ifndef GN8_MAX_THREADS
 #define GN8_MAX_THREADS 512  /* 8 wavefronts per workgroup: 256 VGPRs per lane, nothing spills (at 768 / 168 VGPRs the search spills ~50) */
 #endif
@@ -1926,8 +1930,8 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             const int nmiss = nq;
             nq = 0;
             // ---- phase B, GN8_LPB LANES PER POINT: the full search of the queued points (gn8_search)
-            {
-                constexpr int LPB = GN8_LPB;
+            auto phaseB = [&](auto lp_tag) {
+                constexpr int LPB = decltype(lp_tag)::value;
                 const int laneL = tid & (LPB - 1), gb = (tid & 63) & ~(LPB - 1);
                 for (int k = tid / LPB; __any(k < nmiss); k += NT / LPB) {
                   if (k < nmiss) {
@@ -1965,7 +1969,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
 #endif
                   }
                 }
-            }
+            };
+            if (GN8_IT0_LP != GN8_LPB && it == 0) phaseB(std::integral_constant<int, GN8_IT0_LP>{});  // (every point searches: more points per pass)
+            else phaseB(std::integral_constant<int, GN8_LPB>{});
             __syncthreads();  // the queue is reused by the next chunk
             {   // (queue flushed before the last chunk: its loads are requested again rather than carried across the search;
                 // after the last chunk nothing is loaded - chunk_point says so - and the stale values are dead for the compiler too)
