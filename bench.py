@@ -25,6 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GN_EVENT_EVERY = 8
+DEFAULT_SEQS = 48
+PARITY_EXTRA_SEQS = 2     # sequences beside sequence 0 whose trajectories are checked against the oracle (single rank)
+PARITY_EXTRA_SWEEPS = 40  # ... over their first sweeps
 GATHER_TIMEOUT_S = 120
 CPU_MIN_SWEEPS = 300  # sweeps offered to the CPU baseline (it stops at its time budget)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -44,6 +47,57 @@ def scan_bytes(s, n_raw):
     b_ds = (12 + 16) * nv + 12 * nd + (12 + 16) * nd + 12 * ns
     b_map = (12 + 16 + 12) * nd + (16 + 12) * mv
     return b_pre + b_ds + icp_bytes(s) + b_map
+
+
+# ---- as-executed byte model of the free-running kernel ("Executed bytes"): every global load / store the
+# kernel issues, at the width the lane requests (no cache-line rounding, no cache assumed), driven by the counters the
+# kernel keeps (ptl_batch_exec_counters) and the per-scan statistics.  Unit costs in bytes:
+EXEC_COST = {
+    # Gauss-Newton loop (gn8_body): phase A of every point-iteration reads the position (24) and writes it back (24);
+    # after the first iteration of a scan it also reads the voxel key (8) and the 96-byte answer row
+    "point_iteration": 48, "point_iteration_later": 104,
+    # a full search reads the probe row (128) + key (8), writes the answer row (96) + the winner's voxel (4)
+    "search": 236,
+    # a rebuilt probe row: 27 hash-table entries of 16 B, the row (128) and the key (8) written
+    "row_rebuilt": 27 * 16 + 136,
+    "map_point_read": 24,
+    # per iteration and workgroup of a team of G: its row stored (36 words of 8 B), G rows read once by its first wavefront
+    "exchange_word": 8, "exchange_words_per_row": 36,
+    # stages, per raw point: K1 f32 xyz (12) + slot2 release read (4) + slot1 write (4) | K2 slot1 (4) + slot2 write (4) | K3 slot2 (4) | K4 slot2 (4)
+    "raw_point": 12 + 4 + 4 + 4 + 4 + 4 + 4,
+    # per valid point: K1 writes the deskewed point (24), K2 reads the slot's winner index (4)
+    "valid_point": 24 + 4,
+    # per voxel claim (run head) of either down-sampling pass: key read (8) + compare-and-swap (8) + index read (4) + atomicMin (4)
+    "vds_claim": 24,
+    # per frame_down point: K2 reads it (24); K3 reads index (4) + slot (4) + point (24), writes fd (24), releases the pass-1 slot (12);
+    # map insert a: fd read (24), world point written (24), table key read (8), list push (4), slot + link written (8);
+    # b: slot (4) + table entry (16) + list walk (~8) + block header (4) + world point (24) read, block written (24), rank + length written (8);
+    # c: rank read (4)
+    "down_point": 24 + (4 + 4 + 24 + 24 + 12) + (24 + 24 + 8 + 4 + 8) + (4 + 16 + 8 + 4 + 24 + 24 + 8) + 4,
+    # per source point: K3 marks (4), K4 reads + writes it (48), the next K1 releases its pass-2 slot (12)
+    "source_point": 4 + 48 + 12,
+    # prune: header (8) + first point (24) of every block below the pool's high-water mark (~ live voxels)
+    "map_voxel": 32,
+    # the per-column deskew table (12 doubles per column), written once per scan and read through the caches: counted once
+    "scan_column": 96,
+}
+
+
+def executed_bytes(cnt, stats, n_raw, G, cols=1024):
+    """bytes the free-running kernel requested from memory for the scans in `stats` (ptl_icp_stats rows of the timed scans of
+    one sequence), given the delta of its executed-work counters over those scans"""
+    c = EXEC_COST
+    pi = cnt["point_iterations"]
+    first = sum(s["n_src"] for s in stats if s["iterations"] > 0)
+    gn = (c["point_iteration"] * pi + c["point_iteration_later"] * max(pi - first, 0) + c["search"] * cnt["searches"]
+          + c["row_rebuilt"] * cnt["rows_rebuilt"] + c["map_point_read"] * cnt["map_points_read"]
+          + cnt["gn_iterations"] * G * (1 + G) * c["exchange_words_per_row"] * c["exchange_word"])
+    st = 0
+    for s in stats:
+        st += (c["raw_point"] * n_raw + c["valid_point"] * s["n_valid"] + c["down_point"] * s["n_down"]
+               + c["source_point"] * s["n_src"] + c["map_voxel"] * s["map_voxels"] + c["scan_column"] * cols)
+    st += c["vds_claim"] * (cnt["vds1_claims"] + cnt["vds2_claims"])
+    return gn + st, gn, st
 
 
 def _cpu_pass(seq, n_total, use_imu_prediction, budget_s, with_ekf=True, oracle_over=None):
@@ -163,9 +217,12 @@ def launch_ranks(n, argv, worker=None, timeout_s=3600.0, out=None):
     return worst
 
 
-def pmc_traffic_for(workload_key):
+def pmc_traffic_for(workload_key, scans_per_launch=None):
     """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC pass (profiles/) whose recorded workload
-    is THIS run's workload, or None: a counter value belongs to the run it was collected on."""
+    is THIS run's workload, or None: a counter value belongs to the workload it was collected on.  The free-running kernel's
+    summaries record bytes per SCAN (a launch carries as many scans as the run asks for: the same workload at another step
+    count moves the same bytes per scan) - scaled here by this run's scans per launch; per-launch kernels record bytes per
+    launch.  The latest matching file wins."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json"))):
@@ -173,17 +230,30 @@ def pmc_traffic_for(workload_key):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload_key") == workload_key and d.get("traffic_bytes_per_launch") is not None:
+        if d.get("workload_key") != workload_key:
+            continue
+        if d.get("traffic_bytes_per_scan") is not None and scans_per_launch:
+            best = (d["traffic_bytes_per_scan"] * scans_per_launch, os.path.basename(f))
+        elif d.get("traffic_bytes_per_launch") is not None and not scans_per_launch:
             best = (d["traffic_bytes_per_launch"], os.path.basename(f))
     return best
 
 
 def workload_key(args, S):
-    """what a PMC pass has to have been collected on to speak for this run"""
+    """what a PMC pass has to have been collected on to speak for this run.  Per-launch kernels (one Gauss-Newton launch per
+    step): including the warm-up and step counts, which decide what the map holds during the timed launches.  The free-running
+    kernel (one launch for the whole run, summaries per scan): without them, with the team geometry instead."""
+    free = free_running(args, S)
     return (f"{args.rows}x{args.cols}_r{args.min_range:g}-{args.max_range:g}_v{(args.voxel_size or args.max_range / 100):g}_"
-            f"seed{args.seed_base}_S{S}_W{args.warmup}_K{args.steps}_{'cv' if args.const_velocity else 'imu'}"
+            f"seed{args.seed_base}_S{S}_" + ("" if free else f"W{args.warmup}_K{args.steps}_") +
+            f"{'cv' if args.const_velocity else 'imu'}"
             f"{'' if not args.icp_only else '_icponly'}{'' if not args.gn_lanes else '_L%d' % args.gn_lanes}"
-            f"{'_free' if free_running(args, S) else ''}")
+            + (f"_free_g{getattr(args, 'gn_wgs', 0) or 256}x{getattr(args, 'gn_threads', 0) or 512}_t{getattr(args, 'team_wgs', 0)}" if free else ""))
+
+
+def default_team_wgs(S):
+    """bench default: the library's geometry"""
+    return 0
 
 
 def free_running(args, S):
@@ -196,13 +266,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seqs-per-gpu", type=int, default=48,
+    ap.add_argument("--seqs-per-gpu", type=int, default=DEFAULT_SEQS,
                     help="independent sequences per GPU (SURVEY.md 8(e), second level), batched runner.  The sequences s = x (mod 8) "
-                         "live on XCD x; up to 8 / 16 sequences: one / two teams of workgroups per XCD, one sequence each; more "
-                         "(default 48, up to 64): four teams per XCD that take the sequences' scans as they come free, so the "
-                         "sequences advance evenly (6.0k / 9.9k / 13.0k / 14.8k scans/s for 8 / 16 / 32 / 48).  One Gauss-Newton "
-                         "loop alone leaves an XCD latency-bound, more of them fill the gaps.  1 = the single-sequence latency "
-                         "pipeline (one sequence over the whole chip)")
+                         "live on XCD x, whose teams of workgroups take their scans as they come free (--team-wgs).  1 = the "
+                         "single-sequence latency pipeline (one sequence over the whole chip)")
+    ap.add_argument("--team-wgs", type=int, default=-1,
+                    help="workgroups per team of the free-running kernel (-1: bench default for the number of sequences, 0: the "
+                         "library's).  Smaller teams spread the per-iteration fixed costs over more points and want more sequences")
     ap.add_argument("--seed-base", type=int, default=1000, help="sequence s of SURVEY.md 8(d) uses seed seed_base + s")
     ap.add_argument("--equal-work", action="store_true",
                     help="every rank registers its own copy of sequences seed_base .. seed_base + S - 1 (equal work per GPU) "
@@ -247,8 +317,10 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    if args.seqs_per_gpu < 1 or args.seqs_per_gpu > 64:
-        sys.exit("bench.py: --seqs-per-gpu must be in [1, 64]")
+    if args.seqs_per_gpu < 1 or args.seqs_per_gpu > 256:
+        sys.exit("bench.py: --seqs-per-gpu must be in [1, 256]")
+    if args.team_wgs < 0:
+        args.team_wgs = default_team_wgs(args.seqs_per_gpu)
     multi = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # a rank of a multi-process run
     dist = None
     torch = None
@@ -321,15 +393,27 @@ def main():
         def profile(self, **kw): return self.r.profile(**kw)
         def copy_traj(self, j, ptr, n): return self.r.copy_traj(ptr, n)
     free = free_running(args, S)
+    t_setup = time.perf_counter()
     runner = _One() if S == 1 else core.BatchRunner(S, n_total, pps, n_imu, max_range=args.max_range,
                                                     min_range=args.min_range, use_imu_prediction=use_imu,
                                                     with_ekf=with_ekf, device_id=local_rank, free_running=free,
-                                                    scans_per_launch=args.scans_per_launch, **icp_over)
+                                                    scans_per_launch=args.scans_per_launch,
+                                                    team_workgroups=args.team_wgs if free else 0, **icp_over)
+    team_g, teams = runner.team_geometry() if free else (0, 0)
+    t_render, t_upload = 0.0, 0.0
     for j, sq in enumerate(seqs):
         for k in range(n_total):
-            runner.upload_scan(j, k, sq.scan(k))
+            ta = time.perf_counter()
+            x = sq.scan(k)
+            tb = time.perf_counter()
+            runner.upload_scan(j, k, x)
+            t_render += tb - ta
+            t_upload += time.perf_counter() - tb
         runner.upload_imu(j, sq.imu[:n_imu] if with_ekf else np.zeros((0, 7)),
                           [sq.imu_range_for_scan(k)[1] if with_ekf else 0 for k in range(n_total)])
+    # where a slow start-up of a many-rank run goes: per rank, to stderr (fd 1 is stderr here)
+    print(f"bench.py rank {rank}: {S} sequences x {n_total} sweeps - handles {time.perf_counter() - t_setup - t_render - t_upload:.1f} s, "
+          f"rendering {t_render:.1f} s ({synth.usable_cores()} usable cores), upload {t_upload:.1f} s", file=sys.stderr, flush=True)
 
     def barrier():
         if dist is not None:
@@ -341,7 +425,10 @@ def main():
         core.device_sync(local_rank)
 
     # warm-up: cold start + the first W sweeps (untimed)
+    t_warm = time.perf_counter()
     runner.run(W)
+    print(f"bench.py rank {rank}: warm-up ({W} sweeps of every sequence) {time.perf_counter() - t_warm:.2f} s", file=sys.stderr, flush=True)
+    cnt0 = [runner.exec_counters(j) for j in range(S)] if free else None
     # HIP events around every 8th launch of the dominant kernel: two event records per scan cost ~18 us (4 %) of
     # command-processor time on the critical path
     ev_every = GN_EVENT_EVERY if S == 1 else 1  # (the batched runner times every launch)
@@ -354,6 +441,7 @@ def main():
     dt_own = time.perf_counter() - t0  # this rank's own K steps
     barrier()
     dt = time.perf_counter() - t0
+    print(f"bench.py rank {rank}: timed region {dt_own:.3f} s own, {dt:.3f} s to the barrier", file=sys.stderr, flush=True)
     per_rank = [K * S / dt_own]
     if dist is not None:
         from ptudes_lab_amd import parallel
@@ -377,6 +465,16 @@ def main():
             b_scan += scan_bytes(s, pps)
             iters.append(s["iterations"])
     seq_clk = [runner.seq_clocks(j) for j in range(S)] if free else None
+    exec_bytes, exec_gn, exec_stages, cnt_tot = 0.0, 0.0, 0.0, None
+    if free:  # the as-executed byte model over the timed scans: counters now minus counters after the warm-up
+        cnt_tot = {k: 0 for k in core.BatchRunner.EXEC_COUNTERS}
+        for j, o in enumerate(outs):
+            c1 = runner.exec_counters(j)
+            d = {k: c1[k] - cnt0[j][k] for k in c1}
+            tot, gnb, stb = executed_bytes(d, o["stats"][W:], pps, team_g, args.cols)
+            exec_bytes += tot; exec_gn += gnb; exec_stages += stb
+            for k in d:
+                cnt_tot[k] += d[k]
     n_timed = sum(len(o["stats"]) - W for o in outs)
     assert n_timed == K * S, (n_timed, K, S)
 
@@ -434,7 +532,39 @@ def main():
         mode_txt = "ICP only, constant-velocity guess" if not with_ekf else \
             f"ICP + IMU-EKF ({'--use-imu-prediction' if use_imu else 'constant-velocity guess'})"
         wkey = workload_key(args, S)
-        pmc = pmc_traffic_for(wkey) if world == 1 else None
+        launches = max(gn_n, 1)
+        scans_per_launch_mean = (K * S / launches) if free else None
+        pmc = pmc_traffic_for(wkey, scans_per_launch_mean) if world == 1 else None
+        alg_frac = achieved / HBM_PEAK  # SURVEY 8(d)'s brute-force bytes / launch time / peak
+        if free:
+            # what the kernel itself requested from memory (EXEC_COST x its own counters): the roofline figure of the line
+            avg_exec = exec_bytes / launches
+            achieved = avg_exec / avg_gn_s if avg_gn_s > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK,
+                "frac_kind": ("executed bytes: every load / store the kernel issued, at the width requested (bench.py EXEC_COST x the "
+                              "kernel's own counters, DESIGN.md 3) / launch time / peak" if free else
+                              "algorithmic bytes of SURVEY 8(d) (27 probes x 16 B + every candidate x 12 B + the source, per iteration) / "
+                              "launch time / peak; the kernel prunes the search exactly and skips ~3/4 of the candidate bytes"),
+                "algorithmic_frac": alg_frac, "algorithmic_bytes_per_launch": avg_gn_bytes,
+                "executed_bytes_per_launch": (exec_bytes / launches) if free else None,
+                "executed_bytes_per_scan": (exec_bytes / max(n_timed, 1)) if free else None,
+                "executed_split_per_scan": ({"gauss_newton": exec_gn / max(n_timed, 1), "stages": exec_stages / max(n_timed, 1)} if free else None),
+                "executed_counters_per_scan": ({k: v / max(n_timed, 1) for k, v in cnt_tot.items()} if free else None),
+                "traffic": pmc[0] if pmc else None, "traffic_source": pmc[1] if pmc else None,
+                "measured_frac": (pmc[0] / avg_gn_s / HBM_PEAK) if (pmc and avg_gn_s > 0) else None,
+                "kernel": ("k_gn_loop8" if args.gn_lanes == 8 else "k_gn_loop") if S == 1 else
+                          "kx_seq_run" if free else ("kx_gn_loop" if args.gn_lanes == 32 else "kx_gn_loop8"),
+                "avg_launch_us": 1e6 * avg_gn_s, "launches": gn_n,
+                "scans_per_launch": scans_per_launch_mean,
+                "timed_launches": (f"all {gn_n} persistent launches of the {K} steps (HIP events)" if free else
+                                   f"every {ev_every}th of {K} (HIP events)"),
+                "note": ("the free-running kernel carries the WHOLE per-scan pipeline of every sequence.  frac = executed bytes / launch time "
+                         "/ peak; algorithmic_frac = B_scan of SURVEY 8(d) (brute-force 27-voxel search) the same way - above 1 because the "
+                         "answer cache settles most point-iterations without the probes and candidate reads that formula charges; "
+                         "traffic = HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE) of a committed pass of this workload, per scan x this run's "
+                         "scans per launch; measured_frac = traffic / launch time / peak" if free else
+                         "measured_frac = PMC HBM bytes of the same workload / launch time / peak")}
         line = {
             "metric": f"lidar scans/sec (ICP+EKF) on {args.rows}x{args.cols} sweeps",
             "value": K * S * world / dt, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -447,27 +577,11 @@ def main():
                        "sequences_per_gpu": S, "sequence_seeds": seeds_txt,
                        "driver": "single sequence" if S == 1 else
                                  "free-running (one persistent launch, every sequence at its own pace)" if free else "lockstep (one launch per stage)",
+                       "team_workgroups": team_g if free else None, "teams": teams if free else None,
                        "scans_per_sequence": n_total, "parallelism": f"{world} independent sequence shard(s), no data-path collective"},
             "per_rank_scans_per_s": {"values": per_rank, "min": min(per_rank), "mean": float(np.mean(per_rank)), "max": max(per_rank),
                                      "note": "each rank's own K steps / its own wall time; `value` uses the max-over-ranks clock"},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": pmc[0] if pmc else None,
-                         "traffic_source": pmc[1] if pmc else None,
-                         "measured_frac": (pmc[0] / avg_gn_s / HBM_PEAK) if (pmc and avg_gn_s > 0) else None,
-                         "kernel": ("k_gn_loop8" if args.gn_lanes == 8 else "k_gn_loop") if S == 1 else
-                                   "kx_seq_run" if free else ("kx_gn_loop" if args.gn_lanes == 32 else "kx_gn_loop8"),
-                         "avg_launch_us": 1e6 * avg_gn_s, "algorithmic_bytes_per_launch": avg_gn_bytes,
-                         "launches": gn_n,
-                         "timed_launches": (f"all {gn_n} persistent launches of the {K} steps (HIP events)" if free else
-                                            f"every {ev_every}th of {K} (HIP events)"),
-                         "note": ("the free-running kernel carries the WHOLE per-scan pipeline of every sequence: frac = B_scan of SURVEY "
-                                  "8(d) (pre-processing + down-sampling + the Gauss-Newton iterations + map update) of all scans of a "
-                                  "launch / launch time / peak - it can exceed 1: the answer cache settles most point-iterations "
-                                  "without the 27 probes and the candidate reads the formula charges, and most of the rest hits the "
-                                  "L2; what reaches HBM is `traffic`; " if free else
-                                  "frac = ALGORITHMIC bytes (SURVEY 8(d): 27 probes x 16 B + every candidate x 12 B + the source, per "
-                                  "iteration) / launch time / peak; ") +
-                                 "measured_frac = PMC HBM bytes of the same workload / launch time / peak"},
+            "roofline": roof,
             "whole_scan": {"algorithmic_bytes_per_scan": b_scan / max(n_timed, 1),
                            "achieved_GBps": (b_scan * world / dt) / 1e9 if world == 1 else None,
                            "gn_share_of_wall": ((gn_ms / 1e3) / dt) if free else (avg_gn_s * K) / dt,
@@ -492,6 +606,21 @@ def main():
             d = np.linalg.norm(est[:m, :3, 3] - res_cpu[:m, :3, 3], axis=1)
             line["parity_vs_oracle"] = {"scans": m, "max_dpos_m": float(d.max()), "rmse_dpos_m": float(np.sqrt(np.mean(d ** 2)))}
             line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
+            if S > 1 and PARITY_EXTRA_SEQS > 0:
+                # two more sequences of the batch, picked by a fixed generator, against the oracle over their first sweeps
+                from oracle import cpu as orc
+                orc.set_threads(synth.usable_cores())
+                pick = sorted(int(v) for v in np.random.default_rng(args.seed_base + S).choice(np.arange(1, S), size=min(PARITY_EXTRA_SEQS, S - 1), replace=False))
+                m2 = min(n_total, PARITY_EXTRA_SWEEPS)
+                worst = 0.0
+                for j in pick:
+                    _, _, kiss_j, res_j = _cpu_pass(seqs[j], m2, use_imu, 1e9, with_ekf,
+                                                    {"voxel_size": args.voxel_size} if args.voxel_size else None)
+                    est_j = outs[j]["res_poses"] if with_ekf else outs[j]["kiss_poses"]
+                    worst = max(worst, float(np.linalg.norm(est_j[:m2, :3, 3] - res_j[:m2, :3, 3], axis=1).max()))
+                orc.set_threads(1)
+                line["parity_vs_oracle"]["extra_sequences"] = {"sequences": pick, "seeds": [args.seed_base + seq_ids[j] for j in pick],
+                                                               "sweeps_each": m2, "max_dpos_m": worst}
         else:
             line["cpu_baseline"] = None
         if world == 1 and S > 1 and not args.no_single_sequence:

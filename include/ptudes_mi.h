@@ -255,12 +255,12 @@ int ptl_seq_icp(ptl_seq *s, ptl_icp **icp);
 int ptl_seq_profile(ptl_seq *s, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
 
 /* ------------------------------------------------------------------------------------------------
- * Batched runner: up to 64 independent sequences on ONE GPU.  The sequences s = x (mod 8) live on XCD x (their maps,
+ * Batched runner: up to 256 independent sequences on ONE GPU.  The sequences s = x (mod 8) live on XCD x (their maps,
  * probe rows and exchange stay in its L2); the workgroups with blockIdx & 7 == x form 1 / 2 / 4 teams of gn_workgroups /
- * 8, / 16, / 32 workgroups (<= 8 / <= 16 / more sequences).  Two drivers, see ptl_batch_set_driver: the free-running
+ * 8, / 16, / 32 workgroups (<= 8 / <= 16 / <= 64 sequences), 8 teams for up to 128 sequences, 16 beyond
+ * (ptl_batch_set_team_workgroups overrides).  Two drivers, see ptl_batch_set_driver: the free-running
  * kernel (default) and lockstep (one launch per stage for all sequences, <= 32 sequences).  Each sequence's results are
- * bit-identical to running it alone with a team's workgroups (gn_workgroups / 8, / 16, / 32) and the same
- * gn_lanes_per_point.  cfg describes every sequence (same n_scans / points_per_scan / n_imu; gn_workgroups = 8 x
+ * bit-identical to running it alone with a team's workgroups and the same gn_lanes_per_point.  cfg describes every sequence (same n_scans / points_per_scan / n_imu; gn_workgroups = 8 x
  * workgroups per XCD); with_ekf requires >= 1 IMU sample between consecutive scans.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ptl_batch ptl_batch;
@@ -284,7 +284,8 @@ int ptl_batch_profile(ptl_batch *b, int enable, double *gn_ms_total, int64_t *gn
  *     scans_per_launch scans (0 = keep, default 256) of EVERY sequence; the workgroups of a sequence walk its whole
  *     per-scan pipeline - reference cli/ekf_bench.py:493-563 - at their own pace, so a sequence whose Gauss-Newton loop
  *     converges early starts its next scan instead of waiting for the slowest one.  ptl_batch_profile then times these
- *     launches.  Needs gn_lanes_per_point = 8 and, with a filter, at least two workgroups per sequence.
+ *     launches.  Needs gn_lanes_per_point = 8 and a grid whose workgroups can all be resident (checked here, or at the
+ *     first enqueue when the driver is the default); scans_per_launch <= 4096.
  *   free_running == 0: lockstep, one launch per stage for all sequences; a step lasts as long as its slowest sequence.
  * Same results either way (bit-identical). */
 int ptl_batch_set_driver(ptl_batch *b, int32_t free_running, int64_t scans_per_launch);
@@ -292,6 +293,18 @@ int ptl_batch_set_driver(ptl_batch *b, int32_t free_running, int64_t scans_per_l
  * workgroup 0's K0-K4 | its wait before the Gauss-Newton loop | the loop | its wait after it | its map update;
  * out[5] the filter workgroup's step; out[6] scans */
 int ptl_batch_seq_clocks(ptl_batch *b, int32_t seq, int64_t out[8]);
+/* Team size of the free-running kernel: `team_workgroups` workgroups (1 .. min(64, gn_workgroups / 8); 0 = the default for
+ * the number of sequences) walk one scan of one sequence together; an XCD's gn_workgroups / 8 / team_workgroups teams serve
+ * its sequences scan by scan.  Smaller teams spread the per-iteration fixed costs of the Gauss-Newton loop (workgroup
+ * reduction, exchange, 6x6 solve) over more points each and want more sequences in flight; the results of a sequence
+ * are those of a run alone with `team_workgroups` workgroups.  Before the first scan of a run. */
+int ptl_batch_set_team_workgroups(ptl_batch *b, int32_t team_workgroups);
+int ptl_batch_team_workgroups(ptl_batch *b, int32_t *team_workgroups, int32_t *teams /* nullable: teams that can get work */);
+/* Executed-work counters of sequence `seq`, cumulative since the cold start - what the kernels requested from memory, as
+ * opposed to the brute-force counts of ptl_icp_stats: [0] full 27-voxel searches (points the answer cache did not
+ * settle), [1] probe rows rebuilt (27 hash probes each), [2] stored map points read by the searches, [3] Gauss-Newton
+ * iterations, [4] / [5] voxel claims of down-sampling pass 1 / 2, [6] source point-iterations, [7] scans. */
+int ptl_batch_exec_counters(ptl_batch *b, int32_t seq, uint64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -126,6 +126,9 @@ PROTOTYPES = {
     "ptl_batch_profile": (C.c_int, [_vp, C.c_int, c_d_p, c_i64_p, C.c_int]),
     "ptl_batch_set_driver": (C.c_int, [_vp, C.c_int32, C.c_int64]),
     "ptl_batch_seq_clocks": (C.c_int, [_vp, C.c_int32, c_i64_p]),
+    "ptl_batch_set_team_workgroups": (C.c_int, [_vp, C.c_int32]),
+    "ptl_batch_team_workgroups": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ptl_batch_exec_counters": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

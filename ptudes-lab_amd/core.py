@@ -355,15 +355,16 @@ class SeqRunner:
 
 
 class BatchRunner:
-    """Up to 32 independent sequences on one GPU, each on its share of one XCD (the workgroups with blockIdx & 7 == s & 7).
-    Two drivers (`free_running`): True (the default with the 8-lane Gauss-Newton kernel) - one persistent launch carries
-    up to `scans_per_launch` scans of every sequence and each sequence advances at its own pace; False - lockstep, one
-    launch per stage for all sequences, a step lasts as long as its slowest sequence.  Either way the per-sequence
-    results are bit-identical to `SeqRunner(..., gn_workgroups=<workgroups per sequence>, gn_lanes_per_point=<the batch's>)`."""
+    """Up to 256 independent sequences on one GPU (lockstep: 32); sequence s lives on XCD s & 7 (the workgroups with
+    blockIdx & 7 == s & 7).  Two drivers (`free_running`): True (the default with the 8-lane Gauss-Newton kernel) - one
+    persistent launch carries up to `scans_per_launch` scans of every sequence, teams of `team_workgroups` workgroups take
+    the scans of their XCD's sequences as they come free; False - lockstep, one launch per stage for all sequences, a step
+    lasts as long as its slowest sequence.  Either way the per-sequence results are bit-identical to
+    `SeqRunner(..., gn_workgroups=<workgroups per team>, gn_lanes_per_point=<the batch's>)`."""
 
     def __init__(self, n_sequences, n_scans, points_per_scan, n_imu, *, max_range=70.0, min_range=1.0,
                  use_imu_prediction=False, with_ekf=True, device_id=0, ekf=None, free_running=None, scans_per_launch=0,
-                 **icp_over):
+                 team_workgroups=0, **icp_over):
         cfg = L.SeqCfg()
         icp_over.setdefault("gn_lanes_per_point", 8)  # a workgroup walks ~200 points per iteration here: the throughput form
         if icp_over["gn_lanes_per_point"] == 8:
@@ -379,6 +380,23 @@ class BatchRunner:
         self.free_running = (cfg.icp.gn_lanes_per_point == 8) if free_running is None else bool(free_running)
         if free_running is not None or scans_per_launch:
             L.check(L.lib().ptl_batch_set_driver(self._h, int(self.free_running), int(scans_per_launch)))
+        if team_workgroups:
+            L.check(L.lib().ptl_batch_set_team_workgroups(self._h, int(team_workgroups)))
+
+    def team_geometry(self):
+        """(workgroups per team, teams that can get work) of the free-running kernel"""
+        g, t = C.c_int32(), C.c_int32()
+        L.check(L.lib().ptl_batch_team_workgroups(self._h, C.byref(g), C.byref(t)))
+        return g.value, t.value
+
+    EXEC_COUNTERS = ("searches", "rows_rebuilt", "map_points_read", "gn_iterations", "vds1_claims", "vds2_claims",
+                     "point_iterations", "scans")
+
+    def exec_counters(self, s):
+        """executed-work counters of sequence s, cumulative since the cold start (include/ptudes_mi.h ptl_batch_exec_counters)"""
+        out = (C.c_uint64 * 8)()
+        L.check(L.lib().ptl_batch_exec_counters(self._h, s, out))
+        return dict(zip(self.EXEC_COUNTERS, (int(v) for v in out)))
 
     def close(self):
         if getattr(self, "_h", None):

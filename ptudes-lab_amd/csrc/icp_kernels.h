@@ -84,6 +84,12 @@ struct DevState {
     long long map_points;
     unsigned tab_used;
     int err_flags;
+    // executed-work counters, cumulative over the scans of the sequence (never reset by a scan; ptl_*_exec_counters):
+    // what the kernels actually requested from memory, as opposed to the brute-force figures of SURVEY 8(d) -
+    //   [0] full 27-voxel searches (8-lane kernel: points the answer cache did not settle)   [1] probe rows rebuilt (27 hash probes each)
+    //   [2] stored map points read by those searches   [3] Gauss-Newton iterations   [4] voxel claims of VDS pass 1 (run heads)   [5] of pass 2
+    //   [6] source point-iterations (phase A evaluations)   [7] scans
+    unsigned long long exec_cnt[8];
 };
 
 struct Ctx {
@@ -209,7 +215,9 @@ __device__ __forceinline__ void gn_ll_clear_on_wrap(const Ctx& c) {
     for (size_t i = threadIdx.x; i < n_rows; i += blockDim.x) c.gn_rows_ll[i] = 0ull;
     for (size_t i = threadIdx.x; i < n_xsum; i += blockDim.x) c.gn_xsum_ll[i] = 0ull;
 }
-__device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
+// keep_abort: the caller runs beside workgroups that may still poll the sequence's abort word (the free-running kernel's filter
+// workgroup runs scan k + 1's prologue during scan k's map update): an abort raised there must not be erased
+__device__ __forceinline__ void d_scan_prologue(const Ctx& c, const bool keep_abort = false) {
     DevState* st = c.st;
     // The pose block of the state (first, previous, last, new, model deviation: 80 doubles) is brought into LDS by 80
     // threads at once, one thread does the bookkeeping on it, and the three poses that changed go back in parallel:
@@ -240,7 +248,8 @@ __device__ __forceinline__ void d_scan_prologue(const Ctx& c) {
     st->n_in = c.n_in;
     st->n_valid = 0; st->n_down = 0; st->n_src = 0;
     st->gn_epoch = (st->gn_epoch + 1u) & 0x3FFFFFu;
-    st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0; st->gn_abort = 0;
+    st->gn_iters = 0; st->gn_ncorr = 0; st->gn_cand = 0;
+    if (!keep_abort) st->gn_abort = 0;
     st->do_deskew = (c.deskew && n_poses >= 2) ? 1 : 0;
     s_nposes = n_poses;
     __threadfence_block();
@@ -492,6 +501,12 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
             head[u] = keyed[u] && (lane == 0 || !prev_keyed || prev != key[u]);
         }
         vds_claim_u<U>(c.vkey1, c.vmask, key, head, slot);
+        {   // executed-work counter: voxel claims (one per run head)
+            int nh = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) nh += __popcll(__ballot(head[u]));
+            if (lane == 0 && nh) atomicAdd(&st->exec_cnt[4], (unsigned long long)nh);
+        }
         K1_CLK(22);
         vds_bid_u<U>(c.vmin1, slot, head, idx, &st->err_flags);
         K1_CLK(23);
@@ -552,6 +567,12 @@ __device__ __forceinline__ void d_vds2(const Ctx& c, const Slice sl) {
             head[u] = w1[u] && (!before || prev_key != key[u]);
         }
         vds_claim_u<U>(c.vkey2, c.vmask, key, head, slot);
+        {
+            int nh = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) nh += __popcll(__ballot(head[u]));
+            if (lane == 0 && nh) atomicAdd(&c.st->exec_cnt[5], (unsigned long long)nh);
+        }
         vds_bid_u<U>(c.vmin2, slot, head, idx, &c.st->err_flags);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1514,8 +1535,11 @@ __device__ __forceinline__ void scan_voxelsL(const CT& c, const int (&pb)[NV], c
 // the point changed voxel), box distances, first round = own voxel + last winner's voxel (+ the two nearest other boxes
 // when LP == 8), the remaining voxels exactly pruned and scanned two at a time, the new answer row.  Returns in every
 // lane the neighbour, its squared distance, found, and the candidate count of the 27 voxels.
+// xc: the workgroup's executed-work counters in LDS ([1] probe rows rebuilt, [2] stored points read; DevState::exec_cnt)
+__device__ __forceinline__ unsigned pb_count(int pb) { return pb < 0 ? 0u : (unsigned)pb >> 24; }
 template <int PC, int LP>
-__device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, double inv_vs, int laneL, int gb, V3& t, double& m, bool& found, int& ctot) {
+__device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, double inv_vs, int laneL, int gb, V3& t, double& m, bool& found, int& ctot,
+                                           unsigned* xc) {
     constexpr int RE = 32 / LP;  // row entries per lane
     const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
     const unsigned long long key = pack_key(kx, ky, kz);
@@ -1562,7 +1586,7 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
         int4* wp = (int4*)(c.pc_pb + 32 * (size_t)i + RE * laneL);
 #pragma unroll
         for (int k = 0; k < RE / 4; ++k) wp[k] = make_int4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
-        if (laneL == 0) c.pc_key[i] = key;
+        if (laneL == 0) { c.pc_key[i] = key; atomicAdd(xc + 1, 1u); }
     }
     const int lv_raw = __shfl(r[27 % RE], gb + 27 / RE);
     ctot = __shfl(r[28 % RE], gb + 28 / RE);
@@ -1617,9 +1641,11 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
             }
         }
         const int pb4[4] = {pbc, pbl, psel[0], psel[1]}, vx4[4] = {13, lv, vsel[0], vsel[1]};
+        if (laneL == 0) atomicAdd(xc + 2, pb_count(pbc) + pb_count(pbl) + pb_count(psel[0]) + pb_count(psel[1]));
         scan_voxelsL<PC, LP, 4>(c, pb4, vx4, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
     } else {
         const int pb2[2] = {pbc, pbl}, vx2[2] = {13, lv};
+        if (laneL == 0) atomicAdd(xc + 2, pb_count(pbc) + pb_count(pbl));
         scan_voxelsL<PC, LP, 2>(c, pb2, vx2, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
     }
     // the other voxels: dropped when their box lies farther than the best distance so far (exact, see nn_scan32)
@@ -1647,6 +1673,7 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
         const int p0 = __shfl(sel_entry<RE>(r, (int)(v0 % RE)), gb + (int)(v0 / RE));
         const int p1 = (v1 != 0xFFu) ? __shfl(sel_entry<RE>(r, (int)(v1 % RE)), gb + (int)((v1 / RE) & (LP - 1))) : -1;
         const int pb2[2] = {p0, p1}, vx2[2] = {(int)v0, (int)v1};
+        if (laneL == 0) atomicAdd(xc + 2, pb_count(p0) + pb_count(p1));
         scan_voxelsL<PC, LP, 2>(c, pb2, vx2, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
     }
 #ifdef GN_PHASE_CLOCKS
@@ -1789,9 +1816,11 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     __shared__ double Tsh[12];
     __shared__ int flag_done2[2];
     __shared__ long long cand_total_sh;
+    __shared__ unsigned xcnt[4];  // executed-work counters of this workgroup and scan: searches | rows rebuilt | stored points read
     DevState* st = c.st;
     const int tid = threadIdx.x, lane32 = tid & 31, grp32 = tid >> 5;
     const int NT = blockDim.x, NG32 = blockDim.x >> 5, NW = blockDim.x >> 6;
+    if (tid < 4) xcnt[tid] = 0u;
     const int n = st->n_src;
     const unsigned epoch = st->gn_epoch;
     if (wg == 0 && tid == 0 && mode == 0) flush_map_stats(c, st);
@@ -1929,6 +1958,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             __syncthreads();
             const int nmiss = nq;
             nq = 0;
+            if (tid == 0) xcnt[0] += (unsigned)nmiss;
             // ---- phase B, GN8_LPB LANES PER POINT: the full search of the queued points (gn8_search)
             auto phaseB = [&](auto lp_tag) {
                 constexpr int LPB = decltype(lp_tag)::value;
@@ -1953,7 +1983,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                         old_sl = c.pc_ans[GN8_ANS_ROW * (size_t)i + 6];
                     }
 #endif
-                    gn8_search<PC, LPB>(c, i, it, s, inv_vs, laneL, gb, t, m, found, ctot);
+                    gn8_search<PC, LPB>(c, i, it, s, inv_vs, laneL, gb, t, m, found, ctot, xcnt);
 #ifdef GN_PHASE_CLOCKS
                     if (wg == 0 && it > 0 && laneL == 0) {
                         const int cat = !old_same_key ? 5 : (old_sl < 0.0) ? 6 : (found && t.x == old_t[0] && t.y == old_t[1] && t.z == old_t[2]) ? 7 : 4;
@@ -2040,7 +2070,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 }
                 double t = 0.0;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {  // members g, g + 8, ... of group g in order, then the groups in order
+                for (int g = 0; g < (GC < 8 ? GC : 8); ++g) {  // members g, g + 8, ... of group g in order, then the groups in order
                     double sg = 0.0 + gn_ll_join(h[g]);
                     if (GC > 8) sg += gn_ll_join(h[(g + 8) % (GC > 0 ? GC : 32)]);
                     if (GC > 16) { sg += gn_ll_join(h[(g + 16) % (GC > 0 ? GC : 32)]); sg += gn_ll_join(h[(g + 24) % (GC > 0 ? GC : 32)]); }
@@ -2167,6 +2197,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     if (tid == 64 && iters > 0) gn_compose(Esh2[(iters - 1) & 1], Tsh);
     __syncthreads();
     if (tid == 0 && c.wg_clk) { c.wg_clk[wg] += ph[0]; c.wg_clk[G + wg] += ph_miss; }
+    if (tid < 3 && xcnt[tid]) atomicAdd(&st->exec_cnt[tid], (unsigned long long)xcnt[tid]);  // (integer sums: any order gives the same totals)
     if (wg == 0 && tid == 0) {
         Rt T;
         for (int k = 0; k < 9; ++k) T.R[k] = Tsh[k];
@@ -2175,6 +2206,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         st->gn_iters = iters;
         st->gn_ncorr = iters > 0 ? (int)tot[27] : 0;
         st->gn_cand = cand_total_sh;
+        st->exec_cnt[3] += (unsigned long long)iters;
+        st->exec_cnt[6] += (unsigned long long)iters * (unsigned long long)n;
+        st->exec_cnt[7] += 1ull;
         for (int k = 0; k < 5; ++k) st->gn_phase_clk[k] += ph[k];
         st->gn_phase_clk[5] += iters;
         st->gn_phase_clk[6] += ph_miss; st->gn_phase_clk[7] += ph_a;
@@ -2576,7 +2610,7 @@ __global__ __launch_bounds__(256) void kb_map_rebuild(const SeqCtx* a, int scan_
 // its workgroups meet through the one-hop exchange of gn_loop_body<XL = true> - nothing crosses the chip - and it leaves
 // the loop on its own convergence.  Per sequence the point -> workgroup assignment, the reduction trees and the
 // arithmetic are those of k_gn_loop launched alone with gridDim / 8 workgroups: bit-identical results.
-#define GN_MAX_SEQ 64  /* lockstep: up to four sequences per XCD (32); free-running: up to eight, served by up to four teams */
+#define GN_MAX_SEQ 256  /* lockstep: up to four sequences per XCD (32); free-running: up to 32 per XCD, served by its teams (seq_kernel.h) */
 // S <= 8: sequence s <-> XCD s with all gridDim / 8 workgroups of that XCD.  S > 8: the XCD's workgroups are split evenly
 // among the sequences s, s + 8, s + 16, ... it hosts (spx of them, a power of two): one sequence alone leaves an XCD
 // latency-bound and mostly idle (it costs the same per iteration as eight on eight), a second and a fourth loop fill

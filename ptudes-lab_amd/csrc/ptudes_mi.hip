@@ -1286,9 +1286,11 @@ struct ptl_batch {
     float* d_scans[GN_MAX_SEQ];
     double* d_imu[GN_MAX_SEQ];
     int* d_imu_end[GN_MAX_SEQ];
-    unsigned* d_bar;            // [32 teams][64] barrier counters and job words of the free-running kernel's teams
+    unsigned* d_bar;            // [SEQ_MAX_TEAMS][64] barrier counters and job words of the free-running kernel's teams
     SeqSched* d_sched;          // [8] its per-XCD scan schedulers
     bool free_running;
+    int team_wgs;               // workgroups per team of the free-running kernel (0 = by the number of sequences, batch_gseq)
+    bool seq_run_checked;
     int64_t scans_per_launch;
     std::vector<int64_t> imu_end[GN_MAX_SEQ];
     double *d_res_poses[GN_MAX_SEQ], *d_res_t[GN_MAX_SEQ], *d_rows[GN_MAX_SEQ];
@@ -1305,26 +1307,39 @@ struct ptl_batch {
     int64_t gn_launches;
 };
 
-// launch geometry of the free-running kernel: workgroups per sequence (GC template instance) as in kx_assign
-static int batch_gseq(const ptl_batch* b) { return (b->cfg.icp.gn_workgroups / 8) / (b->S <= 8 ? 1 : b->S <= 16 ? 2 : 4); }
+// launch geometry: workgroups per team.  Lockstep (kx_assign): one team per sequence, 1 / 2 / 4 per XCD.  Free-running: 1 / 2 / 4
+// teams per XCD for up to 8 / 16 / 64 sequences as before (a team of 8 workgroups of 512 threads at the default 256 workgroups),
+// 8 teams up to 128 sequences, 16 beyond; ptl_batch_set_team_workgroups overrides.  Smaller teams pay the per-iteration
+// fixed costs (workgroup reduction, exchange, solve) over more points each and need more sequences to stay busy.
+static int batch_gseq(const ptl_batch* b) {
+    if (b->free_running && b->team_wgs > 0) return b->team_wgs;
+    const int J = b->cfg.icp.gn_workgroups / 8;
+    if (!b->free_running || b->S <= 64) return J / (b->S <= 8 ? 1 : b->S <= 16 ? 2 : 4);
+    const int g = J / (b->S <= 128 ? 8 : 16);
+    return g < 1 ? 1 : g;
+}
 template <int GC>
 static hipError_t seq_run_occupancy(bool p20, int threads, int* per_cu) {
     return p20 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kx_seq_run<20, GC>, threads, 0)
                : hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kx_seq_run<0, GC>, threads, 0);
 }
+// the instance of a template <int PC, int GC> kernel for `gseq` workgroups per team: GC = gseq when that is 32 / 16 / 8 / 4 / 2 / 1, else 0
+#define GC_DISPATCH(gseq, CALL) do { switch (gseq) { case 32: CALL(32); break; case 16: CALL(16); break; case 8: CALL(8); break; \
+    case 4: CALL(4); break; case 2: CALL(2); break; case 1: CALL(1); break; default: CALL(0); break; } } while (0)
 // every workgroup of the persistent launch has to be resident (they wait for each other); a team needs a workgroup
 // beside the filter's
 static int batch_check_seq_run(ptl_batch* b) {
     const ptl_icp_cfg& ic = b->cfg.icp;
     if (ic.gn_lanes_per_point != 8) return set_err(PTL_ERR_ARG, "free-running batches use the 8-lane Gauss-Newton kernel (gn_lanes_per_point = 8)");
-    const int gseq = batch_gseq(b);
-    if (gseq < 2 && b->cfg.with_ekf) return set_err(PTL_ERR_ARG, "free-running batches with a filter need at least 2 workgroups per sequence");
-    if (gseq < 1) return set_err(PTL_ERR_ARG, "gn_workgroups too small for %d sequences", b->S);
+    const int gseq = batch_gseq(b), J = ic.gn_workgroups / 8;
+    if (gseq < 1 || gseq > J || gseq > 64) return set_err(PTL_ERR_ARG, "a team needs 1 .. min(64, gn_workgroups / 8 = %d) workgroups, not %d", J, gseq);
     if (b->S > 8 * SEQ_SLOTS) return set_err(PTL_ERR_ARG, "at most %d sequences", 8 * SEQ_SLOTS);
     int per_cu = 0, cus = 0;
     const bool p20 = ic.max_points_per_voxel == 20;
-    hipError_t e = gseq == 32 ? seq_run_occupancy<32>(p20, ic.gn_threads, &per_cu) : gseq == 16 ? seq_run_occupancy<16>(p20, ic.gn_threads, &per_cu)
-                 : gseq == 8 ? seq_run_occupancy<8>(p20, ic.gn_threads, &per_cu) : seq_run_occupancy<0>(p20, ic.gn_threads, &per_cu);
+    hipError_t e = hipSuccess;
+#define OCC(GC) e = seq_run_occupancy<GC>(p20, ic.gn_threads, &per_cu)
+    GC_DISPATCH(gseq, OCC);
+#undef OCC
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ic.device_id);
     if (e != hipSuccess) return set_err(PTL_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
     if ((int64_t)per_cu * cus < ic.gn_workgroups)
@@ -1365,6 +1380,7 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     b->S = n_sequences;
     b->stream = nullptr; b->d_ctx = nullptr; b->lut = nullptr; b->is_range = 0; b->d_bar = nullptr; b->d_sched = nullptr;
     b->free_running = cfg->icp.gn_lanes_per_point == 8;
+    b->team_wgs = 0; b->seq_run_checked = false;
     b->scans_per_launch = 256;
     b->next_scan = 0; b->n_out = 0; b->ctx_dirty = true; b->prof = false; b->ev_used = 0; b->gn_ms = 0; b->gn_launches = 0;
     for (int s = 0; s < GN_MAX_SEQ; ++s) {
@@ -1395,9 +1411,10 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
         if (rc == PTL_OK && hipMemset(b->d_imu_end[s], 0, (size_t)cfg->n_scans * sizeof(int)) != hipSuccess) rc = set_err(PTL_ERR_HIP, "memset failed");
         b->imu_end[s].assign((size_t)cfg->n_scans, 0);
     }
-    if (rc == PTL_OK && (dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess || dalloc(&b->d_bar, (size_t)GN_MAX_SEQ * 64) != hipSuccess || dalloc(&b->d_sched, (size_t)8) != hipSuccess))
+    if (rc == PTL_OK && (dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess || dalloc(&b->d_bar, (size_t)SEQ_MAX_TEAMS * 64) != hipSuccess || dalloc(&b->d_sched, (size_t)8) != hipSuccess))
         rc = set_err(PTL_ERR_HIP, "batch allocation failed");
-    if (rc == PTL_OK && b->free_running) rc = batch_check_seq_run(b);
+    // (the free-running driver's own limits - co-residency of the persistent grid, team size - are checked when that driver is
+    // chosen or first used: a batch that is switched to lockstep right after creation must not be refused on them)
     if (rc) { ptl_batch_destroy(b); return rc; }
     *out = b;
     return PTL_OK;
@@ -1443,8 +1460,9 @@ extern "C" int ptl_batch_upload_imu(ptl_batch* b, int32_t s, const double* imu, 
     return PTL_OK;
 }
 static int batch_push_ctx(ptl_batch* b) {
-    SeqCtx h[GN_MAX_SEQ];
-    memset(h, 0, sizeof h);
+    std::vector<SeqCtx> hv((size_t)GN_MAX_SEQ);
+    SeqCtx* h = hv.data();
+    memset(h, 0, sizeof(SeqCtx) * GN_MAX_SEQ);
     const bool with_ekf = b->cfg.with_ekf != 0;
     for (int s = 0; s < b->S; ++s) {
         Ctx c = b->icp[s]->c;
@@ -1462,7 +1480,7 @@ static int batch_push_ctx(ptl_batch* b) {
         h[s].ekf = b->ekf[s]->st; h[s].imu = b->d_imu[s]; h[s].imu_end = b->d_imu_end[s];
         h[s].res_poses = b->d_res_poses[s]; h[s].res_t = b->d_res_t[s]; h[s].rows = b->d_rows[s];
     }
-    HIPCHK(hipMemcpyAsync(b->d_ctx, h, sizeof h, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_ctx, h, sizeof(SeqCtx) * GN_MAX_SEQ, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     b->ctx_dirty = false;
     return PTL_OK;
@@ -1489,22 +1507,27 @@ static int batch_enqueue_free(ptl_batch* b, int64_t n) {
     const ptl_icp_cfg& ic = b->cfg.icp;
     hipStream_t st = b->stream;
     const int64_t end = b->next_scan + n;
+    if (!b->seq_run_checked) { int rc = batch_check_seq_run(b); if (rc) return rc; b->seq_run_checked = true; }
     while (b->next_scan < end) {
         const int64_t k0 = b->next_scan, k1 = (end - k0 > b->scans_per_launch) ? k0 + b->scans_per_launch : end;
         if (with_ekf) {  // IMU samples before the first scan of the launch that the filter has not seen (a run's first scan)
-            EkfBatchArgs ea;
-            memset(&ea, 0, sizeof ea);
-            bool any = false;
-            for (int s = 0; s < S; ++s) {
-                ea.e[s] = b->ekf[s]->st; ea.imu[s] = b->d_imu[s];
-                ea.i0[s] = (int)b->imu_pos[s]; ea.i1[s] = (int)b->imu_end[s][(size_t)k0];
-                any = any || ea.i1[s] > ea.i0[s];
-                if (b->imu_end[s][(size_t)k0] > b->imu_pos[s]) b->imu_pos[s] = b->imu_end[s][(size_t)k0];
+            for (int s0 = 0; s0 < S; s0 += EKF_MAX_SEQ) {  // (the argument block holds EKF_MAX_SEQ sequences)
+                EkfBatchArgs ea;
+                memset(&ea, 0, sizeof ea);
+                bool any = false;
+                const int ns = S - s0 < EKF_MAX_SEQ ? S - s0 : EKF_MAX_SEQ;
+                for (int q = 0; q < ns; ++q) {
+                    const int s = s0 + q;
+                    ea.e[q] = b->ekf[s]->st; ea.imu[q] = b->d_imu[s];
+                    ea.i0[q] = (int)b->imu_pos[s]; ea.i1[q] = (int)b->imu_end[s][(size_t)k0];
+                    any = any || ea.i1[q] > ea.i0[q];
+                    if (b->imu_end[s][(size_t)k0] > b->imu_pos[s]) b->imu_pos[s] = b->imu_end[s][(size_t)k0];
+                }
+                if (any) kb_ekf_step<<<ns, 384, 0, st>>>(ea);
             }
-            if (any) kb_ekf_step<<<S, 384, 0, st>>>(ea);
         }
-        HIPCHK(hipMemsetAsync(b->d_bar, 0, (size_t)GN_MAX_SEQ * 64 * sizeof(unsigned), st));
-        k_sched_init<<<1, 64, 0, st>>>(b->d_sched, S, (int)k0, (int)k1);
+        HIPCHK(hipMemsetAsync(b->d_bar, 0, (size_t)SEQ_MAX_TEAMS * 64 * sizeof(unsigned), st));
+        k_sched_init<<<1, 8 * SEQ_SLOTS, 0, st>>>(b->d_sched, S, (int)k0, (int)k1);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (b->prof) {
             if (b->ev_used + 2 > b->ev.size())
@@ -1515,10 +1538,11 @@ static int batch_enqueue_free(ptl_batch* b, int64_t n) {
         SeqRun r;
         r.S = S; r.k0 = (int)k0; r.k1 = (int)k1; r.with_ekf = with_ekf ? 1 : 0; r.rebuild_every = ic.rebuild_every;
         const int gseq = batch_gseq(b);
+        r.G = gseq;
         const bool p20 = ic.max_points_per_voxel == 20;
 #define KXR(GC) do { if (p20) kx_seq_run<20, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r, b->d_sched, b->d_bar); \
                      else kx_seq_run<0, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r, b->d_sched, b->d_bar); } while (0)
-        if (gseq == 32) KXR(32); else if (gseq == 16) KXR(16); else if (gseq == 8) KXR(8); else KXR(0);
+        GC_DISPATCH(gseq, KXR);
 #undef KXR
         if (b->prof) HIPCHK(hipEventRecord(e1, st));
         for (int s = 0; s < S; ++s) {
@@ -1536,9 +1560,34 @@ extern "C" int ptl_batch_set_driver(ptl_batch* b, int32_t free_running, int64_t 
     if (!b || scans_per_launch < 0) return set_err(PTL_ERR_ARG, "bad argument");
     if (b->next_scan != 0) return set_err(PTL_ERR_STATE, "choose the driver before the first scan of a run");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    if (scans_per_launch > 4096) return set_err(PTL_ERR_ARG, "scans_per_launch: at most 4096 (every wait inside the persistent kernel has a poll budget worth seconds, and a launch must stay well below it)");
     if (scans_per_launch > 0) b->scans_per_launch = scans_per_launch;
-    if (free_running) { int rc = batch_check_seq_run(b); if (rc) return rc; }
+    const bool was = b->free_running;
     b->free_running = free_running != 0;
+    b->seq_run_checked = false;
+    if (free_running) { int rc = batch_check_seq_run(b); if (rc) { b->free_running = was; return rc; } b->seq_run_checked = true; }
+    return PTL_OK;
+}
+// workgroups per team of the free-running kernel (0 = the default for the number of sequences, batch_gseq); before the first scan of a run
+extern "C" int ptl_batch_set_team_workgroups(ptl_batch* b, int32_t team_workgroups) {
+    if (!b || team_workgroups < 0) return set_err(PTL_ERR_ARG, "bad argument");
+    if (b->next_scan != 0) return set_err(PTL_ERR_STATE, "choose the team size before the first scan of a run");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    const int was = b->team_wgs;
+    b->team_wgs = team_workgroups;
+    b->seq_run_checked = false;
+    if (b->free_running) { int rc = batch_check_seq_run(b); if (rc) { b->team_wgs = was; return rc; } b->seq_run_checked = true; }
+    return PTL_OK;
+}
+extern "C" int ptl_batch_team_workgroups(ptl_batch* b, int32_t* team_workgroups, int32_t* teams) {
+    if (!b || !team_workgroups) return set_err(PTL_ERR_ARG, "null argument");
+    const int g = batch_gseq(b);
+    *team_workgroups = g;
+    if (teams) {  // teams that can get work: per XCD min(workgroups / team size, its sequences)
+        int n = 0;
+        for (int x = 0; x < 8 && x < b->S; ++x) { const int per = (b->cfg.icp.gn_workgroups / 8) / (g > 0 ? g : 1), ns = (b->S - x + 7) / 8; n += per < ns ? per : ns; }
+        *teams = n;
+    }
     return PTL_OK;
 }
 extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
@@ -1590,7 +1639,7 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
             const bool p20 = ic.max_points_per_voxel == 20;
 #define KX8(GC) do { if (p20) kx_gn_loop8<20, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki); \
                      else kx_gn_loop8<0, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki); } while (0)
-            if (gseq == 32) KX8(32); else if (gseq == 16) KX8(16); else if (gseq == 8) KX8(8); else KX8(0);
+            GC_DISPATCH(gseq, KX8);
 #undef KX8
         } else if (ic.max_points_per_voxel == 20) kx_gn_loop<20><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
         else kx_gn_loop<0><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, S, ki);
@@ -1704,6 +1753,15 @@ extern "C" int ptl_batch_seq_clocks(ptl_batch* b, int32_t s, int64_t out[8]) {
     long long h[8];
     HIPCHK(hipMemcpy(h, (char*)b->icp[s]->c.st + offsetof(DevState, seq_clk), sizeof h, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) out[i] = h[i];
+    return PTL_OK;
+}
+// executed-work counters of sequence s (DevState::exec_cnt), cumulative since the cold start
+extern "C" int ptl_batch_exec_counters(ptl_batch* b, int32_t s, uint64_t out[8]) {
+    if (!b || !out || s < 0 || s >= b->S) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    HIPCHK(hipStreamSynchronize(b->side));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(out, (char*)b->icp[s]->c.st + offsetof(DevState, exec_cnt), 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PTL_OK;
 }
 extern "C" int ptl_batch_gn_phases(ptl_batch* b, int64_t out[8]) {

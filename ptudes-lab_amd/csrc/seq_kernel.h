@@ -28,30 +28,56 @@
 
 // Barrier of the `n` workgroups of a team on a counter in device memory (zeroed by the host before the launch): the
 // k-th barrier is passed when the counter reaches k n (`target`, kept by the caller; only thread 0's copy counts).
-// Agent-scope release before the arrival and acquire after the last one: the stages exchange their data through plain
-// global memory.  A wait that exceeds TEAM_BAR_POLLS, or sees the sequence's abort word, raises ERR_GN_TIMEOUT and
-// returns false: the caller leaves the kernel (and so does, at its next barrier, every other workgroup of the team).
+// The stages exchange their data through plain global memory, so the barrier is a release / acquire pair:
+//   * `local` == false: agent-scope release before the arrival (on gfx950: `buffer_wbl2 sc1`, every dirty line of the XCD's L2
+//     goes out to memory - the only way another XCD sees the data) and an agent-scope acquire (`buffer_inv sc1`) after;
+//   * `local` == true - every workgroup of the team reported the same XCC_ID at the head of the launch (TeamEnv): they share
+//     one L2.  Every wavefront waits until the L2 has acknowledged its own stores (s_waitcnt vmcnt(0)), the arrival and the
+//     polls stay agent-scope atomics, the acquire stays (it empties the CU's vector L1): no write-back of the L2, which cost
+//     35 MB of HBM writes per scan (round 2's PMC pass) at ~14 barriers per scan.  tools/hip/sync_probe.hip measures both.
+// n == 1 (a team of one workgroup): a workgroup barrier.
+// A wait that exceeds TEAM_BAR_POLLS, or sees `*abort_word` set, returns false: the caller leaves the kernel (and so does, at
+// its next barrier, every other workgroup of the team).  With `st` given the expiry is an error of that sequence
+// (ERR_GN_TIMEOUT + its abort word); without (the job barrier: nobody is working on a sequence) only `*abort_word` goes up.
 #define TEAM_BAR_POLLS (1u << 23) /* polls with an s_sleep between them: several seconds of EXECUTED time (a wall-clock limit would fire
                                      falsely when the queue is time-sliced with another process's and the team sleeps in between) */
-__device__ __forceinline__ bool team_sync(unsigned* word, unsigned n, unsigned& target, DevState* st) {
+__device__ __forceinline__ bool team_sync(unsigned* word, unsigned n, unsigned& target, int* abort_word, DevState* st, const bool local) {
     __shared__ int s_bad;
+    if (n <= 1u) {  // one workgroup: its waves share the CU's L1, but atomics execute in the L2 behind it - same release / acquire, no counter
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        return true;
+    }
+    if (local) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     target += n;
     if (threadIdx.x == 0) {
         int bad = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (!local) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned polls = 0;
         while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if ((++polls & 255u) == 0u && (gn_abort_seen(&st->gn_abort) || polls > TEAM_BAR_POLLS)) { bad = 1; break; }
+            if ((++polls & 255u) == 0u && (gn_abort_seen(abort_word) || polls > TEAM_BAR_POLLS)) { bad = 1; break; }
         }
-        if (bad) gn_raise_abort(st);
+        if (bad) {
+            if (st) gn_raise_abort(st);
+            __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         s_bad = bad;
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return s_bad == 0;
+}
+// what a stage needs to synchronise its team: the barrier word, the team's size, the sequence's abort word, the mode
+struct TeamEnv { unsigned* word; int* abort_word; DevState* st; bool local; };
+__device__ __forceinline__ bool team_sync(const TeamEnv& e, unsigned n, unsigned& target) { return team_sync(e.word, n, target, e.abort_word, e.st, e.local); }
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xFu;
 }
 
 // The stages are separate (not inlined) functions: the Gauss-Newton loop and the filter step each need the whole register
@@ -71,52 +97,54 @@ __device__ __forceinline__ bool team_sync(unsigned* word, unsigned n, unsigned& 
 #define SQ_CLK(i) do { } while (0)
 #endif
 // K0-K4 of scan k by the team's `nw` working workgroups (this one is number `wg`); returns the barrier target, SEQ_FAIL on abort
-__device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, unsigned* word) {
+__device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, unsigned* word, bool local) {
     const Ctx c = load_seq_ctx(a, s, k);
     DevState* st = c.st;
     const int BS = (int)blockDim.x * SEQ_U, nbs = (c.n_in + BS - 1) / BS;
     Slice sl;
     sl.nb = nbs;
+    const TeamEnv te = {word, &st->gn_abort, st, local};
     SQ_CLK_DECL;
-    if (wg == 0 && st->pro_next != k + 1) d_scan_prologue(c);  // (with a filter it has usually been run already: sq_filter)
+    if (wg == 0 && st->pro_next != k + 1) d_scan_prologue(c, true);  // (with a filter it has usually been run already: sq_filter)
     SQ_CLK(0);
-    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(1);
     for (sl.b = wg; sl.b < nbs; sl.b += nw) d_deskew_vds1<SEQ_U>(c, sl);
     SQ_CLK(2);
-    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(3);
     for (sl.b = wg; sl.b < nbs; sl.b += nw) d_vds2<SEQ_U>(c, sl);
     SQ_CLK(4);
-    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(5);
     for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_fd<SEQ_U>(c, sl);
     SQ_CLK(6);
-    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(7);
     for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_src<SEQ_U>(c, sl);
     SQ_CLK(8);
     return target;
 }
 // K7-K11 of scan k
-__device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, int rebuild, unsigned* word) {
+__device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, int rebuild, unsigned* word, bool local) {
     const Ctx c = load_seq_ctx(a, s, k);
     DevState* st = c.st;
     const int BS = (int)blockDim.x, BU = BS * SEQ_U, nbd = (st->n_down_ins + BU - 1) / BU;
     Slice sl;
     sl.nb = nbd;
+    const TeamEnv te = {word, &st->gn_abort, st, local};
     SQ_CLK_DECL;
     for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_a<SEQ_U>(c, c.fd, &st->n_down_ins, 0, 1, sl);
     SQ_CLK(10);
-    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(11);
     for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_b<SEQ_U>(c, &st->n_down_ins, 0, sl);
     SQ_CLK(12);
-    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(13);
     for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_c<SEQ_U>(c, &st->n_down_ins, 0, sl);
     SQ_CLK(14);
-    if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+    if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(15);
     const int nbpu = (st->pool_hw + BU - 1) / BU;
     sl.nb = nbpu;
@@ -125,12 +153,12 @@ __device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, in
     const int nbp = (st->pool_hw + BS - 1) / BS;
     sl.nb = nbp;
     if (rebuild) {  // drop the tombstones: empty table, re-enter the live voxels
-        if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+        if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
         unsigned long long* tw = (unsigned long long*)c.tab;
         const size_t nwords = ((size_t)c.tmask + 1) * (sizeof(TabEnt) / 8);
         for (size_t i = (size_t)wg * BS + threadIdx.x; i < nwords; i += (size_t)nw * BS) tw[i] = ~0ull;
         if (wg == 0 && threadIdx.x == 0) st->tab_used = 0u;
-        if (!team_sync(word, (unsigned)nw, target, st)) return SEQ_FAIL;
+        if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
         for (sl.b = wg; sl.b < nbp; sl.b += nw) d_map_rebuild(c, sl);
     }
     return target;
@@ -151,38 +179,41 @@ __device__ __noinline__ void sq_filter(const SeqCtx* a, int s, int k) {
     if (k + 1 < my->n_scans) {
         __syncthreads();
         const Ctx c = load_seq_ctx(a, s, k + 1);
-        d_scan_prologue(c);
+        d_scan_prologue(c, true);
         __syncthreads();
         if (threadIdx.x == 0) c.st->pro_next = k + 2;
     }
 }
 
-struct SeqRun { int S, k0, k1, with_ekf, rebuild_every; };
+struct SeqRun { int S, k0, k1, with_ekf, rebuild_every, G; };  // G: workgroups per team (run-time value; the GC instances fix it at compile time)
 
 // scheduler state of one XCD's sequences (slot q <-> sequence x + 8 q): the next scan of each and whether a team is on it
-#define SEQ_SLOTS 8
-struct SeqSched { int next_scan[SEQ_SLOTS]; int busy[SEQ_SLOTS]; int pad[16]; };  // 128 B
+#define SEQ_SLOTS 32
+struct SeqSched { int next_scan[SEQ_SLOTS]; int busy[SEQ_SLOTS]; };  // 256 B
 __global__ void k_sched_init(SeqSched* sc, int S, int k0, int k1) {
-    const int x = threadIdx.x >> 3, q = threadIdx.x & 7;
+    const int x = threadIdx.x / SEQ_SLOTS, q = threadIdx.x % SEQ_SLOTS;
     if (x >= 8) return;
     sc[x].next_scan[q] = (x + 8 * q < S) ? k0 : k1;
     sc[x].busy[q] = 0;
 }
-// The team leader's choice: the sequence of this XCD with the fewest scans done that nobody is working on, or -1 when
-// every sequence has reached k1 (or nothing came free for a long time: a team that left its sequence marked busy).
-__device__ __forceinline__ int sched_pick(SeqSched* sc, int k1, int* scan_out) {
-    unsigned polls = 0;
-    for (;;) {
+// The team leader's choice: the sequence of this XCD with the fewest scans done that nobody is working on.  Returns its slot,
+// SCHED_DONE when every sequence of the XCD has reached k1, SCHED_RETRY when all that is left is in other teams' hands right
+// now (after a short bounded wait: the caller goes round its team barrier and asks again, so no wait in the kernel is long
+// enough to outlast a teammate's poll budget).
+#define SCHED_DONE (-1)
+#define SCHED_RETRY (-2)
+#define SCHED_POLLS 256
+__device__ __forceinline__ int sched_pick(SeqSched* sc, int nslots, int k1, int* scan_out) {
+    for (unsigned polls = 0; polls < SCHED_POLLS; ++polls) {
         int best = -1, bestk = 0x7FFFFFFF;
         bool pending = false;
-#pragma unroll
-        for (int q = 0; q < SEQ_SLOTS; ++q) {
+        for (int q = 0; q < nslots; ++q) {
             const int k = __hip_atomic_load(&sc->next_scan[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (k >= k1) continue;
             pending = true;
-            if (__hip_atomic_load(&sc->busy[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && k < bestk) { best = q; bestk = k; }
+            if (k < bestk && __hip_atomic_load(&sc->busy[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { best = q; bestk = k; }
         }
-        if (!pending) return -1;
+        if (!pending) return SCHED_DONE;
         if (best >= 0 && atomicCAS(&sc->busy[best], 0, 1) == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the team that ran the previous scan wrote
             const int k = __hip_atomic_load(&sc->next_scan[best], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -190,71 +221,105 @@ __device__ __forceinline__ int sched_pick(SeqSched* sc, int k1, int* scan_out) {
             __hip_atomic_store(&sc->busy[best], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (finished meanwhile)
             continue;
         }
-        if (++polls > TEAM_BAR_POLLS / 4) return -1;
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(16);
     }
+    return SCHED_RETRY;
 }
 __device__ __forceinline__ void sched_release(SeqSched* sc, int q, int next_scan) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (always the full release: the next scan may run on any team - any XCD as far as this protocol knows)
     __hip_atomic_store(&sc->next_scan[q], next_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&sc->busy[q], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a team that gives up on its sequence (abort word, poll budget) takes it off the schedule: nobody waits for its remaining scans
+__device__ __forceinline__ void sched_abandon(SeqSched* sc, int q, int k1) {
+    __hip_atomic_store(&sc->next_scan[q], k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-// bar: per team 64 words - [0] barrier of the whole team, [32] of its working workgroups, [40], [41] the leader's job (sequence, scan)
+// bar: per team 64 words - [0] barrier of the whole team, [32] of its working workgroups, [40], [41] the leader's job (sequence,
+// scan), [42] the XCC ids its workgroups reported (one bit each), [43] the team's own abort word (the job barrier)
+#define SEQ_MAX_TEAMS 512
+#define JOB_DONE 0xFFFFFFFFu
+#define JOB_RETRY 0xFFFFFFFEu
+#define TEAM_IDLE_ROUNDS (1u << 20)  /* rounds of SCHED_POLLS polls a team keeps asking for work before it leaves quietly */
 template <int PC, int GC>
 __global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, SeqRun r, SeqSched* sched, unsigned* bar) {
     const int x = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3), J = (int)(gridDim.x >> 3);
-    const int G = GC > 0 ? GC : J / (r.S <= 8 ? 1 : (r.S <= 16 ? 2 : 4));
+    const int G = GC > 0 ? GC : r.G;
     const int t = j / G, wg = j % G;
-    if (x >= r.S || (t + 1) * G > J) return;  // no sequence on this XCD / a workgroup beyond the last whole team
+    const int nslots = (r.S - x + 7) >> 3;  // sequences of this XCD: x, x + 8, ...
+    // no sequence on this XCD / a workgroup beyond the last whole team / a team that can never be needed (more teams than sequences)
+    if (x >= r.S || (t + 1) * G > J || t >= nslots) return;
     unsigned* tb = bar + (size_t)(x + 8 * t) * 64;
     SeqSched* sc = sched + x;
     // with a filter, the team's last workgroup is the filter workgroup: after the Gauss-Newton loop it steps the filter
-    // while the others update the map (and is back, waiting, long before they are done); K0-K4 are everybody's
-    const bool fwg = r.with_ekf && wg == G - 1;
-    const int nw = r.with_ekf ? G - 1 : G;
+    // while the others update the map (and is back, waiting, long before they are done); K0-K4 are everybody's.  A team of
+    // one workgroup does both, one after the other.
+    const bool solo = G == 1;
+    const bool fwg = r.with_ekf && !solo && wg == G - 1;
+    const int nw = (r.with_ekf && !solo) ? G - 1 : G;
     unsigned t_all = 0u, t_work = 0u;
-    const bool lead = wg == 0 && threadIdx.x == 0, clkf = fwg && threadIdx.x == 0;
-    DevState* st = a[x].c.st;  // (any state of this XCD for the abort word of the first barrier)
+    const bool lead = wg == 0 && threadIdx.x == 0, clkf = (fwg || (solo && r.with_ekf)) && threadIdx.x == 0;
+    int* team_abort = (int*)&tb[43];
+    // do the team's workgroups share one L2?  Everybody reports its XCC_ID, one full (agent-scope) barrier, everybody reads the
+    // mask: one bit set = one XCD = the barriers from here on need no L2 write-back (team_sync).  Any other placement - the
+    // dispatch order is not specified - keeps the agent-scope protocol.
+    bool local = solo;
+    if (!solo) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(&tb[42], 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!team_sync(tb, (unsigned)G, t_all, team_abort, nullptr, false)) return;
+        const unsigned m = __hip_atomic_load(&tb[42], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        local = (m & (m - 1u)) == 0u;
+    }
     int q_mine = -1, k_mine = 0;
+    unsigned idle = 0u;
     for (;;) {
         if (lead) {  // hand the finished scan back, take the next job
             if (q_mine >= 0) sched_release(sc, q_mine, k_mine + 1);
             int k = 0;
-            const int q = sched_pick(sc, r.k1, &k);
+            const int q = sched_pick(sc, nslots, r.k1, &k);
             q_mine = q; k_mine = k;
-            __hip_atomic_store(&tb[40], (unsigned)(q < 0 ? 0xFFFFFFFFu : (unsigned)(x + 8 * q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&tb[40], q == SCHED_DONE ? JOB_DONE : q == SCHED_RETRY ? JOB_RETRY : (unsigned)(x + 8 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&tb[41], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (!team_sync(tb, (unsigned)G, t_all, st)) return;
+        // the job barrier: nobody is on a sequence here, so an expiry (a teammate that never came) is the team's own affair
+        if (!team_sync(tb, (unsigned)G, t_all, team_abort, nullptr, local)) return;
         const unsigned job = __hip_atomic_load(&tb[40], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (job == 0xFFFFFFFFu) return;
+        if (job == JOB_DONE) return;
+        if (job == JOB_RETRY) { if (++idle > TEAM_IDLE_ROUNDS) return; continue; }
+        idle = 0u;
         const int s = (int)job, k = (int)__hip_atomic_load(&tb[41], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int q = s >> 3;
         const SeqCtx* my = a + s;
-        st = my->c.st;
+        DevState* st = my->c.st;
+        const TeamEnv te = {tb, &st->gn_abort, st, local};
+        // (every exit below takes the sequence off the schedule first: the other teams must not wait for scans nobody will run)
+#define SEQ_LEAVE do { if (threadIdx.x == 0) sched_abandon(sc, q, r.k1); return; } while (0)
         const long long c0 = (long long)wall_clock64();
-        t_all = sq_prepare(a, s, k, wg, G, t_all, tb);  // (all G workgroups: the filter workgroup has nothing else to do here)
-        if (t_all == SEQ_FAIL) return;
+        t_all = sq_prepare(a, s, k, wg, G, t_all, tb, local);  // (all G workgroups: the filter workgroup has nothing else to do here)
+        if (t_all == SEQ_FAIL) SEQ_LEAVE;
         const long long c1 = (long long)wall_clock64();
-        if (!team_sync(tb, (unsigned)G, t_all, st)) return;  // source ready (map and filter: complete since the scan before)
+        if (!team_sync(te, (unsigned)G, t_all)) SEQ_LEAVE;  // source ready (map and filter: complete since the scan before)
         const long long c2 = (long long)wall_clock64();
         sq_gauss_newton<PC, GC>(a, s, k, G, wg);
-        if (gn_abort_seen(&st->gn_abort)) return;
+        if (gn_abort_seen(&st->gn_abort)) SEQ_LEAVE;
         const long long c3 = (long long)wall_clock64();
-        if (!team_sync(tb, (unsigned)G, t_all, st)) return;  // new pose, trajectory row
+        if (!team_sync(te, (unsigned)G, t_all)) SEQ_LEAVE;  // new pose, trajectory row
         const long long c4 = (long long)wall_clock64();
+        long long c5f = c4;
         if (fwg) {
             sq_filter(a, s, k);
         } else {
-            t_work = sq_map_update(a, s, k, wg, nw, t_work, (r.rebuild_every > 0 && ((k + 1) % r.rebuild_every) == 0) ? 1 : 0, tb + 32);
-            if (t_work == SEQ_FAIL) return;
+            t_work = sq_map_update(a, s, k, wg, nw, t_work, (r.rebuild_every > 0 && ((k + 1) % r.rebuild_every) == 0) ? 1 : 0, tb + 32, local);
+            if (t_work == SEQ_FAIL) SEQ_LEAVE;
+            if (solo && r.with_ekf) { c5f = (long long)wall_clock64(); sq_filter(a, s, k); }
         }
         const long long c5 = (long long)wall_clock64();
         if (lead) {
             st->seq_clk[0] += c1 - c0; st->seq_clk[1] += c2 - c1; st->seq_clk[2] += c3 - c2; st->seq_clk[3] += c4 - c3; st->seq_clk[4] += c5 - c4;
             st->seq_clk[6] += 1;
         }
-        if (clkf) st->seq_clk[5] += c5 - c4;
-        if (!team_sync(tb, (unsigned)G, t_all, st)) return;  // the scan is complete: the sequence may go to another team
+        if (clkf) st->seq_clk[5] += c5 - c5f;
+        if (!team_sync(te, (unsigned)G, t_all)) SEQ_LEAVE;  // the scan is complete: the sequence may go to another team
+#undef SEQ_LEAVE
     }
 }

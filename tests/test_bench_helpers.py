@@ -22,7 +22,7 @@ def _bench():
 
 def _args(**over):
     a = dict(rows=128, cols=1024, min_range=1.0, max_range=70.0, voxel_size=0.0, seed_base=1000, warmup=20, steps=200,
-             const_velocity=False, icp_only=False, gn_lanes=0, lockstep=False)
+             const_velocity=False, icp_only=False, gn_lanes=0, lockstep=False, gn_wgs=0, gn_threads=0, team_wgs=0)
     a.update(over)
     return types.SimpleNamespace(**a)
 
@@ -30,18 +30,26 @@ def _args(**over):
 def test_roofline_traffic_only_from_a_pmc_pass_of_the_same_workload(tmp_path, monkeypatch):
     b = _bench()
     k16, k8 = b.workload_key(_args(), 16), b.workload_key(_args(), 8)
-    assert k16 != k8 and b.workload_key(_args(steps=60), 16) != k16 and b.workload_key(_args(voxel_size=0.1), 16) != k16
+    assert k16 != k8 and b.workload_key(_args(voxel_size=0.1), 16) != k16
     assert b.workload_key(_args(gn_lanes=8), 1) != b.workload_key(_args(), 1)
     # the driver is part of the workload: counters of the lockstep Gauss-Newton launches say nothing about the free-running kernel
-    assert k16.endswith("_free") and b.workload_key(_args(lockstep=True), 16) == k16[:-len("_free")]
-    assert not b.workload_key(_args(), 1).endswith("_free") and not b.workload_key(_args(gn_lanes=32), 16).endswith("_free")
+    lock16 = b.workload_key(_args(lockstep=True), 16)
+    assert "_free" in k16 and "_free" not in lock16
+    assert "_free" not in b.workload_key(_args(), 1) and "_free" not in b.workload_key(_args(gn_lanes=32), 16)
+    # per-launch kernels: warm-up and step counts decide what the timed launches see.  The free-running kernel's summaries are per
+    # scan: the same workload at another step count (the driver's --steps 20 --warmup 5) finds them - the team geometry must match
+    assert b.workload_key(_args(lockstep=True, steps=60), 16) != lock16 and b.workload_key(_args(lockstep=True, warmup=5), 16) != lock16
+    assert b.workload_key(_args(steps=20, warmup=5), 16) == k16
+    assert b.workload_key(_args(team_wgs=4), 16) != k16 and b.workload_key(_args(gn_threads=256, gn_wgs=512), 16) != k16
     prof = tmp_path / "profiles"
     prof.mkdir()
-    (prof / "r09_x_pmc_hbm_traffic_a.json").write_text(json.dumps({"workload_key": k8, "traffic_bytes_per_launch": 1.0e9}))
+    (prof / "r09_x_pmc_hbm_traffic_a.json").write_text(json.dumps({"workload_key": lock16, "traffic_bytes_per_launch": 1.0e9}))
+    (prof / "r09_x_pmc_hbm_traffic_b.json").write_text(json.dumps({"workload_key": k8, "traffic_bytes_per_launch": 9.6e11, "traffic_bytes_per_scan": 1.0e8}))
     (prof / "r01_n_pmc_hbm_traffic.json").write_text(json.dumps({"k_gn_loop_traffic_bytes_per_launch": 2.5e7}))  # round-1 form: no key
     monkeypatch.setattr(b, "ROOT", str(tmp_path))
-    assert b.pmc_traffic_for(k8) == (1.0e9, "r09_x_pmc_hbm_traffic_a.json")
-    assert b.pmc_traffic_for(k16) is None  # another workload's counters are not this run's
+    assert b.pmc_traffic_for(lock16) == (1.0e9, "r09_x_pmc_hbm_traffic_a.json")
+    assert b.pmc_traffic_for(k8, scans_per_launch=160) == (1.6e10, "r09_x_pmc_hbm_traffic_b.json")  # 8 sequences x 20 steps in one launch
+    assert b.pmc_traffic_for(k16, scans_per_launch=320) is None  # another workload's counters are not this run's
 
 
 def test_committed_pmc_summaries_name_their_workload():
@@ -60,6 +68,23 @@ def test_scan_and_icp_byte_models_follow_survey_8d():
     n_raw = 131072
     assert b.scan_bytes(st, n_raw) == (12 * n_raw + 12 * 100000) + ((12 + 16) * 100000 + 12 * 30000 + (12 + 16) * 30000 + 12 * 1000) \
         + b.icp_bytes(st) + ((12 + 16 + 12) * 30000 + (16 + 12) * 20000)
+
+
+def test_executed_byte_model():
+    """the as-executed model of the free-running kernel: unit costs x the kernel's counters + the per-scan statistics"""
+    b = _bench()
+    c = b.EXEC_COST
+    cnt = dict(searches=100, rows_rebuilt=10, map_points_read=5000, gn_iterations=7, vds1_claims=300, vds2_claims=40, point_iterations=7000, scans=1)
+    st = [dict(iterations=7, n_src=1000, n_valid=100000, n_down=30000, map_voxels=20000)]
+    tot, gn, stages = b.executed_bytes(cnt, st, 131072, 8, 1024)
+    assert gn == 48 * 7000 + 104 * 6000 + c["search"] * 100 + c["row_rebuilt"] * 10 + 24 * 5000 + 7 * 8 * 9 * 36 * 8
+    assert stages == c["raw_point"] * 131072 + c["valid_point"] * 100000 + c["down_point"] * 30000 + c["source_point"] * 1000 \
+        + 32 * 20000 + 96 * 1024 + 24 * 340
+    assert tot == gn + stages
+    # a first scan (empty map: no iteration) costs its stages only
+    tot0, gn0, _ = b.executed_bytes(dict(cnt, searches=0, rows_rebuilt=0, map_points_read=0, gn_iterations=0, point_iterations=0),
+                                    [dict(st[0], iterations=0)], 131072, 8, 1024)
+    assert gn0 == 0 and tot0 == stages
 
 
 def test_pose_rows_round_trip():
@@ -95,7 +120,7 @@ def test_pmc_summary_takes_the_timed_launches_of_the_dominant_kernel(tmp_path):
     timed launch's (the last `roofline.launches` dispatches), fetch side doubled (gfx950), write side as reported"""
     import subprocess
     import sys
-    line = {"value": 1.0, "steps": 200, "config": {"workload_key": "K"}, "roofline": {"kernel": "kx_seq_run", "launches": 1}}
+    line = {"value": 1.0, "steps": 200, "config": {"workload_key": "K"}, "roofline": {"kernel": "kx_seq_run", "launches": 1, "scans_per_launch": 9600.0}}
     (tmp_path / "line.json").write_text("some library noise\n" + json.dumps(line) + "\n")
     for name, vals in (("FETCH_SIZE", (10.0, 100.0)), ("WRITE_SIZE", (4.0, 40.0))):
         d = tmp_path / name / "x"
@@ -113,3 +138,4 @@ def test_pmc_summary_takes_the_timed_launches_of_the_dominant_kernel(tmp_path):
     assert r["workload_key"] == "K" and r["dominant_kernel"] == "kx_seq_run"
     assert r["FETCH_SIZE_timed"] == {"launches": 1, "mean_per_launch_KB": 100.0}
     assert r["traffic_bytes_per_launch"] == 2 * 100.0 * 1024 + 40.0 * 1024
+    assert r["traffic_bytes_per_scan"] == (2 * 100.0 * 1024 + 40.0 * 1024) / 9600.0

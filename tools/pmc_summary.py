@@ -8,7 +8,8 @@ FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  On gfx950 FETCH_SIZE t
 wide coalesced reads (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): the fetch side is doubled (an upper
 bound for this kernel's 8-byte gathers, an uncalibrated width) and WRITE_SIZE is taken as reported.
 The per-launch figure of the dominant kernel is the mean over its launches of the TIMED region - the last `steps`
-launches (the free-running kernel: the last `roofline.launches`, a launch carries many scans) - not the warm-up's."""
+launches (the free-running kernel: the last `roofline.launches`, a launch carries many scans) - not the warm-up's.
+For the free-running kernel the summary also records bytes per scan (per launch / the line's roofline.scans_per_launch)."""
 import collections
 import csv
 import glob
@@ -52,5 +53,16 @@ if ft.get("mean_per_launch_KB") is not None:
     out["hbm_bytes_per_launch"] = {"kernel": dom, "fetch_reported": fk, "fetch_x2_gfx950": 2 * fk, "write_reported": wk,
                                    "total_corrected": 2 * fk + wk}
     out["traffic_bytes_per_launch"] = 2 * fk + wk  # what bench.py reports as roofline.traffic for this workload
+    # the free-running kernel: one launch carries the whole run, so the figure that carries over to another step count of the same
+    # workload is bytes per SCAN (bench.py scales it by its own scans per launch)
+    try:
+        spl = line["roofline"].get("scans_per_launch")
+        if dom == "kx_seq_run" and spl:
+            out["scans_per_launch"] = spl
+            out["traffic_bytes_per_scan"] = (2 * fk + wk) / spl
+            out["fetch_x2_bytes_per_scan"] = 2 * fk / spl
+            out["write_bytes_per_scan"] = wk / spl
+    except Exception:  # noqa: BLE001
+        pass
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps({k: out.get(k) for k in ("workload_key", "hbm_bytes_per_launch")}))
