@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libptudes_mi.so")
+# PTL_LIB_PATH: a diagnostic / experiment build of the same library (csrc/Makefile: make OUT=... PHASES=1 ...), A/B runs on the GPU box
+LIB_PATH = os.environ.get("PTL_LIB_PATH") or os.path.join(_HERE, "csrc", "libptudes_mi.so")
 
 PTL_F32, PTL_F64 = 0, 1
 c_d_p = C.POINTER(C.c_double)

@@ -14,10 +14,10 @@
 //
 // Data layout in HBM (all fp64 coordinates, as the reference):
 //   points            AoS double[3] per point (24 B), scan order (row-major beam-outer)
-//   VDS hash tables   u64 packed voxel key + u32 "smallest claiming point index" per slot
-//   local map table   16-B entries {u64 key, i32 block, i32 batch list head}, open addressing, linear probe
-//   local map blocks  one 128-B-aligned block per voxel: x[P] | y[P] | z[P] | {i32 count, i32 slot}
-//                     (P = 20 -> 512 B = four cache lines; lanes read x[j], y[j], z[j] coalesced)
+//   VDS hash tables   16-byte entries {u64 packed voxel key, u32 smallest claiming point index}, 2x2x2 voxel bricks per 128-byte line
+//   local map table   16-B entries {u64 key, i32 block, i32 batch list head}, open addressing, linear probe, 2x2x2 voxel bricks per line
+//   local map blocks  one 128-B-aligned block per voxel: {i32 count, i32 slot, pad} | (x, y, z)[P]
+//                     (P = 20 -> 512 B = four cache lines; a typical voxel's 7-8 points + header: its first two)
 // Deterministic semantics shared with the CPU oracle: first point per voxel in scan order, voxel keeps
 // its first P points in scan order, nearest neighbour = strictly-smaller distance in (voxel i,j,k
 // ascending, insertion order) candidate order, voxel index by truncation toward zero.
@@ -43,6 +43,12 @@ struct TabEnt {
 };
 #define BLK_ID_MASK 0x00FFFFFF
 
+// per-scan voxel-downsampling table: the voxel and the smallest point index that maps to it, one line for claim and bid
+struct VdsEnt {
+    unsigned long long key;
+    unsigned vmin;
+    unsigned pad;
+};
 struct ScanStats {  // mirrors ptl_icp_stats
     double sigma, err_dt, err_drot;
     int iterations, n_corr_last;
@@ -109,8 +115,7 @@ struct Ctx {
     // scan work buffers
     double* pts;
     int *slot1, *slot2;
-    unsigned long long *vkey1, *vkey2;
-    unsigned *vmin1, *vmin2;
+    VdsEnt *vtab1, *vtab2;
     unsigned vmask;
     int *bcnt1, *bcnt2;
     double *fd, *src0, *src_cur, *fdw;
@@ -139,16 +144,30 @@ struct Ctx {
     int traj_cap;
 };
 
+// One block per voxel: a 16-byte header {i32 count, i32 table slot, pad} and then the stored points as (x, y, z) triples,
+// point j at blk_x()[3 j .. 3 j + 2].  HBM serves whole 128-byte lines (tools/hip/gather_probe.hip: a scattered 8-byte read
+// costs as much bandwidth as a full line), and a voxel holds 7-8 points on average: header + points of a typical voxel
+// sit in its first two lines, a voxel of <= 4 points and the first point every prune pass looks at in the first one.
+// (Round 1-2 kept x[P] | y[P] | z[P] | header: three to four lines per visit, four per pruned block.)
+#define BLK_HDR_BYTES 16
 template <class CT>
-__device__ __forceinline__ double* blk_x(const CT& c, int b) { return (double*)(c.blocks + (size_t)b * c.bstride); }
+__device__ __forceinline__ double* blk_x(const CT& c, int b) { return (double*)(c.blocks + (size_t)b * c.bstride + BLK_HDR_BYTES); }
 template <class CT>
-__device__ __forceinline__ int* blk_hdr(const CT& c, int b) {
-    return (int*)(c.blocks + (size_t)b * c.bstride + (size_t)c.P * 24);
-}
+__device__ __forceinline__ int* blk_hdr(const CT& c, int b) { return (int*)(c.blocks + (size_t)b * c.bstride); }
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long h) {
     h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;
     return h;
+}
+// Slot of a voxel in an open-addressing table of 16-byte entries: the 2 x 2 x 2 brick of voxels that agree in all but the
+// lowest bit of each (offset) index occupies 8 consecutive entries = one 128-byte line, and the bricks are scattered by the
+// hash.  A 27-voxel neighbourhood then touches at most 8 lines instead of 27, consecutive returns of a beam (neighbouring
+// voxels) meet in the same lines, and every line that arrives carries up to 8 useful entries - HBM moves whole lines
+// whatever a lane asks for.  Linear probing walks on from there as before.
+__device__ __forceinline__ unsigned brick_slot(unsigned long long key, unsigned mask) {
+    const unsigned long long low = (1ull << 42) | (1ull << 21) | 1ull;
+    const unsigned fine = (unsigned)(((key >> 42) & 1ull) << 2 | ((key >> 21) & 1ull) << 1 | (key & 1ull));
+    return (((unsigned)mix64(key & ~low) << 3) | fine) & mask;
 }
 // voxel index by C truncation toward zero, exactly (int)(coordinate / voxel_size)
 __device__ __forceinline__ bool vox_key(V3 p, double size, unsigned long long& key, int& kx, int& ky, int& kz) {
@@ -164,15 +183,15 @@ __device__ __forceinline__ unsigned long long pack_key(int kx, int ky, int kz) {
 }
 
 // find-or-claim a slot for `key` in a per-scan VDS table; returns slot or -1 when the table is full
-__device__ __forceinline__ int vds_claim(unsigned long long* keys, unsigned mask, unsigned long long key) {
-    unsigned s = (unsigned)mix64(key) & mask;
+__device__ __forceinline__ int vds_claim(VdsEnt* tab, unsigned mask, unsigned long long key) {
+    unsigned s = brick_slot(key, mask);
     for (unsigned probe = 0; probe <= mask; ++probe) {
         // A plain (L2-cached) read: within a kernel a slot only ever goes EMPTY -> key, so the worst a stale line can
         // show is EMPTY, and then the CAS below - performed at device scope - decides.
-        unsigned long long cur = keys[s];
+        unsigned long long cur = tab[s].key;
         if (cur == key) return (int)s;
         if (cur == EMPTY_KEY) {
-            unsigned long long old = atomicCAS(&keys[s], EMPTY_KEY, key);
+            unsigned long long old = atomicCAS(&tab[s].key, EMPTY_KEY, key);
             if (old == EMPTY_KEY || old == key) return (int)s;
         }
         s = (s + 1) & mask;
@@ -349,47 +368,47 @@ __global__ __launch_bounds__(256) void k_build_lut(int H, int W, const double* a
 // CU alone hides memory latency only with independent accesses of its own, so the U points of a thread go through every
 // step together: U loads in flight, then U hash probes, then U atomics.  Every thread of the workgroup calls the body (it
 // contains workgroup barriers).
-struct Slice { int b, nb; };
-__device__ __forceinline__ Slice launch_slice() { Slice s; s.b = (int)blockIdx.x; s.nb = (int)gridDim.x; return s; }
+struct Slice { int b, nb, clk; };  // clk: this caller's thread 0 records the stage-internal clocks (make STAGES=1)
+__device__ __forceinline__ Slice launch_slice() { Slice s; s.b = (int)blockIdx.x; s.nb = (int)gridDim.x; s.clk = 0; return s; }
 #define STAGE_MAX_WAVES 16  /* blockDim.x <= 1024 */
 #define STAGE_MAX_U 8
 
 // U find-or-claims in a per-scan VDS table with their probes in flight together: the hashed slot of each (one load; one
 // compare-and-swap where it was empty), and whatever that does not settle (a collision) goes through vds_claim
 template <int U>
-__device__ __forceinline__ void vds_claim_u(unsigned long long* keys, unsigned mask, const unsigned long long (&key)[U], const bool (&want)[U],
+__device__ __forceinline__ void vds_claim_u(VdsEnt* tab, unsigned mask, const unsigned long long (&key)[U], const bool (&want)[U],
                                             int (&slot)[U]) {
     unsigned s0[U];
     unsigned long long cur[U], old[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        s0[u] = (unsigned)mix64(key[u]) & mask;
-        cur[u] = want[u] ? keys[s0[u]] : key[u];
+        s0[u] = brick_slot(key[u], mask);
+        cur[u] = want[u] ? tab[s0[u]].key : key[u];
         slot[u] = -1;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         old[u] = key[u];
-        if (want[u] && cur[u] == EMPTY_KEY) old[u] = atomicCAS(&keys[s0[u]], EMPTY_KEY, key[u]);
+        if (want[u] && cur[u] == EMPTY_KEY) old[u] = atomicCAS(&tab[s0[u]].key, EMPTY_KEY, key[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (!want[u]) continue;
         if (cur[u] == key[u] || (cur[u] == EMPTY_KEY && (old[u] == EMPTY_KEY || old[u] == key[u]))) slot[u] = (int)s0[u];
-        else slot[u] = vds_claim(keys, mask, key[u]);
+        else slot[u] = vds_claim(tab, mask, key[u]);
     }
 }
 // the claimed slots' bids: slot value = the smallest point index that maps to the voxel
 template <int U>
-__device__ __forceinline__ void vds_bid_u(unsigned* vmin, const int (&slot)[U], const bool (&want)[U], const int (&idx)[U], int* err_flags) {
+__device__ __forceinline__ void vds_bid_u(VdsEnt* tab, const int (&slot)[U], const bool (&want)[U], const int (&idx)[U], int* err_flags) {
     unsigned cur[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = (want[u] && slot[u] >= 0) ? vmin[slot[u]] : 0u;  // plain read: a stale (larger) value only costs a redundant atomicMin
+    for (int u = 0; u < U; ++u) cur[u] = (want[u] && slot[u] >= 0) ? tab[slot[u]].vmin : 0u;  // plain read: a stale (larger) value only costs a redundant atomicMin
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (!want[u]) continue;
         if (slot[u] < 0) atomicOr(err_flags, ERR_VDS_TABLE);
-        else if (cur[u] > (unsigned)idx[u]) atomicMin(&vmin[slot[u]], (unsigned)idx[u]);  // the slot's value only ever decreases: a smaller one seen = nothing to do
+        else if (cur[u] > (unsigned)idx[u]) atomicMin(&tab[slot[u]].vmin, (unsigned)idx[u]);  // the slot's value only ever decreases: a smaller one seen = nothing to do
     }
 }
 // number of set flags over the workgroup's U * blockDim.x points (every thread gets it)
@@ -419,7 +438,7 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
     DevState* st = c.st;
 #ifdef SEQ_STAGE_CLOCKS
     long long k1_t = (long long)wall_clock64();
-    const bool k1_me = U > 1 && sl.b % 15 == 0 && threadIdx.x == 0;  // (workgroup 0 of a team of 15 workers)
+    const bool k1_me = sl.clk != 0 && threadIdx.x == 0;  // (workgroup 0 of the team)
 #endif
     const int prev_n_in = st->prev_n_in, do_deskew = st->do_deskew;
     int idx[U];
@@ -432,7 +451,7 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
         for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s2[u] = (idx[u] < prev_n_in) ? c.slot2[idx[u]] : -1; }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (s2[u] >= 0) { c.vkey2[s2[u]] = EMPTY_KEY; c.vmin2[s2[u]] = 0xFFFFFFFFu; }
+            if (s2[u] >= 0) { c.vtab2[s2[u]].key = EMPTY_KEY; c.vtab2[s2[u]].vmin = 0xFFFFFFFFu; }
             if (idx[u] >= c.n_in && idx[u] < prev_n_in) c.slot2[idx[u]] = -1;
         }
     }
@@ -500,7 +519,7 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
             const bool prev_keyed = __shfl_up(keyed[u] ? 1 : 0, 1) != 0;
             head[u] = keyed[u] && (lane == 0 || !prev_keyed || prev != key[u]);
         }
-        vds_claim_u<U>(c.vkey1, c.vmask, key, head, slot);
+        vds_claim_u<U>(c.vtab1, c.vmask, key, head, slot);
         {   // executed-work counter: voxel claims (one per run head)
             int nh = 0;
 #pragma unroll
@@ -508,7 +527,7 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
             if (lane == 0 && nh) atomicAdd(&st->exec_cnt[4], (unsigned long long)nh);
         }
         K1_CLK(22);
-        vds_bid_u<U>(c.vmin1, slot, head, idx, &st->err_flags);
+        vds_bid_u<U>(c.vtab1, slot, head, idx, &st->err_flags);
         K1_CLK(23);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -537,7 +556,7 @@ __device__ __forceinline__ void d_vds2(const Ctx& c, const Slice sl) {
     {
         unsigned vm[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) vm[u] = (s1[u] >= 0) ? c.vmin1[s1[u]] : 0u;
+        for (int u = 0; u < U; ++u) vm[u] = (s1[u] >= 0) ? c.vtab1[s1[u]].vmin : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) w1[u] = (s1[u] >= 0) && (vm[u] == (unsigned)idx[u]);
     }
@@ -566,14 +585,14 @@ __device__ __forceinline__ void d_vds2(const Ctx& c, const Slice sl) {
             const unsigned long long prev_key = __shfl(key[u], prev_lane);
             head[u] = w1[u] && (!before || prev_key != key[u]);
         }
-        vds_claim_u<U>(c.vkey2, c.vmask, key, head, slot);
+        vds_claim_u<U>(c.vtab2, c.vmask, key, head, slot);
         {
             int nh = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) nh += __popcll(__ballot(head[u]));
             if (lane == 0 && nh) atomicAdd(&c.st->exec_cnt[5], (unsigned long long)nh);
         }
-        vds_bid_u<U>(c.vmin2, slot, head, idx, &c.st->err_flags);
+        vds_bid_u<U>(c.vtab2, slot, head, idx, &c.st->err_flags);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned long long heads = __ballot(head[u]);
@@ -638,7 +657,7 @@ __device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl) {
     {
         unsigned vm[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { w1[u] = s2[u] >= 0; vm[u] = w1[u] ? c.vmin2[s2[u]] : 0u; }
+        for (int u = 0; u < U; ++u) { w1[u] = s2[u] >= 0; vm[u] = w1[u] ? c.vtab2[s2[u]].vmin : 0u; }
 #pragma unroll
         for (int u = 0; u < U; ++u) w2[u] = w1[u] && (vm[u] == (unsigned)idx[u]);
     }
@@ -660,8 +679,8 @@ __device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl) {
             const size_t o = (size_t)(off + rk[u]) * 3;
             c.fd[o] = q[u][0]; c.fd[o + 1] = q[u][1]; c.fd[o + 2] = q[u][2];
             // release the pass-1 slot for the next scan (only its winner touches it)
-            c.vkey1[s1[u]] = EMPTY_KEY;
-            c.vmin1[s1[u]] = 0xFFFFFFFFu;
+            c.vtab1[s1[u]].key = EMPTY_KEY;
+            c.vtab1[s1[u]].vmin = 0xFFFFFFFFu;
             // from here on slot2 >= 0 marks the pass-2 winners only (K4, and the next scan's K1 which releases their slots)
             if (!w2[u]) c.slot2[idx[u]] = -1;
         }
@@ -696,7 +715,7 @@ __device__ __forceinline__ void d_compact_src(const Ctx& c, const Slice sl) {
 // map probe: block id of voxel `key` or -1
 template <class CT>
 __device__ __forceinline__ int map_find(const CT& c, unsigned long long key) {
-    unsigned s = (unsigned)mix64(key) & c.tmask;
+    unsigned s = brick_slot(key, c.tmask);
     for (unsigned probe = 0; probe <= c.tmask; ++probe) {
         const TabEnt e = c.tab[s];
         if (e.key == key) return e.blk;  // packed: block id | count << 24
@@ -789,7 +808,6 @@ __device__ __forceinline__ int nn_probe32(const CT& c, int kx, int ky, int kz, i
 template <int PC, class CT>
 __device__ __forceinline__ bool nn_scan32(const CT& c, V3 s, int kx, int ky, int kz, int pb, int lane32, int gbase,
                                           V3& best, double& best_d2, int& lastv) {
-    const int P = (PC > 0) ? PC : c.P;  // compile-time for the default 20: y / z become immediate offsets of x
     const int di = lane32 / 9 - 1, dj = (lane32 / 3) % 3 - 1, dk = lane32 % 3 - 1;
     const int cnt0 = (pb < 0) ? 0 : (int)((unsigned)pb >> 24);
     double bd = 1.7976931348623157e308;
@@ -802,8 +820,8 @@ __device__ __forceinline__ bool nn_scan32(const CT& c, V3 s, int kx, int ky, int
     if (pbc >= 0 || pbl >= 0) {  // uniform over the group (a stored voxel holds at least one point)
         const bool ac = pbc >= 0 && lane32 < (int)((unsigned)pbc >> 24), al = pbl >= 0 && lane32 < (int)((unsigned)pbl >> 24);
         double cx = 0.0, cy = 0.0, cz = 0.0, lx = 0.0, ly = 0.0, lz = 0.0;
-        if (ac) { const double* X = blk_x(c, pbc & BLK_ID_MASK); cx = X[lane32]; cy = X[P + lane32]; cz = X[2 * P + lane32]; }
-        if (al) { const double* X = blk_x(c, pbl & BLK_ID_MASK); lx = X[lane32]; ly = X[P + lane32]; lz = X[2 * P + lane32]; }
+        if (ac) { const double* X = blk_x(c, pbc & BLK_ID_MASK); cx = X[3 * lane32]; cy = X[3 * lane32 + 1]; cz = X[3 * lane32 + 2]; }
+        if (al) { const double* X = blk_x(c, pbl & BLK_ID_MASK); lx = X[3 * lane32]; ly = X[3 * lane32 + 1]; lz = X[3 * lane32 + 2]; }
         if (ac) {
             const double dx = cx - s.x, dy = cy - s.y, dz = cz - s.z;
             bd = dx * dx + dy * dy + dz * dz;
@@ -842,8 +860,8 @@ __device__ __forceinline__ bool nn_scan32(const CT& c, V3 s, int kx, int ky, int
         const int pb0 = __shfl(pb, gbase + v0), pb1 = __shfl(pb, gbase + v1);
         const bool a0 = lane32 < (int)((unsigned)pb0 >> 24), a1 = two && lane32 < (int)((unsigned)pb1 >> 24);
         double q0x = 0.0, q0y = 0.0, q0z = 0.0, q1x = 0.0, q1y = 0.0, q1z = 0.0;
-        if (a0) { const double* X = blk_x(c, pb0 & BLK_ID_MASK); q0x = X[lane32]; q0y = X[P + lane32]; q0z = X[2 * P + lane32]; }
-        if (a1) { const double* X = blk_x(c, pb1 & BLK_ID_MASK); q1x = X[lane32]; q1y = X[P + lane32]; q1z = X[2 * P + lane32]; }
+        if (a0) { const double* X = blk_x(c, pb0 & BLK_ID_MASK); q0x = X[3 * lane32]; q0y = X[3 * lane32 + 1]; q0z = X[3 * lane32 + 2]; }
+        if (a1) { const double* X = blk_x(c, pb1 & BLK_ID_MASK); q1x = X[3 * lane32]; q1y = X[3 * lane32 + 1]; q1z = X[3 * lane32 + 2]; }
         if (a0) {
             const double dx = q0x - s.x, dy = q0y - s.y, dz = q0z - s.z;
             const double d2 = dx * dx + dy * dy + dz * dz;
@@ -1488,9 +1506,9 @@ __device__ __forceinline__ void scan_voxelsL(const CT& c, const int (&pb)[NV], c
             for (int k = 0; k < NCH; ++k) {
                 const int idx = LP * k + laneL;
                 act[v][k] = idx < cnt;
-                q[v][k][0] = act[v][k] ? X[idx] : 0.0;
-                q[v][k][1] = act[v][k] ? X[P + idx] : 0.0;
-                q[v][k][2] = act[v][k] ? X[2 * P + idx] : 0.0;
+                q[v][k][0] = act[v][k] ? X[3 * idx] : 0.0;
+                q[v][k][1] = act[v][k] ? X[3 * idx + 1] : 0.0;
+                q[v][k][2] = act[v][k] ? X[3 * idx + 2] : 0.0;
             }
         }
 #pragma unroll
@@ -1516,7 +1534,7 @@ __device__ __forceinline__ void scan_voxelsL(const CT& c, const int (&pb)[NV], c
             for (int base = 0; __any(base < cnt); base += LP) {
                 const int idx = base + laneL;
                 if (idx < cnt) {
-                    const double qx = X[idx], qy = X[P + idx], qz = X[2 * P + idx];
+                    const double qx = X[3 * idx], qy = X[3 * idx + 1], qz = X[3 * idx + 2];
                     const double dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
                     const double d2 = dx * dx + dy * dy + dz * dz;
                     const unsigned id = (unsigned)(vx[v] * 32 + idx);
@@ -1560,7 +1578,7 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
             for (int q = 0; q < RE; ++q) {
                 const int ee = RE * laneL + q;
                 kq[q] = pack_key(kx + ee / 9 - 1, ky + (ee / 3) % 3 - 1, kz + ee % 3 - 1);
-                sq[q] = (unsigned)mix64(kq[q]) & c.tmask;
+                sq[q] = brick_slot(kq[q], c.tmask);
                 eq[q].key = EMPTY_KEY; eq[q].blk = -1; eq[q].head = -1;
                 if (ee < 27) eq[q] = c.tab[sq[q]];
             }
@@ -2260,7 +2278,7 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
         int kx, ky, kz;
         keyed[u] = vox_key(p[u], c.vs, key[u], kx, ky, kz);
         if (!keyed[u]) { atomicOr(&st->err_flags, ERR_KEY_RANGE); continue; }
-        s0[u] = (unsigned)mix64(key[u]) & c.tmask;
+        s0[u] = brick_slot(key[u], c.tmask);
         cur[u] = c.tab[s0[u]].key;  // plain read, as in vds_claim: EMPTY -> key is the only change in this kernel
     }
 #pragma unroll
@@ -2353,7 +2371,7 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
         const int pos = cnt[u] + rank[u];
         if (pos < c.P) {
             double* X = blk_x(c, pb[u] & BLK_ID_MASK);
-            X[pos] = c.fdw[3 * i]; X[c.P + pos] = c.fdw[3 * i + 1]; X[2 * c.P + pos] = c.fdw[3 * i + 2];
+            X[3 * pos] = c.fdw[3 * i]; X[3 * pos + 1] = c.fdw[3 * i + 1]; X[3 * pos + 2] = c.fdw[3 * i + 2];
         }
     }
 }
@@ -2412,7 +2430,7 @@ __device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_x
             const int* h = blk_hdr(c, b);
             cnt[u] = h[0]; hs[u] = h[1];
             const double* X = blk_x(c, b);
-            x0[u] = X[0]; y0[u] = X[c.P]; z0[u] = X[2 * c.P];  // (read whether or not the block is live: no dependent round trip)
+            x0[u] = X[0]; y0[u] = X[1]; z0[u] = X[2];  // (read whether or not the block is live: no dependent round trip)
         }
     }
 #pragma unroll
@@ -2441,8 +2459,8 @@ __device__ __forceinline__ void d_map_rebuild(const Ctx& c, const Slice sl) {
     if (h[0] <= 0) return;
     const double* X = blk_x(c, b);
     unsigned long long key; int kx, ky, kz;
-    vox_key(v3(X[0], X[c.P], X[2 * c.P]), c.vs, key, kx, ky, kz);
-    unsigned s = (unsigned)mix64(key) & c.tmask;
+    vox_key(v3(X[0], X[1], X[2]), c.vs, key, kx, ky, kz);
+    unsigned s = brick_slot(key, c.tmask);
     for (unsigned probe = 0; probe <= c.tmask; ++probe) {
         const unsigned long long old = atomicCAS(&c.tab[s].key, EMPTY_KEY, key);
         if (old == EMPTY_KEY) { c.tab[s].blk = b | (h[0] << 24); h[1] = (int)s; atomicAdd(&c.st->tab_used, 1u); return; }
@@ -2461,7 +2479,7 @@ __global__ __launch_bounds__(256) void k_map_export(Ctx c, double* out, int* cou
     const double* X = blk_x(c, b);
     for (int j = 0; j < cnt; ++j) {
         if (o + j >= max_points) break;
-        out[3 * (size_t)(o + j)] = X[j]; out[3 * (size_t)(o + j) + 1] = X[c.P + j]; out[3 * (size_t)(o + j) + 2] = X[2 * c.P + j];
+        out[3 * (size_t)(o + j)] = X[3 * j]; out[3 * (size_t)(o + j) + 1] = X[3 * j + 1]; out[3 * (size_t)(o + j) + 2] = X[3 * j + 2];
     }
 }
 

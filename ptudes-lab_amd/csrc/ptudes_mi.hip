@@ -105,7 +105,7 @@ static int icp_free(ptl_icp* h) {
     if (!h) return PTL_OK;
     (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
-    void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vkey1, c.vkey2, c.vmin1, c.vmin2, c.bcnt1, c.bcnt2, h->fd_buf[0], h->fd_buf[1], c.src0,
+    void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vtab1, c.vtab2, c.bcnt1, c.bcnt2, h->fd_buf[0], h->fd_buf[1], c.src0,
                     c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.wg_clk, c.pc_key, c.pc_pb, c.pc_ans, c.gn_rows_ll, c.gn_xsum_ll,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter, h->d_row_mask};
     for (void* p : ptrs)
@@ -138,10 +138,8 @@ __global__ void k_state_init(DevState* st, int pool_cap) {
 static int icp_reset_device(ptl_icp* h) {
     Ctx& c = h->c;
     const size_t vcap = (size_t)c.vmask + 1;
-    HIPCHK(hipMemsetAsync(c.vkey1, 0xFF, vcap * 8, h->stream));
-    HIPCHK(hipMemsetAsync(c.vkey2, 0xFF, vcap * 8, h->stream));
-    HIPCHK(hipMemsetAsync(c.vmin1, 0xFF, vcap * 4, h->stream));
-    HIPCHK(hipMemsetAsync(c.vmin2, 0xFF, vcap * 4, h->stream));
+    HIPCHK(hipMemsetAsync(c.vtab1, 0xFF, vcap * sizeof(VdsEnt), h->stream));  // (key = EMPTY, index = none)
+    HIPCHK(hipMemsetAsync(c.vtab2, 0xFF, vcap * sizeof(VdsEnt), h->stream));
     HIPCHK(hipMemsetAsync(c.tab, 0xFF, ((size_t)c.tmask + 1) * sizeof(TabEnt), h->stream));
     HIPCHK(hipMemsetAsync(c.blocks, 0, (size_t)c.pool_cap * c.bstride, h->stream));
     HIPCHK(hipMemsetAsync(c.gn_rows_ll, 0, (size_t)2 * c.G * 64 * 8, h->stream));  // the launch epoch restarts with the state
@@ -228,8 +226,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     bool ok = true;
     ok &= dalloc(&c.pts, 3 * n) == hipSuccess;
     ok &= dalloc(&c.slot1, n) == hipSuccess && dalloc(&c.slot2, n) == hipSuccess;
-    ok &= dalloc(&c.vkey1, vcap) == hipSuccess && dalloc(&c.vkey2, vcap) == hipSuccess;
-    ok &= dalloc(&c.vmin1, vcap) == hipSuccess && dalloc(&c.vmin2, vcap) == hipSuccess;
+    ok &= dalloc(&c.vtab1, vcap) == hipSuccess && dalloc(&c.vtab2, vcap) == hipSuccess;
     ok &= dalloc(&c.bcnt1, h->nblk_scan) == hipSuccess && dalloc(&c.bcnt2, h->nblk_scan) == hipSuccess;
     ok &= dalloc(&c.fd, 3 * n) == hipSuccess && dalloc(&c.src0, 3 * n) == hipSuccess;
     h->fd_buf[0] = c.fd;
@@ -1334,6 +1331,7 @@ static int batch_check_seq_run(ptl_batch* b) {
     const int gseq = batch_gseq(b), J = ic.gn_workgroups / 8;
     if (gseq < 1 || gseq > J || gseq > 64) return set_err(PTL_ERR_ARG, "a team needs 1 .. min(64, gn_workgroups / 8 = %d) workgroups, not %d", J, gseq);
     if (b->S > 8 * SEQ_SLOTS) return set_err(PTL_ERR_ARG, "at most %d sequences", 8 * SEQ_SLOTS);
+    if (b->cfg.with_ekf && ic.gn_threads < 384) return set_err(PTL_ERR_ARG, "free-running batches with a filter need gn_threads >= 384 (the filter step maps one thread to each of the 324 covariance cells)");
     int per_cu = 0, cus = 0;
     const bool p20 = ic.max_points_per_voxel == 20;
     hipError_t e = hipSuccess;

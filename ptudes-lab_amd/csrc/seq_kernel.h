@@ -85,7 +85,7 @@ __device__ __forceinline__ unsigned xcc_id() {
 // the sequence table itself (scalar loads), like the per-stage kernels.
 #define SEQ_FAIL 0xFFFFFFFFu
 #ifndef SEQ_U
-#define SEQ_U 4  /* points per thread and pass in K1-K4 (see Slice) */
+#define SEQ_U 8  /* points per thread and pass in K1-K4 and the map update (see Slice): 4 -> 8 took K0-K4 of a team of 2 from 1585 to 1406 us */
 #endif
 // make STAGES=1: workgroup 0 of every sequence adds the wall-clock ticks of every stage and of every barrier wait to
 // st->dbg_sums[0..19] (tools/free_vs_lockstep.py prints them)
@@ -102,7 +102,7 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     DevState* st = c.st;
     const int BS = (int)blockDim.x * SEQ_U, nbs = (c.n_in + BS - 1) / BS;
     Slice sl;
-    sl.nb = nbs;
+    sl.nb = nbs; sl.clk = wg == 0 ? 1 : 0;
     const TeamEnv te = {word, &st->gn_abort, st, local};
     SQ_CLK_DECL;
     if (wg == 0 && st->pro_next != k + 1) d_scan_prologue(c, true);  // (with a filter it has usually been run already: sq_filter)
@@ -125,30 +125,40 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     SQ_CLK(8);
     return target;
 }
-// K7-K11 of scan k
-__device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, int rebuild, unsigned* word, bool local) {
+// K7-K11 of scan k by all `nw` workgroups of the team.  The blocks of a phase are handed out through a counter (`ctr`, five
+// words zeroed by the team's leader before the scan): the filter workgroup joins when its filter step is done and takes what
+// is left - nobody waits for it, and a team of two does not leave the whole update to one workgroup.  Which workgroup
+// inserts which block does not show in the result (voxel contents are ranked by point index, counters are integer sums).
+__device__ __forceinline__ int sq_grab(unsigned* ctr) {
+    __shared__ int s_blk;
+    __syncthreads();
+    if (threadIdx.x == 0) s_blk = (int)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return s_blk;
+}
+__device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, int rebuild, unsigned* word, unsigned* ctr, bool local) {
     const Ctx c = load_seq_ctx(a, s, k);
     DevState* st = c.st;
     const int BS = (int)blockDim.x, BU = BS * SEQ_U, nbd = (st->n_down_ins + BU - 1) / BU;
     Slice sl;
-    sl.nb = nbd;
+    sl.nb = nbd; sl.clk = 0;
     const TeamEnv te = {word, &st->gn_abort, st, local};
     SQ_CLK_DECL;
-    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_a<SEQ_U>(c, c.fd, &st->n_down_ins, 0, 1, sl);
+    for (sl.b = sq_grab(ctr); sl.b < nbd; sl.b = sq_grab(ctr)) d_map_insert_a<SEQ_U>(c, c.fd, &st->n_down_ins, 0, 1, sl);
     SQ_CLK(10);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(11);
-    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_b<SEQ_U>(c, &st->n_down_ins, 0, sl);
+    for (sl.b = sq_grab(ctr + 1); sl.b < nbd; sl.b = sq_grab(ctr + 1)) d_map_insert_b<SEQ_U>(c, &st->n_down_ins, 0, sl);
     SQ_CLK(12);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(13);
-    for (sl.b = wg; sl.b < nbd; sl.b += nw) d_map_insert_c<SEQ_U>(c, &st->n_down_ins, 0, sl);
+    for (sl.b = sq_grab(ctr + 2); sl.b < nbd; sl.b = sq_grab(ctr + 2)) d_map_insert_c<SEQ_U>(c, &st->n_down_ins, 0, sl);
     SQ_CLK(14);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(15);
     const int nbpu = (st->pool_hw + BU - 1) / BU;
     sl.nb = nbpu;
-    for (sl.b = wg; sl.b < nbpu; sl.b += nw) d_map_prune<SEQ_U>(c, nullptr, 1, sl);
+    for (sl.b = sq_grab(ctr + 3); sl.b < nbpu; sl.b = sq_grab(ctr + 3)) d_map_prune<SEQ_U>(c, nullptr, 1, sl);
     SQ_CLK(16);
     const int nbp = (st->pool_hw + BS - 1) / BS;
     sl.nb = nbp;
@@ -159,7 +169,7 @@ __device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, in
         for (size_t i = (size_t)wg * BS + threadIdx.x; i < nwords; i += (size_t)nw * BS) tw[i] = ~0ull;
         if (wg == 0 && threadIdx.x == 0) st->tab_used = 0u;
         if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
-        for (sl.b = wg; sl.b < nbp; sl.b += nw) d_map_rebuild(c, sl);
+        for (sl.b = sq_grab(ctr + 4); sl.b < nbp; sl.b = sq_grab(ctr + 4)) d_map_rebuild(c, sl);
     }
     return target;
 }
@@ -235,8 +245,9 @@ __device__ __forceinline__ void sched_abandon(SeqSched* sc, int q, int k1) {
     __hip_atomic_store(&sc->next_scan[q], k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// bar: per team 64 words - [0] barrier of the whole team, [32] of its working workgroups, [40], [41] the leader's job (sequence,
-// scan), [42] the XCC ids its workgroups reported (one bit each), [43] the team's own abort word (the job barrier)
+// bar: per team 64 words - [0] barrier of the whole team, [32] of the map update, [40], [41] the leader's job (sequence,
+// scan), [42] the XCC ids its workgroups reported (one bit each), [43] the team's own abort word (the job barrier),
+// [44..48] block counters of the map update's phases
 #define SEQ_MAX_TEAMS 512
 #define JOB_DONE 0xFFFFFFFFu
 #define JOB_RETRY 0xFFFFFFFEu
@@ -256,7 +267,6 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, S
     // one workgroup does both, one after the other.
     const bool solo = G == 1;
     const bool fwg = r.with_ekf && !solo && wg == G - 1;
-    const int nw = (r.with_ekf && !solo) ? G - 1 : G;
     unsigned t_all = 0u, t_work = 0u;
     const bool lead = wg == 0 && threadIdx.x == 0, clkf = (fwg || (solo && r.with_ekf)) && threadIdx.x == 0;
     int* team_abort = (int*)&tb[43];
@@ -280,6 +290,7 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, S
             q_mine = q; k_mine = k;
             __hip_atomic_store(&tb[40], q == SCHED_DONE ? JOB_DONE : q == SCHED_RETRY ? JOB_RETRY : (unsigned)(x + 8 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&tb[41], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 5; ++i) __hip_atomic_store(&tb[44 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the map update's block counters
         }
         // the job barrier: nobody is on a sequence here, so an expiry (a teammate that never came) is the team's own affair
         if (!team_sync(tb, (unsigned)G, t_all, team_abort, nullptr, local)) return;
@@ -305,20 +316,17 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, S
         const long long c3 = (long long)wall_clock64();
         if (!team_sync(te, (unsigned)G, t_all)) SEQ_LEAVE;  // new pose, trajectory row
         const long long c4 = (long long)wall_clock64();
-        long long c5f = c4;
-        if (fwg) {
-            sq_filter(a, s, k);
-        } else {
-            t_work = sq_map_update(a, s, k, wg, nw, t_work, (r.rebuild_every > 0 && ((k + 1) % r.rebuild_every) == 0) ? 1 : 0, tb + 32, local);
-            if (t_work == SEQ_FAIL) SEQ_LEAVE;
-            if (solo && r.with_ekf) { c5f = (long long)wall_clock64(); sq_filter(a, s, k); }
-        }
+        long long c5f = c4, c5g = c4;
+        if (fwg) { sq_filter(a, s, k); c5g = (long long)wall_clock64(); }  // ... and then it joins the map update
+        t_work = sq_map_update(a, s, k, wg, G, t_work, (r.rebuild_every > 0 && ((k + 1) % r.rebuild_every) == 0) ? 1 : 0, tb + 32, tb + 44, local);
+        if (t_work == SEQ_FAIL) SEQ_LEAVE;
+        if (solo && r.with_ekf) { c5f = (long long)wall_clock64(); sq_filter(a, s, k); c5g = (long long)wall_clock64(); }
         const long long c5 = (long long)wall_clock64();
         if (lead) {
             st->seq_clk[0] += c1 - c0; st->seq_clk[1] += c2 - c1; st->seq_clk[2] += c3 - c2; st->seq_clk[3] += c4 - c3; st->seq_clk[4] += c5 - c4;
             st->seq_clk[6] += 1;
         }
-        if (clkf) st->seq_clk[5] += c5 - c5f;
+        if (clkf) st->seq_clk[5] += c5g - c5f;
         if (!team_sync(te, (unsigned)G, t_all)) SEQ_LEAVE;  // the scan is complete: the sequence may go to another team
 #undef SEQ_LEAVE
     }
