@@ -53,9 +53,10 @@ def scan_bytes(s, n_raw):
 # kernel issues, at the width the lane requests (no cache-line rounding, no cache assumed), driven by the counters the
 # kernel keeps (ptl_batch_exec_counters) and the per-scan statistics.  Unit costs in bytes:
 EXEC_COST = {
-    # Gauss-Newton loop (gn8_body): phase A of every point-iteration reads the position (24) and writes it back (24);
-    # after the first iteration of a scan it also reads the voxel key (8) and the 96-byte answer row
-    "point_iteration": 48, "point_iteration_later": 104,
+    # Gauss-Newton loop (gn8_body): the first iteration of a scan reads every source point (24); the positions then live in the
+    # workgroup's LDS (GN8_LDS_PTS = 3072 per workgroup), only the points beyond that are written (24) and read back (24) through
+    # src_cur every iteration; after the first iteration phase A also reads the voxel key (8) and the 96-byte answer row
+    "source_read": 24, "point_iteration_in_memory": 48, "point_iteration_later": 104, "lds_points_per_workgroup": 3072,
     # a full search reads the probe row (128) + key (8), writes the answer row (96) + the winner's voxel (4)
     "search": 236,
     # a rebuilt probe row: 27 hash-table entries of 16 B, the row (128) and the key (8) written
@@ -89,7 +90,8 @@ def executed_bytes(cnt, stats, n_raw, G, cols=1024):
     c = EXEC_COST
     pi = cnt["point_iterations"]
     first = sum(s["n_src"] for s in stats if s["iterations"] > 0)
-    gn = (c["point_iteration"] * pi + c["point_iteration_later"] * max(pi - first, 0) + c["search"] * cnt["searches"]
+    in_mem = sum(max(s["n_src"] - max(G, 1) * c["lds_points_per_workgroup"], 0) * s["iterations"] for s in stats)  # point-iterations through src_cur
+    gn = (c["source_read"] * first + c["point_iteration_in_memory"] * in_mem + c["point_iteration_later"] * max(pi - first, 0) + c["search"] * cnt["searches"]
           + c["row_rebuilt"] * cnt["rows_rebuilt"] + c["map_point_read"] * cnt["map_points_read"]
           + cnt["gn_iterations"] * G * (1 + G) * c["exchange_words_per_row"] * c["exchange_word"])
     st = 0

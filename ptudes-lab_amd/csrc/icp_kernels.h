@@ -1770,6 +1770,9 @@ __device__ __forceinline__ double sums_from_moments(int e, const double* M) {
 }
 
 #define GN8_ROW_ENTRIES 18   /* 16 moments, pair count, candidate count */
+#ifndef GN8_LDS_PTS
+#define GN8_LDS_PTS (6 * 512) /* source-point positions a workgroup keeps in LDS (72 KB) */
+#endif
 #define GN8_QCAP (2 * GN8_MAX_THREADS)  /* queue of points awaiting the full search: the misses of several phase-A chunks share the search passes */
 #ifndef GN8_LPB
 #define GN8_LPB 8             /* lanes per point of the full search (8 or 4) */
@@ -1805,13 +1808,15 @@ struct Gn8Pre {
     unsigned long long key;
     double2 r0, r1, r2, r3, r4, r5;  // s0.xy | s0.z t.x | t.yz | bound, count | t2.xy | t2.z, order ids
 };
-__device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, bool first) {
+// want_pos: the point's previous position comes from memory (the scan's first iteration: src0; later: src_cur for the points
+// that do not fit the workgroup's LDS copy, gn8_body)
+__device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, bool first, bool want_pos) {
     Gn8Pre p;
     p.px = p.py = p.pz = 0.0; p.key = EMPTY_KEY;
     p.r0 = p.r1 = p.r2 = p.r3 = p.r4 = p.r5 = make_double2(0.0, -1.0);
     if (valid) {
         const double* sp0 = first ? c.src0 : c.src_cur;
-        p.px = sp0[3 * (size_t)i]; p.py = sp0[3 * (size_t)i + 1]; p.pz = sp0[3 * (size_t)i + 2];
+        if (want_pos) { p.px = sp0[3 * (size_t)i]; p.py = sp0[3 * (size_t)i + 1]; p.pz = sp0[3 * (size_t)i + 2]; }
         if (!first) {
             p.key = c.pc_key[i];
             const double2* row = (const double2*)(c.pc_ans + GN8_ANS_ROW * (size_t)i);
@@ -1835,6 +1840,11 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     __shared__ int flag_done2[2];
     __shared__ long long cand_total_sh;
     __shared__ unsigned xcnt[4];  // executed-work counters of this workgroup and scan: searches | rows rebuilt | stored points read
+    // The current positions of the workgroup's source points live in LDS for the whole loop (every iteration moves every point:
+    // 24 B read + 24 B written per point-iteration otherwise, a sixth of the loop's memory traffic): chunk q of the workgroup
+    // (blockDim points) at [q blockDim, (q + 1) blockDim).  Chunks beyond the array (a team of 2 on a scan of > 6144 source
+    // points) keep theirs in src_cur.
+    __shared__ double posL[3][GN8_LDS_PTS];
     DevState* st = c.st;
     const int tid = threadIdx.x, lane32 = tid & 31, grp32 = tid >> 5;
     const int NT = blockDim.x, NG32 = blockDim.x >> 5, NW = blockDim.x >> 6;
@@ -1877,8 +1887,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     long long ph[5] = {0, 0, 0, 0, 0};  // (only with -DGN_PHASE_CLOCKS) point loop | wg reduce + publish | exchange | - | totals + solve
     // this lane's point of chunk qb: block qb + wavefront of this workgroup, i.e. global block (qb + wavefront) G + wg
     auto chunk_point = [&](int qb, int& i) -> bool { const int q = qb + (tid >> 6); i = ((q * G + wg) << 6) + (tid & 63); return q < my_blocks && i < n; };
+    auto pos_in_lds = [&](int qb) -> bool { return (qb / NW + 1) * NT <= GN8_LDS_PTS; };
     Gn8Pre pre;
-    { int i0; const bool v0 = chunk_point(0, i0); pre = gn8_preload(c, i0, v0, true); }
+    { int i0; const bool v0 = chunk_point(0, i0); pre = gn8_preload(c, i0, v0, true, true); }
     for (int it = 0; it < c.max_iter; ++it) {
         const long long c0 = GN_CLK();
         const double* Esh = Esh2[(it + 1) & 1];
@@ -1909,7 +1920,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 if (qb + NW < my_blocks) {  // the next chunk's loads, in flight while this one is evaluated
                     int i2;
                     const bool v2 = chunk_point(qb + NW, i2);
-                    pre = gn8_preload(c, i2, v2, it == 0);
+                    pre = gn8_preload(c, i2, v2, it == 0, it == 0 || !pos_in_lds(qb + NW));
                 }
                 int miss = -1;
                 sA = v3(0.0, 0.0, 0.0);
@@ -1917,8 +1928,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     Rt E;
                     for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
                     for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
-                    const V3 s = rt_apply(E, v3(cur.px, cur.py, cur.pz));
-                    c.src_cur[3 * (size_t)i] = s.x; c.src_cur[3 * (size_t)i + 1] = s.y; c.src_cur[3 * (size_t)i + 2] = s.z;
+                    const bool lds = pos_in_lds(qb);
+                    const int li = (qb / NW) * NT + tid;
+                    const V3 p0 = (it == 0 || !lds) ? v3(cur.px, cur.py, cur.pz) : v3(posL[0][li], posL[1][li], posL[2][li]);
+                    const V3 s = rt_apply(E, p0);
+                    if (lds) { posL[0][li] = s.x; posL[1][li] = s.y; posL[2][li] = s.z; }
+                    else { c.src_cur[3 * (size_t)i] = s.x; c.src_cur[3 * (size_t)i + 1] = s.y; c.src_cur[3 * (size_t)i + 2] = s.z; }
                     sA = s;
                     miss = i;
                     if (it > 0) {
@@ -2025,12 +2040,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 // after the last chunk nothing is loaded - chunk_point says so - and the stale values are dead for the compiler too)
                 int i2;
                 const bool v2 = chunk_point(qb + NW, i2);
-                pre = gn8_preload(c, i2, v2, it == 0);
+                pre = gn8_preload(c, i2, v2, it == 0, it == 0 || !pos_in_lds(qb + NW));
             }
         }
         // the next iteration's first chunk: positions and answer rows as this iteration leaves them (the searches above have
         // written theirs), requested now - they arrive while the sums are exchanged and the system is solved
-        { int i0; const bool v0 = chunk_point(0, i0); pre = gn8_preload(c, i0, v0, false); }
+        { int i0; const bool v0 = chunk_point(0, i0); pre = gn8_preload(c, i0, v0, false, !pos_in_lds(0)); }
         const long long c1 = GN_CLK();
         // ---- workgroup reduction, fixed tree: the 64 lanes of a wavefront (DPP inside the rows, two crossbar steps across
         // them), then the wavefronts in order

@@ -2,10 +2,10 @@ import sys, ctypes as C, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ptudes_lab_amd
 from ptudes_lab_amd import core, synth, _lib as L
-S=int(sys.argv[1]); n=40
+S=int(sys.argv[1]); n=40; TG=int(sys.argv[2]) if len(sys.argv) > 2 else 0
 seqs=[synth.make_sequence(seed=1000+s, n_scans=n) for s in range(S)]
 n_imu=seqs[0].imu_range_for_scan(n-1)[1]
-b=core.BatchRunner(S,n,seqs[0].H*seqs[0].W,n_imu,use_imu_prediction=True,with_ekf=True)
+b=core.BatchRunner(S,n,seqs[0].H*seqs[0].W,n_imu,use_imu_prediction=True,with_ekf=True,team_workgroups=TG)
 for s,sq in enumerate(seqs):
     for k in range(n): b.upload_scan(s,k,sq.scan(k))
     b.upload_imu(s, sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
