@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GN_EVENT_EVERY = 8
-DEFAULT_SEQS = 48
+DEFAULT_SEQS = 192
 PARITY_EXTRA_SEQS = 2     # sequences beside sequence 0 whose trajectories are checked against the oracle (single rank)
 PARITY_EXTRA_SWEEPS = 40  # ... over their first sweeps
 GATHER_TIMEOUT_S = 120

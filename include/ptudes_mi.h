@@ -179,6 +179,9 @@ int ptl_icp_debug_sums(ptl_icp *h, double out[32]);
 /* test hook: workgroup `wg` of the following Gauss-Newton launches returns at once (-1 = back to normal, also clears the
  * time-out flag): the others must run into the exchange time-out, abort together and report it - not hang */
 int ptl_icp_debug_stall_workgroup(ptl_icp *h, int32_t wg);
+/* test hook: at most `free_blocks` free voxel blocks left in the pool (< 0: unchanged), `table_used` map-table entries declared
+ * taken (< 0: unchanged): the following map updates raise the pool / table capacity flags (PTL_ERR_CAPACITY at the next wait) */
+int ptl_icp_debug_limit_capacity(ptl_icp *h, int32_t free_blocks, int64_t table_used);
 /* test hook: set the 22-bit launch epoch of the Gauss-Newton exchange (exercises its wrap-around) */
 int ptl_icp_debug_set_epoch(ptl_icp *h, uint32_t epoch);
 

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "ptl_icp_debug_set_epoch": (C.c_int, [_vp, C.c_uint32]),
     "ptl_icp_debug_sums": (C.c_int, [_vp, c_d_p]),
     "ptl_icp_debug_stall_workgroup": (C.c_int, [_vp, C.c_int32]),
+    "ptl_icp_debug_limit_capacity": (C.c_int, [_vp, C.c_int32, C.c_int64]),
     "ptl_icp_deskew": (C.c_int, [_vp, c_d_p, c_d_p, C.c_int64, c_d_p]),
     "ptl_icp_map_add": (C.c_int, [_vp, c_d_p, C.c_int64, c_d_p, C.c_int]),
     "ptl_icp_linear_system": (C.c_int, [_vp, c_d_p, C.c_int64, C.c_double, C.c_double, c_d_p, c_i64_p, c_i64_p]),

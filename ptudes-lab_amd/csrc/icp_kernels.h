@@ -2324,6 +2324,7 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
         if (created) {  // take a block from the pool
             const int top = atomicSub(&st->free_top, 1) - 1;
             int b = -1;
+            if (top < 0) atomicAdd(&st->free_top, 1);  // pool exhausted: put the count back (the prune pass pushes at free_top: it must not find it negative)
             if (top >= 0) {
                 b = c.free_stack[top];
                 int* h = blk_hdr(c, b);
@@ -2458,7 +2459,7 @@ __device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_x
             c.tab[hs[u]].blk = -1;
             blk_hdr(c, b)[0] = 0;
             const int top = atomicAdd(&st->free_top, 1);
-            c.free_stack[top] = b;
+            if (top >= 0 && top < c.pool_cap) c.free_stack[top] = b;
             atomicSub(&st->n_live, 1);
             atomicAdd((unsigned long long*)&st->map_points, (unsigned long long)(-(long long)cnt[u]));
         }

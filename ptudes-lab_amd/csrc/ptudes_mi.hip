@@ -602,6 +602,23 @@ extern "C" int ptl_icp_debug_stall_workgroup(ptl_icp* h, int32_t wg) {
     return PTL_OK;
 }
 
+// test hook: leave the handle's block pool with at most `free_blocks` free blocks (< 0: unchanged) and / or declare `table_used`
+// entries of its map table taken (< 0: unchanged) - the next map updates then run into ERR_POOL / ERR_TABLE, which the call
+// that synchronises next reports as PTL_ERR_CAPACITY
+__global__ void k_limit_capacity(DevState* st, int free_blocks, long long table_used) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (free_blocks >= 0 && st->free_top > free_blocks) st->free_top = free_blocks;
+    if (table_used >= 0) st->tab_used = (unsigned)table_used;
+}
+extern "C" int ptl_icp_debug_limit_capacity(ptl_icp* h, int32_t free_blocks, int64_t table_used) {
+    if (!h) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->map_stream));
+    k_limit_capacity<<<1, 64, 0, h->stream>>>(h->c.st, free_blocks, (long long)table_used);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PTL_OK;
+}
+
 // diagnostic: ticks every GN workgroup spent in the search phase since creation: out[0..G) until its last wavefront
 // finished, out[G..2G) its first wavefront
 extern "C" int ptl_icp_gn_wg_clocks(ptl_icp* h, int64_t* out, int32_t max_wgs) {

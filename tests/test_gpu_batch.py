@@ -195,3 +195,132 @@ def test_points_per_voxel_above_32_is_rejected_and_32_matches_the_oracle():
     ref = m.linear_system(src[None], 2.0, 0.5)
     assert nc == 1 and cand == 32
     assert np.allclose(sums, ref[0], rtol=1e-12, atol=1e-15)
+
+
+def _load(b, seqs, n, n_imu, with_ekf=True):
+    for s, sq in enumerate(seqs):
+        for k in range(n):
+            b.upload_scan(s, k, sq.scan(k))
+        b.upload_imu(s, sq.imu[:n_imu] if with_ekf else np.zeros((0, 7)),
+                     [sq.imu_range_for_scan(k)[1] if with_ekf else 0 for k in range(n)])
+
+
+@pytest.mark.parametrize("team,S", [(4, 9), (2, 21), (1, 11)])
+def test_small_teams_equal_independent_runs(team, S):
+    """teams of 4 / 2 / 1 workgroups (the geometry of 96 - 256 sequences per GPU: 8 / 16 / 32 teams per XCD), more sequences than
+    some XCDs have teams and fewer than others: every sequence equals its run alone with as many Gauss-Newton workgroups, bit for
+    bit.  (A team of one is a workgroup on its own - no exchange partner, the filter step after the map update.)"""
+    n = 5
+    seqs = [synth.make_sequence(seed=1300 + s, n_scans=n) for s in range(S)]
+    n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
+    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=True, with_ekf=True, team_workgroups=team, scans_per_launch=3)
+    assert b.team_geometry()[0] == team
+    _load(b, seqs, n, n_imu)
+    b.run()
+    for s in (0, 1, S // 2, S - 1):
+        sq = seqs[s]
+        r = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=True, with_ekf=True, gn_workgroups=team, gn_lanes_per_point=8, gn_threads=512)
+        for k in range(n):
+            r.upload_scan(k, sq.scan(k))
+        r.upload_imu(sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
+        r.run()
+        one, out = r.results(), b.results(s)
+        assert np.array_equal(out["kiss_poses"], one["kiss_poses"]) and np.array_equal(out["res_poses"], one["res_poses"]), s
+        assert out["stats"] == one["stats"], s
+    c = b.exec_counters(0)
+    st = b.results(0)["stats"]
+    assert c["scans"] == n - 1 and c["gn_iterations"] == sum(q["iterations"] for q in st)  # (the first scan meets an empty map: no loop)
+    assert c["point_iterations"] == sum(q["iterations"] * q["n_src"] for q in st)
+    assert c["searches"] >= sum(q["n_src"] for q in st[1:]) and c["rows_rebuilt"] >= sum(q["n_src"] for q in st[1:])  # every point searches in a scan's first iteration
+    assert 0 < c["vds2_claims"] <= c["vds1_claims"] <= sum(q["n_valid"] for q in st)
+
+
+@pytest.mark.parametrize("what,free", [("pool", True), ("pool", False), ("table", True), ("table", False)])
+def test_capacity_exhaustion_is_reported_for_that_sequence_and_the_others_finish(what, free):
+    """one sequence of a batch runs out of voxel blocks / of map-table room in the middle of a run (test hook): the wait names it
+    with PTL_ERR_CAPACITY and the flag, nothing hangs, and the other sequences' results are those of their runs alone"""
+    import ctypes as C
+    from ptudes_lab_amd import _lib as L
+    S, n = 10, 6
+    seqs = [synth.make_sequence(seed=1400 + s, n_scans=n) for s in range(S)]
+    n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
+    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=True, with_ekf=True, free_running=free)
+    _load(b, seqs, n, n_imu)
+    b.run(3)
+    h = C.c_void_p()
+    L.check(L.lib().ptl_batch_icp(b._h, 4, C.byref(h)))
+    L.check(L.lib().ptl_icp_debug_limit_capacity(h, 50 if what == "pool" else -1, -1 if what == "pool" else 1 << 30))
+    b.enqueue(n - 3)
+    with pytest.raises(RuntimeError, match=r"sequence 4.*0x%d" % (2 if what == "pool" else 4)):
+        b.wait()
+    for s in (0, 5, 9):
+        sq = seqs[s]
+        r = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=True, with_ekf=True, gn_workgroups=16, gn_lanes_per_point=8, gn_threads=512)
+        for k in range(n):
+            r.upload_scan(k, sq.scan(k))
+        r.upload_imu(sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
+        r.run()
+        one, out = r.results(), b.results(s)
+        assert np.array_equal(out["res_poses"], one["res_poses"]) and out["stats"] == one["stats"], s
+    bad = b.results(4)
+    assert np.all(np.isfinite(bad["kiss_poses"])) and len(bad["stats"]) == n  # it went on (with a map that stopped growing)
+
+
+def _oracle_run(sq, n, use_imu, with_ekf):
+    from oracle import cpu as orc
+    icp, ekf = orc.ICP(max_range=sq.max_range, min_range=sq.min_range), orc.EKF()
+    t01 = sq.column_times()
+    kiss, res = [], []
+    for k in range(n):
+        a, e = sq.imu_range_for_scan(k)
+        if with_ekf:
+            for i in range(a, e):
+                ekf.process_imu(sq.imu[i, 1:4], sq.imu[i, 4:7], sq.imu[i, 0])
+        pose = icp.register_frame(sq.scan(k).astype(np.float64), t01, ekf.pose_mat() if use_imu else None)
+        if with_ekf:
+            ekf.process_pose(pose)
+        kiss.append(pose)
+        res.append(ekf.pose_mat() if with_ekf else pose)
+    return np.array(kiss), np.array(res), icp.stats
+
+
+_INT_STATS = ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "sum_cand", "map_voxels", "map_points")
+
+
+@pytest.mark.parametrize("S,team,n", [(48, 0, 100), (40, 2, 60)])
+def test_free_running_batch_against_the_oracle_over_a_long_run(S, team, n):
+    """the bench's kind of run inside the test suite: 48 sequences x 100 sweeps on teams of 8 (and 40 x 60 on teams of 2), ICP +
+    IMU-EKF with the filter's pose as guess - three sequences other than sequence 0 against the CPU oracle: every pose within
+    1e-9 m, every integer statistic of every sweep identical"""
+    from oracle import cpu as orc
+    seqs = [synth.make_sequence(seed=1500 + s, n_scans=n) for s in range(S)]
+    n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
+    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=True, with_ekf=True, team_workgroups=team)
+    _load(b, seqs, n, n_imu)
+    b.run()
+    orc.set_threads(1)  # the sequential pass (the parity form of the oracle)
+    for s in (7, S // 2 + 1, S - 1):
+        kiss, res, stats = _oracle_run(seqs[s], n, True, True)
+        out = b.results(s)
+        assert np.abs(out["kiss_poses"][:, :3, 3] - kiss[:, :3, 3]).max() < 1e-9 and np.abs(out["res_poses"][:, :3, 3] - res[:, :3, 3]).max() < 1e-9, s
+        assert np.abs(out["kiss_poses"] - kiss).max() < 1e-9, s
+        for k in range(n):
+            assert all(out["stats"][k][q] == stats[k][q] for q in _INT_STATS), (s, k, out["stats"][k], stats[k])
+
+
+def test_icp_only_batch_against_the_oracle():
+    """BASELINE config 2 through the batched runner: 48 sequences, no filter, constant-velocity guess, 40 sweeps; two of them
+    against the oracle (poses 1e-9, integer statistics identical)"""
+    from oracle import cpu as orc
+    S, n = 48, 40
+    seqs = [synth.make_sequence(seed=1600 + s, n_scans=n) for s in range(S)]
+    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, 0, with_ekf=False)
+    _load(b, seqs, n, 0, with_ekf=False)
+    b.run()
+    orc.set_threads(1)
+    for s in (3, 29):
+        kiss, _, stats = _oracle_run(seqs[s], n, False, False)
+        out = b.results(s)
+        assert np.abs(out["kiss_poses"] - kiss).max() < 1e-9, s
+        for k in range(n):
+            assert all(out["stats"][k][q] == stats[k][q] for q in _INT_STATS), (s, k)

@@ -160,3 +160,43 @@ def test_registration_returns_an_orthonormal_pose_whatever_the_guess():
         R = out[:3, :3]
         assert np.abs(R @ R.T - np.eye(3)).max() < 1e-15 and abs(np.linalg.det(R) - 1.0) < 1e-15
         assert np.abs(out - g).max() < 1e-4
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", ["constant_velocity", "external_guess"])
+def test_independent_numpy_restatement_agrees_over_free_running_sweeps(mode):
+    """oracle/icp_numpy.py - the pipeline restated a second time from SURVEY.md App. A alone (numpy, dict map, brute-force
+    27-voxel search, scipy SO(3)) - and the C oracle, both free-running over 60 sweeps of the same synthetic sequence: same
+    poses to 1e-9, same integer statistics every sweep (valid / down-sampled / source points, iterations, pairs, candidates
+    examined, map size) and the same threshold.  Both guess modes of the reference: its own constant-velocity model
+    (kiss.py:102-105) and a caller's guess (ekf_bench.py:533-548: here the ground truth, disturbed).  A divergence here is a
+    restatement bug in one of the two (round 1's bare-matrix pose composition would have shown within 40 sweeps)."""
+    import ptudes_lab_amd  # noqa: F401
+    from oracle import icp_numpy as kn
+    from ptudes_lab_amd import synth
+    n = 60
+    seq = synth.make_sequence(seed=2001, n_scans=n, H=16, W=256, min_range=1.0, max_range=70.0)
+    t01 = seq.column_times()
+    gt = seq.gt_poses(0.5)
+    g0i = np.linalg.inv(gt[0])
+    rng = np.random.default_rng(5)
+    a = orc.ICP(max_range=70.0, min_range=1.0)
+    b = kn.KissICP(max_range=70.0, min_range=1.0)
+    worst, moved = 0.0, False
+    for k in range(n):
+        x = seq.scan(k).astype(np.float64)
+        guess = None
+        if mode == "external_guess":
+            guess = g0i @ gt[k] @ kn.se3_exp(np.concatenate([rng.normal(0, 0.03, 3), rng.normal(0, 0.003, 3)]))
+        pa, pb = a.register_frame(x, t01, guess), b.register_frame(x, t01, guess)
+        sa, sb = a.stats[-1], b.stats[-1]
+        for q in ("n_valid", "n_down", "n_src", "iterations", "n_corr_last", "sum_cand", "map_voxels", "map_points"):
+            assert sa[q] == sb[q], (k, q, sa[q], sb[q])
+        assert abs(sa["sigma"] - sb["sigma"]) < 1e-9, (k, sa["sigma"], sb["sigma"])
+        worst = max(worst, float(np.abs(pa - pb).max()))
+        moved = moved or sb["sigma"] != 2.0
+    assert worst < 1e-9, worst
+    assert moved  # the adaptive threshold left its initial value: that branch was compared too
+    assert np.abs(pb[:3, :3] @ pb[:3, :3].T - np.eye(3)).max() < 1e-12
