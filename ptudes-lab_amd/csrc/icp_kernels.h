@@ -169,9 +169,20 @@ __device__ __forceinline__ unsigned brick_slot(unsigned long long key, unsigned 
     const unsigned fine = (unsigned)(((key >> 42) & 1ull) << 2 | ((key >> 21) & 1ull) << 1 | (key & 1ull));
     return (((unsigned)mix64(key & ~low) << 3) | fine) & mask;
 }
+// (int)(x / vs) - the voxel index of VoxelHashMap / VoxelDownsample (C truncation) - without the fp64 division in the
+// common case: q = x * (1 / vs) differs from the correctly rounded quotient by a few ulp, so both truncate alike
+// unless an integer lies within 1e-9 (|q| + 1) of q; only then is the real division evaluated.
+__device__ __forceinline__ int voxel_index(double x, double vs, double inv_vs) {
+    const double q = x * inv_vs;
+    int k = (int)q;
+    if (fabs(q - rint(q)) <= 1e-9 * (fabs(q) + 1.0)) k = (int)(x / vs);
+    return k;
+}
+
 // voxel index by C truncation toward zero, exactly (int)(coordinate / voxel_size)
 __device__ __forceinline__ bool vox_key(V3 p, double size, unsigned long long& key, int& kx, int& ky, int& kz) {
-    kx = (int)(p.x / size); ky = (int)(p.y / size); kz = (int)(p.z / size);
+    const double inv = 1.0 / size;  // (loop-invariant for the callers: one division per thread, not three per point)
+    kx = voxel_index(p.x, size, inv); ky = voxel_index(p.y, size, inv); kz = voxel_index(p.z, size, inv);
     const int ox = kx + KEY_OFF, oy = ky + KEY_OFF, oz = kz + KEY_OFF;
     const bool ok = ((unsigned)ox | (unsigned)oy | (unsigned)oz) < (1u << 21);
     key = ((unsigned long long)ox << 42) | ((unsigned long long)oy << 21) | (unsigned long long)oz;
@@ -371,44 +382,39 @@ __global__ __launch_bounds__(256) void k_build_lut(int H, int W, const double* a
 struct Slice { int b, nb, clk; };  // clk: this caller's thread 0 records the stage-internal clocks (make STAGES=1)
 __device__ __forceinline__ Slice launch_slice() { Slice s; s.b = (int)blockIdx.x; s.nb = (int)gridDim.x; s.clk = 0; return s; }
 #define STAGE_MAX_WAVES 16  /* blockDim.x <= 1024 */
-#define STAGE_MAX_U 8
+#define STAGE_MAX_U 16
 
-// U find-or-claims in a per-scan VDS table with their probes in flight together: the hashed slot of each (one load; one
-// compare-and-swap where it was empty), and whatever that does not settle (a collision) goes through vds_claim
+// U find-or-claims in a per-scan VDS table in flight together: the compare-and-swap on the hashed slot straight away (it
+// returns what was there: empty -> claimed, the key -> found; a look at the slot first would be one more dependent memory
+// round trip per pass), and whatever that does not settle (a collision) goes through vds_claim
 template <int U>
 __device__ __forceinline__ void vds_claim_u(VdsEnt* tab, unsigned mask, const unsigned long long (&key)[U], const bool (&want)[U],
                                             int (&slot)[U]) {
     unsigned s0[U];
-    unsigned long long cur[U], old[U];
+    unsigned long long old[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         s0[u] = brick_slot(key[u], mask);
-        cur[u] = want[u] ? tab[s0[u]].key : key[u];
         slot[u] = -1;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
         old[u] = key[u];
-        if (want[u] && cur[u] == EMPTY_KEY) old[u] = atomicCAS(&tab[s0[u]].key, EMPTY_KEY, key[u]);
+        if (want[u]) old[u] = atomicCAS(&tab[s0[u]].key, EMPTY_KEY, key[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (!want[u]) continue;
-        if (cur[u] == key[u] || (cur[u] == EMPTY_KEY && (old[u] == EMPTY_KEY || old[u] == key[u]))) slot[u] = (int)s0[u];
+        if (old[u] == EMPTY_KEY || old[u] == key[u]) slot[u] = (int)s0[u];
         else slot[u] = vds_claim(tab, mask, key[u]);
     }
 }
-// the claimed slots' bids: slot value = the smallest point index that maps to the voxel
+// the claimed slots' bids: slot value = the smallest point index that maps to the voxel (no result is needed: the
+// atomics are sent and not waited for)
 template <int U>
 __device__ __forceinline__ void vds_bid_u(VdsEnt* tab, const int (&slot)[U], const bool (&want)[U], const int (&idx)[U], int* err_flags) {
-    unsigned cur[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = (want[u] && slot[u] >= 0) ? tab[slot[u]].vmin : 0u;  // plain read: a stale (larger) value only costs a redundant atomicMin
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (!want[u]) continue;
         if (slot[u] < 0) atomicOr(err_flags, ERR_VDS_TABLE);
-        else if (cur[u] > (unsigned)idx[u]) atomicMin(&tab[slot[u]].vmin, (unsigned)idx[u]);  // the slot's value only ever decreases: a smaller one seen = nothing to do
+        else atomicMin(&tab[slot[u]].vmin, (unsigned)idx[u]);
     }
 }
 // number of set flags over the workgroup's U * blockDim.x points (every thread gets it)
@@ -475,6 +481,8 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
             }
         }
     }
+    Rt Mcol[2];
+    const bool col_period2 = U > 2 && ((2 * BS) % c.W) == 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = idx[u];
@@ -487,10 +495,14 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
                     for (int k = 0; k < 6; ++k) x[k] = s * st->xi[k];
                     p[u] = rt_apply(se3_exp(x), p[u]);
                 } else {
-                    const double* m = c.coltab + (size_t)(i % c.W);
-                    Rt M;
-                    for (int k = 0; k < 9; ++k) M.R[k] = m[(size_t)k * c.W];
-                    for (int k = 0; k < 3; ++k) M.t[k] = m[(size_t)(9 + k) * c.W];
+                    // (2 blockDim) % W == 0 (512 threads, 1024 columns): the thread's points u, u + 2, ... lie in one column - its
+                    // transform is loaded once for the even and once for the odd u instead of 12 words per point
+                    Rt& M = (u & 1) ? Mcol[1] : Mcol[0];
+                    if (u < 2 || !col_period2) {
+                        const double* m = c.coltab + (size_t)(i % c.W);
+                        for (int k = 0; k < 9; ++k) M.R[k] = m[(size_t)k * c.W];
+                        for (int k = 0; k < 3; ++k) M.t[k] = m[(size_t)(9 + k) * c.W];
+                    }
                     p[u] = rt_apply(M, p[u]);
                 }
             }
@@ -703,11 +715,20 @@ __device__ __forceinline__ void d_compact_src(const Ctx& c, const Slice sl) {
     const int off = block_offset(c.bcnt2, sl.b);
     int total;
     block_rank_u<U>(w2, rk, total);
+    {   // every winner's point requested before the first one is stored (a load -> store pair per u would cost one dependent
+        // memory round trip per u: some lane of the wavefront holds a winner for nearly every u)
+        double q[U][3];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        if (!w2[u]) continue;
-        const size_t i = (size_t)idx[u], o = (size_t)(off + rk[u]) * 3;
-        c.src0[o] = c.pts[3 * i]; c.src0[o + 1] = c.pts[3 * i + 1]; c.src0[o + 2] = c.pts[3 * i + 2];
+        for (int u = 0; u < U; ++u) {
+            const size_t i = (size_t)idx[u];
+            if (w2[u]) { q[u][0] = c.pts[3 * i]; q[u][1] = c.pts[3 * i + 1]; q[u][2] = c.pts[3 * i + 2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!w2[u]) continue;
+            const size_t o = (size_t)(off + rk[u]) * 3;
+            c.src0[o] = q[u][0]; c.src0[o + 1] = q[u][1]; c.src0[o + 2] = q[u][2];
+        }
     }
     if (threadIdx.x == 0 && sl.b == sl.nb - 1) c.st->n_src = off + total;
 }
@@ -736,16 +757,6 @@ __device__ __forceinline__ double sqrt_gate(double M) {
         T = __longlong_as_double(__double_as_longlong(T) - 1);
     for (int k = 0; k < 64 && sqrt(T) < M; ++k) T = __longlong_as_double(__double_as_longlong(T) + 1);
     return T;
-}
-
-// (int)(x / vs) - the voxel index of VoxelHashMap / VoxelDownsample (C truncation) - without the fp64 division in the
-// common case: q = x * (1 / vs) differs from the correctly rounded quotient by a few ulp, so both truncate alike
-// unless an integer lies within 1e-9 (|q| + 1) of q; only then is the real division evaluated.
-__device__ __forceinline__ int voxel_index(double x, double vs, double inv_vs) {
-    const double q = x * inv_vs;
-    int k = (int)q;
-    if (fabs(q - rint(q)) <= 1e-9 * (fabs(q) + 1.0)) k = (int)(x / vs);
-    return k;
 }
 
 // 32 lanes cooperate on one source point.  Lanes 0..26 probe the 27 neighbour voxels in (i,j,k) ascending order
@@ -1559,6 +1570,13 @@ template <int PC, int LP>
 __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, double inv_vs, int laneL, int gb, V3& t, double& m, bool& found, int& ctot,
                                            unsigned* xc) {
     constexpr int RE = 32 / LP;  // row entries per lane
+#ifdef GN_PHASE_CLOCKS
+#define SRCH_CLK(k) do { __builtin_amdgcn_s_waitcnt(0); const long long n_ = GN_CLK(); if (srch_me) atomicAdd((unsigned long long*)&c.wg_clk[61 + (k)], (unsigned long long)(n_ - srch_t)); srch_t = n_; } while (0)
+    const bool srch_me = it > 0 && blockIdx.x < 8 && threadIdx.x == 0;  // (thread 0 of workgroup 0 of the sequences on the first teams)
+    long long srch_t = GN_CLK();
+#else
+#define SRCH_CLK(k) do { } while (0)
+#endif
     const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
     const unsigned long long key = pack_key(kx, ky, kz);
     int r[RE];
@@ -1568,6 +1586,7 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
         for (int k = 0; k < RE / 4; ++k) { const int4 v = rp[k]; r[4 * k] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w; }
     }
     const bool same_voxel = it > 0 && c.pc_key[i] == key;
+    SRCH_CLK(0);  // row + key
     if (!same_voxel) {  // uniform over the group: probe this lane's neighbour voxels, rebuild the row
         int cs = 0;
         {   // this lane's RE probes with their first table reads in flight together; a collision walks on by itself
@@ -1606,6 +1625,7 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
         for (int k = 0; k < RE / 4; ++k) wp[k] = make_int4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
         if (laneL == 0) { c.pc_key[i] = key; atomicAdd(xc + 1, 1u); }
     }
+    SRCH_CLK(1);  // rebuild (some group of the wavefront changed voxel)
     const int lv_raw = __shfl(r[27 % RE], gb + 27 / RE);
     ctot = __shfl(r[28 % RE], gb + 28 / RE);
     const int lv = (lv_raw != 13) ? lv_raw : -1;
@@ -1666,6 +1686,7 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
         if (laneL == 0) atomicAdd(xc + 2, pb_count(pbc) + pb_count(pbl));
         scan_voxelsL<PC, LP, 2>(c, pb2, vx2, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
     }
+    SRCH_CLK(2);  // box distances + first round
     // the other voxels: dropped when their box lies farther than the best distance so far (exact, see nn_scan32)
     unsigned mine = 0u;
     double gdrop = 1.7976931348623157e308;  // smallest squared box distance among the voxels this lane dropped
@@ -1697,6 +1718,7 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
 #ifdef GN_PHASE_CLOCKS
     if (laneL == 0) { atomicAdd((unsigned long long*)&c.wg_clk[40], 1ull); if (!same_voxel) atomicAdd((unsigned long long*)&c.wg_clk[42], 1ull); }
 #endif
+    SRCH_CLK(3);  // survivors
     m = group_minL<LP>(bd);
     found = m < 1.7976931348623157e308;
     const unsigned bo = group_minL<LP>((bd == m) ? border : 0xFFFFFFFFu);
@@ -1744,6 +1766,11 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
         rw[0] = p2.x; rw[1] = p2.y; rw[2] = p2.z;
         rw[3] = __longlong_as_double((long long)((unsigned long long)bo | ((unsigned long long)(has2 ? o2 : 0xFFFFFFFFu) << 32)));
     }
+    SRCH_CLK(4);  // reductions + answer row
+#ifdef GN_PHASE_CLOCKS
+    if (srch_me) atomicAdd((unsigned long long*)&c.wg_clk[66], 1ull);
+#endif
+#undef SRCH_CLK
 }
 
 // packed upper triangle of JTJ (21) + JTr (6) from the 16 moments
@@ -1770,6 +1797,9 @@ __device__ __forceinline__ double sums_from_moments(int e, const double* M) {
 }
 
 #define GN8_ROW_ENTRIES 18   /* 16 moments, pair count, candidate count */
+#ifndef GN8_PREFETCH
+#define GN8_PREFETCH 1        /* chunks phase A requests ahead (1 or 2; make PF=2) */
+#endif
 #ifndef GN8_LDS_PTS
 #define GN8_LDS_PTS (6 * 512) /* source-point positions a workgroup keeps in LDS (72 KB) */
 #endif
@@ -1888,8 +1918,11 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     // this lane's point of chunk qb: block qb + wavefront of this workgroup, i.e. global block (qb + wavefront) G + wg
     auto chunk_point = [&](int qb, int& i) -> bool { const int q = qb + (tid >> 6); i = ((q * G + wg) << 6) + (tid & 63); return q < my_blocks && i < n; };
     auto pos_in_lds = [&](int qb) -> bool { return (qb / NW + 1) * NT <= GN8_LDS_PTS; };
-    Gn8Pre pre;
-    { int i0; const bool v0 = chunk_point(0, i0); pre = gn8_preload(c, i0, v0, true, true); }
+    // (two chunks ahead, GN8_PREFETCH = 2: tried - no faster, the loop got 3 % slower)
+    auto preload_chunk = [&](int qb, bool first) -> Gn8Pre { int i2; const bool v2 = chunk_point(qb, i2); return gn8_preload(c, i2, v2, first, first || !pos_in_lds(qb)); };
+    Gn8Pre pre = preload_chunk(0, true);
+    [[maybe_unused]] Gn8Pre pre2 = pre;
+    if (GN8_PREFETCH > 1) pre2 = preload_chunk(NW, true);
     for (int it = 0; it < c.max_iter; ++it) {
         const long long c0 = GN_CLK();
         const double* Esh = Esh2[(it + 1) & 1];
@@ -1901,6 +1934,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         for (int qb = 0; qb < my_blocks; qb += NW) {
             V3 sA;         // this lane's point of phase A
             int missA = -1;  // ... and its index when the answer row did not settle it
+#ifdef GN_PHASE_CLOCKS
+            const long long pa0 = GN_CLK();
+#endif
             // ---- phase A, ONE LANE PER POINT (one pass, one memory round trip): apply the increment, look at the point's
             // answer row.  The last full search of the point (at s0, same voxel => same 27-voxel candidate set) found t and
             // every other candidate - scanned, or inside a dropped voxel's box - at >= D from s0.  After a move by
@@ -1917,11 +1953,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 int i;
                 const bool valid = chunk_point(qb, i);
                 const Gn8Pre cur = pre;
-                if (qb + NW < my_blocks) {  // the next chunk's loads, in flight while this one is evaluated
-                    int i2;
-                    const bool v2 = chunk_point(qb + NW, i2);
-                    pre = gn8_preload(c, i2, v2, it == 0, it == 0 || !pos_in_lds(qb + NW));
-                }
+                if (GN8_PREFETCH > 1) {
+                    pre = pre2;
+                    if (qb + 2 * NW < my_blocks) pre2 = preload_chunk(qb + 2 * NW, it == 0);  // in flight while this chunk and the next are evaluated
+                } else if (qb + NW < my_blocks) pre = preload_chunk(qb + NW, it == 0);
                 int miss = -1;
                 sA = v3(0.0, 0.0, 0.0);
                 if (valid) {
@@ -1963,6 +1998,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 }
                 missA = miss;
             }
+#ifdef GN_PHASE_CLOCKS
+            const long long pa1 = GN_CLK();
+#endif
             // the noted points join the queue in point order (deterministic): wavefront scan, wavefront offsets.  A
             // workgroup with more points than threads (four sequences per XCD) walks them in chunks; the chunks' misses
             // share the search passes below - a pass costs its memory round trips whether 9 or 64 points ride on it.
@@ -1987,6 +2025,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 }
                 nq += total;
             }
+#ifdef GN_PHASE_CLOCKS
+            const long long pa2 = GN_CLK();
+            if (wg == 0 && tid == 0 && it > 0) { atomicAdd((unsigned long long*)&c.wg_clk[56], (unsigned long long)(pa1 - pa0)); atomicAdd((unsigned long long*)&c.wg_clk[57], (unsigned long long)(pa2 - pa1)); atomicAdd((unsigned long long*)&c.wg_clk[59], 1ull); }
+#endif
             if (qb + NW < my_blocks && nq + NT <= GN8_QCAP) continue;  // room for another chunk's misses
             __syncthreads();
             const int nmiss = nq;
@@ -2036,16 +2078,19 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             if (GN8_IT0_LP != GN8_LPB && it == 0) phaseB(std::integral_constant<int, GN8_IT0_LP>{});  // (every point searches: more points per pass)
             else phaseB(std::integral_constant<int, GN8_LPB>{});
             __syncthreads();  // the queue is reused by the next chunk
+#ifdef GN_PHASE_CLOCKS
+            if (wg == 0 && tid == 0 && it > 0) { atomicAdd((unsigned long long*)&c.wg_clk[58], (unsigned long long)(GN_CLK() - pa2)); atomicAdd((unsigned long long*)&c.wg_clk[60], (unsigned long long)((nmiss + NT / GN8_LPB - 1) / (NT / GN8_LPB))); }
+#endif
             {   // (queue flushed before the last chunk: its loads are requested again rather than carried across the search;
                 // after the last chunk nothing is loaded - chunk_point says so - and the stale values are dead for the compiler too)
-                int i2;
-                const bool v2 = chunk_point(qb + NW, i2);
-                pre = gn8_preload(c, i2, v2, it == 0, it == 0 || !pos_in_lds(qb + NW));
+                pre = preload_chunk(qb + NW, it == 0);
+                if (GN8_PREFETCH > 1) pre2 = preload_chunk(qb + 2 * NW, it == 0);
             }
         }
         // the next iteration's first chunk: positions and answer rows as this iteration leaves them (the searches above have
         // written theirs), requested now - they arrive while the sums are exchanged and the system is solved
-        { int i0; const bool v0 = chunk_point(0, i0); pre = gn8_preload(c, i0, v0, false, !pos_in_lds(0)); }
+        pre = preload_chunk(0, false);
+        if (GN8_PREFETCH > 1) pre2 = preload_chunk(NW, false);
         const long long c1 = GN_CLK();
         // ---- workgroup reduction, fixed tree: the 64 lanes of a wavefront (DPP inside the rows, two crossbar steps across
         // them), then the wavefronts in order
@@ -2301,13 +2346,14 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
         old[u] = key[u];
         if (keyed[u] && cur[u] == EMPTY_KEY) old[u] = atomicCAS(&c.tab[s0[u]].key, EMPTY_KEY, key[u]);
     }
+    bool created[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+        created[u] = false;
         if (!keyed[u]) continue;
         unsigned s = s0[u];
-        bool created = false;
         if (cur[u] == key[u] || (cur[u] == EMPTY_KEY && old[u] == key[u])) slot[u] = (int)s;
-        else if (cur[u] == EMPTY_KEY && old[u] == EMPTY_KEY) { slot[u] = (int)s; created = true; }
+        else if (cur[u] == EMPTY_KEY && old[u] == EMPTY_KEY) { slot[u] = (int)s; created[u] = true; }
         else {  // occupied by another voxel or a tombstone (or the swap lost to another key): linear probing goes on
             s = (s + 1) & c.tmask;
             for (unsigned probe = 1; probe <= c.tmask; ++probe) {
@@ -2315,31 +2361,43 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
                 if (ck == key[u]) { slot[u] = (int)s; break; }
                 if (ck == EMPTY_KEY) {
                     const unsigned long long o = atomicCAS(&c.tab[s].key, EMPTY_KEY, key[u]);
-                    if (o == EMPTY_KEY) { slot[u] = (int)s; created = true; break; }
+                    if (o == EMPTY_KEY) { slot[u] = (int)s; created[u] = true; break; }
                     if (o == key[u]) { slot[u] = (int)s; break; }
                 }
                 s = (s + 1) & c.tmask;
             }
         }
-        if (created) {  // take a block from the pool
-            const int top = atomicSub(&st->free_top, 1) - 1;
-            int b = -1;
-            if (top < 0) atomicAdd(&st->free_top, 1);  // pool exhausted: put the count back (the prune pass pushes at free_top: it must not find it negative)
-            if (top >= 0) {
-                b = c.free_stack[top];
-                int* h = blk_hdr(c, b);
+        if (slot[u] < 0) atomicOr(&st->err_flags, ERR_TABLE);
+    }
+    {   // the new voxels take their blocks from the pool: every step for all U points at once (the pops, then the reads of the
+        // free stack, then the headers) - step by step per point it is a chain of dependent memory round trips per u, and some
+        // lane of a wavefront creates a voxel for nearly every u
+        int top[U], blk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) top[u] = created[u] ? atomicSub(&st->free_top, 1) - 1 : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            blk[u] = -1;
+            if (!created[u]) continue;
+            if (top[u] < 0) atomicAdd(&st->free_top, 1);  // pool exhausted: put the count back (the prune pass pushes at free_top: it must not find it negative)
+            else blk[u] = c.free_stack[top[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!created[u]) continue;
+            if (blk[u] >= 0) {
+                int* h = blk_hdr(c, blk[u]);
                 h[0] = 0;
                 h[1] = slot[u];
                 atomicAdd(&st->n_live, 1);
-                atomicMax(&st->pool_hw, b + 1);
+                atomicMax(&st->pool_hw, blk[u] + 1);
             } else {
                 atomicOr(&st->err_flags, ERR_POOL);
             }
-            c.tab[s].blk = b;
+            c.tab[slot[u]].blk = blk[u];
             const unsigned used = atomicAdd(&st->tab_used, 1u) + 1u;
             if (used > (c.tmask + 1u) / 4u * 3u) atomicOr(&st->err_flags, ERR_TABLE);
         }
-        if (slot[u] < 0) atomicOr(&st->err_flags, ERR_TABLE);
     }
     int nx[U];
 #pragma unroll
@@ -2376,6 +2434,13 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
     int cnt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cnt[u] = (slot[u] >= 0 && pb[u] >= 0) ? blk_hdr(c, pb[u] & BLK_ID_MASK)[0] : 0;
+    double w[U][3];  // (requested for all U points before the first store: see d_compact_src)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = (size_t)idx[u];
+        const bool ins = idx[u] < n && slot[u] >= 0 && pb[u] >= 0 && cnt[u] + rank[u] < c.P;
+        if (ins) { w[u][0] = c.fdw[3 * i]; w[u][1] = c.fdw[3 * i + 1]; w[u][2] = c.fdw[3 * i + 2]; }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (idx[u] >= n) continue;
@@ -2387,7 +2452,7 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
         const int pos = cnt[u] + rank[u];
         if (pos < c.P) {
             double* X = blk_x(c, pb[u] & BLK_ID_MASK);
-            X[3 * pos] = c.fdw[3 * i]; X[3 * pos + 1] = c.fdw[3 * i + 1]; X[3 * pos + 2] = c.fdw[3 * i + 2];
+            X[3 * pos] = w[u][0]; X[3 * pos + 1] = w[u][1]; X[3 * pos + 2] = w[u][2];
         }
     }
 }

@@ -213,8 +213,11 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     c.P = cfg->max_points_per_voxel; c.deskew = cfg->deskew; c.max_iter = cfg->max_iterations;
     c.W = cfg->scan_cols > 0 ? cfg->scan_cols : 1;
     c.n_max = (int)n;
+    // per-scan voxel tables: 8 slots per point.  A table line holds a 2x2x2 brick of voxels (brick_slot), so what counts is how many
+    // LINES are taken: at 2 slots per point a third of them were, and every voxel of a brick that landed on a taken line walked on
+    // through dependent reads; the lines a scan touches do not depend on the table's size.
     size_t vcap = 1024;
-    while (vcap < (size_t)(2 * n)) vcap <<= 1;
+    while (vcap < (size_t)(8 * n)) vcap <<= 1;
     c.vmask = (unsigned)(vcap - 1);
     c.tmask = (unsigned)(cfg->map_table_capacity - 1);
     c.bstride = (int)(((size_t)c.P * 24 + 16 + 127) / 128 * 128);

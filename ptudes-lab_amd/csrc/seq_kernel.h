@@ -85,7 +85,10 @@ __device__ __forceinline__ unsigned xcc_id() {
 // the sequence table itself (scalar loads), like the per-stage kernels.
 #define SEQ_FAIL 0xFFFFFFFFu
 #ifndef SEQ_U
-#define SEQ_U 8  /* points per thread and pass in K1-K4 and the map update (see Slice): 4 -> 8 took K0-K4 of a team of 2 from 1585 to 1406 us */
+#define SEQ_U 8  /* points per thread and pass in K1 and the map update (see Slice): 4 -> 8 took K0-K4 of a team of 2 from 1585 to 1406 us */
+#endif
+#ifndef SEQ_U2
+#define SEQ_U2 16  /* ... in K2-K4 (a few registers per point: an index, a slot, two flags); they share their block size through bcnt1 / bcnt2 */
 #endif
 // make STAGES=1: workgroup 0 of every sequence adds the wall-clock ticks of every stage and of every barrier wait to
 // st->dbg_sums[0..19] (tools/free_vs_lockstep.py prints them)
@@ -101,6 +104,7 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     const Ctx c = load_seq_ctx(a, s, k);
     DevState* st = c.st;
     const int BS = (int)blockDim.x * SEQ_U, nbs = (c.n_in + BS - 1) / BS;
+    const int BS2 = (int)blockDim.x * SEQ_U2, nbs2 = (c.n_in + BS2 - 1) / BS2;
     Slice sl;
     sl.nb = nbs; sl.clk = wg == 0 ? 1 : 0;
     const TeamEnv te = {word, &st->gn_abort, st, local};
@@ -113,15 +117,16 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     SQ_CLK(2);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(3);
-    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_vds2<SEQ_U>(c, sl);
+    sl.nb = nbs2;
+    for (sl.b = wg; sl.b < nbs2; sl.b += nw) d_vds2<SEQ_U2>(c, sl);
     SQ_CLK(4);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(5);
-    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_fd<SEQ_U>(c, sl);
+    for (sl.b = wg; sl.b < nbs2; sl.b += nw) d_compact_fd<SEQ_U2>(c, sl);
     SQ_CLK(6);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(7);
-    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_compact_src<SEQ_U>(c, sl);
+    for (sl.b = wg; sl.b < nbs2; sl.b += nw) d_compact_src<SEQ_U2>(c, sl);
     SQ_CLK(8);
     return target;
 }

@@ -29,6 +29,12 @@ try:
         print("searches (all workgroups of sequence 0): %.0f per scan, survivor rounds per search %.2f, row rebuilt (voxel changed / first iteration) %.1f %%" % (w[40] / n, w[41] / w[40], 100 * w[42] / w[40]))
     if w[52] > 0:
         print("point loop of workgroup 0: first iteration %.0f ticks per scan, the others %.0f per iteration" % (w[52] / nscan_all, w[53] / max(it - nscan_all, 1)))
+    if w[59] > 0:
+        print("workgroup 0 of sequence 0, iterations > 0: per chunk of phase A: wait for the loads + evaluation %.0f ticks, compaction %.0f; chunks per iteration %.1f;  per search pass %.0f ticks (%.1f passes per iteration)"
+              % (w[56] / w[59], w[57] / w[59], w[59] / max(it - nscan_all, 1), w[58] / max(w[60], 1), w[60] / max(it - nscan_all, 1)))
+    if w[66] > 0:
+        print("one search (thread 0 of the first teams' workgroup 0, iterations > 0, every step waited out), ticks: row + key %.0f | rebuild %.0f | boxes + first round %.0f | survivors %.0f | reductions + answer row %.0f   (%d searches)"
+              % tuple(list(w[61:66] / w[66]) + [int(w[66])]))
     if w[44] + w[45] > 0:
         print("bound of the others after a search: third-nearest candidate %.1f %%, box of a dropped voxel %.1f %%;  bound / winner's distance in [1,1.2) [1.2,1.5) [1.5,2) [2,3) [3,..): %s %%"
               % (100 * w[44] / (w[44] + w[45]), 100 * w[45] / (w[44] + w[45]), np.round(100 * w[46:51] / max(w[46:51].sum(), 1), 1).tolist()))
