@@ -55,10 +55,11 @@ def scan_bytes(s, n_raw):
 EXEC_COST = {
     # Gauss-Newton loop (gn8_body): the first iteration of a scan reads every source point (24); the positions then live in the
     # workgroup's LDS (GN8_LDS_PTS = 3072 per workgroup), only the points beyond that are written (24) and read back (24) through
-    # src_cur every iteration; after the first iteration phase A also reads the voxel key (8) and the 96-byte answer row
-    "source_read": 24, "point_iteration_in_memory": 48, "point_iteration_later": 104, "lds_points_per_workgroup": 3072,
-    # a full search reads the probe row (128) + key (8), writes the answer row (96) + the winner's voxel (4)
-    "search": 236,
+    # src_cur every iteration; after the first iteration phase A also reads the voxel key (8) and the 144-byte answer row
+    # (position of the last search, its four nearest candidates, the bound on everybody else, ids: GN8_KCAND = 4)
+    "source_read": 24, "point_iteration_in_memory": 48, "point_iteration_later": 152, "lds_points_per_workgroup": 3072,
+    # a full search reads the probe row (128) + key (8), writes the answer row (144) + the winner's voxel (4)
+    "search": 284,
     # a rebuilt probe row: 27 hash-table entries of 16 B, the row (128) and the key (8) written
     "row_rebuilt": 27 * 16 + 136,
     "map_point_read": 24,

@@ -136,7 +136,7 @@ struct Ctx {
     const double* ext_guess;  // device 4x4 or null
     unsigned long long* pc_key;  // [n_max]      multi-pass probe cache: voxel key of source point i at its last probe
     int* pc_pb;                  // [n_max][32]  and the 27 probe results (block id | count << 24, -1 = absent)
-    double* pc_ans;              // [n_max][12]  8-lane kernel: exact answer cache (s0 | winner | distance bound of the others | candidate count | runner-up | order ids)
+    double* pc_ans;              // [n_max][GN8_ANS_ROW]  8-lane kernel: exact answer cache (s0 | the K nearest candidates | distance bound of the others | order ids, counts)
     unsigned long long* gn_rows_ll;  // [2][G][64]      per-workgroup sums as (32 data bits | 32 flag bits) words
     unsigned long long* gn_xsum_ll;  // [2][8][8][64]   per-group sums, one copy per consumer slot
     int overlap_pre;          // the next scan's K0-K4 run beside this scan's map update (own stream): see flush_map_stats
@@ -620,11 +620,16 @@ __device__ __forceinline__ void d_vds2(const Ctx& c, const Slice sl) {
 
 // exclusive prefix of per-block counts + in-block rank (scan order preserved)
 // (integer sums: any grouping gives the same value)
-__device__ __forceinline__ int block_offset(const int* bcnt, int b) {
-    __shared__ int red[STAGE_MAX_WAVES];
-    const int nw = (int)blockDim.x >> 6;
+// (in two steps: the reads of the block counts are requested at the top of a pass, together with its other loads, and summed
+// where the offset is needed - one dependent memory round trip per pass less)
+__device__ __forceinline__ int block_offset_part(const int* bcnt, int b) {
     int s = 0;
     for (int k = threadIdx.x; k < b; k += (int)blockDim.x) s += bcnt[k];
+    return s;
+}
+__device__ __forceinline__ int block_offset(int s) {
+    __shared__ int red[STAGE_MAX_WAVES];
+    const int nw = (int)blockDim.x >> 6;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -664,6 +669,7 @@ __device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     int idx[U], s2[U], rk[U];
     bool w1[U], w2[U];
+    const int off_part = block_offset_part(c.bcnt1, sl.b);
 #pragma unroll
     for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s2[u] = (idx[u] < c.n_in) ? c.slot2[idx[u]] : -1; }  // K2: slot2 >= 0 <=> pass-1 winner
     {
@@ -673,7 +679,7 @@ __device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl) {
 #pragma unroll
         for (int u = 0; u < U; ++u) w2[u] = w1[u] && (vm[u] == (unsigned)idx[u]);
     }
-    const int off = block_offset(c.bcnt1, sl.b);
+    const int off = block_offset(off_part);
     int total;
     block_rank_u<U>(w1, rk, total);
     {
@@ -710,9 +716,10 @@ __device__ __forceinline__ void d_compact_src(const Ctx& c, const Slice sl) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     int idx[U], rk[U];
     bool w2[U];
+    const int off_part = block_offset_part(c.bcnt2, sl.b);
 #pragma unroll
     for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; w2[u] = (idx[u] < c.n_in) && c.slot2[idx[u]] >= 0; }  // K3: slot2 >= 0 <=> pass-2 winner
-    const int off = block_offset(c.bcnt2, sl.b);
+    const int off = block_offset(off_part);
     int total;
     block_rank_u<U>(w2, rk, total);
     {   // every winner's point requested before the first one is stored (a load -> store pair per u would cost one dependent
@@ -1464,7 +1471,12 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
 //   * wavefront reduction by DPP, workgroup reduction through LDS in wavefront order, one 18-entry row per workgroup;
 //     exchange in one hop (<= 64 workgroups: the first wavefront polls every row itself and solves straight away) or in
 //     two hops through 8 group leaders (one sequence over the whole chip).
-#define GN8_ANS_ROW 12        /* doubles per answer row: s0 (3) | winner (3) | bound | candidate count | runner-up (3) | the two order ids */
+#ifndef GN8_KCAND
+#define GN8_KCAND 4           /* candidates an answer row keeps (2..5); a CPU simulation of the policy on the bench's sweeps: repeated searches per scan
+                                 32 k (1) | 11.5 k (2) | 6.5 k (3) | 4.4 k (4) | 2.4 k (6) for ~6800 source points x 36 iterations */
+#endif
+#define GN8_ANS_ROW ((3 + 3 * GN8_KCAND + 2 + 1) & ~1)  /* doubles per answer row: s0 (3) | the K nearest candidates (3 each) | bound | ids, counts (packed) [| pad] */
+#define GN8_ANS_D (3 + 3 * GN8_KCAND)
 #ifndef GN8_SPEC
 #define GN8_SPEC 1            /* first search round takes the two nearest other boxes along (speculatively): 7.14 k against 7.07 k scans/s for 16 sequences */
 #endif
@@ -1719,27 +1731,44 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
     if (laneL == 0) { atomicAdd((unsigned long long*)&c.wg_clk[40], 1ull); if (!same_voxel) atomicAdd((unsigned long long*)&c.wg_clk[42], 1ull); }
 #endif
     SRCH_CLK(3);  // survivors
-    m = group_minL<LP>(bd);
-    found = m < 1.7976931348623157e308;
-    const unsigned bo = group_minL<LP>((bd == m) ? border : 0xFFFFFFFFu);
-    const bool win = found && bd == m && border == bo;
-    t = v3(group_bcastL<LP>(win ? bp.x : 0.0), group_bcastL<LP>(win ? bp.y : 0.0), group_bcastL<LP>(win ? bp.z : 0.0));
+    // ---- the group's GN8_KCAND nearest candidates in (distance, visiting order) order.  Every lane holds its own two nearest
+    // (bd / b2d) and the smallest distance that lost to both (sd): K rounds of "every lane offers the nearest it has not
+    // given yet, the group's minimum takes it"; what is left - the lanes' next offers, sd, the boxes of the dropped voxels -
+    // is at least sqrt(D2) away from s and bounds everybody who is not in the row.  (A lane that holds three of the true K
+    // nearest contributes two, its third goes into the bound: the row is then a little less useful, never wrong.)  The first
+    // is the answer of the search; the winning lanes store their points straight into the row.
+    const double INF = 1.7976931348623157e308;
+    int taken = 0;
+    unsigned long long meta = 0ull;
+    int nvalid = 0;
+    unsigned bo = 0xFFFFFFFFu;
+    m = INF;
+    t = v3(0.0, 0.0, 0.0);
+    double* arow = c.pc_ans + GN8_ANS_ROW * (size_t)i;
+#pragma unroll
+    for (int r4 = 0; r4 < GN8_KCAND; ++r4) {
+        const double od = taken == 0 ? bd : taken == 1 ? b2d : INF;
+        const unsigned oo = taken == 0 ? border : taken == 1 ? b2o : 0xFFFFFFFFu;
+        const double mr = group_minL<LP>(od);
+        const unsigned orr = group_minL<LP>((od == mr) ? oo : 0xFFFFFFFFu);
+        const bool has = mr < INF;
+        const bool win = has && od == mr && oo == orr;
+        const V3 pp = taken == 0 ? bp : b2p;
+        if (r4 == 0) {
+            m = mr; bo = orr;
+            t = v3(group_bcastL<LP>(win ? pp.x : 0.0), group_bcastL<LP>(win ? pp.y : 0.0), group_bcastL<LP>(win ? pp.z : 0.0));
+        }
+        if (win) { arow[3 + 3 * r4] = pp.x; arow[4 + 3 * r4] = pp.y; arow[5 + 3 * r4] = pp.z; ++taken; }
+        meta |= (unsigned long long)(has ? (orr & 0x3FFu) : 0x3FFu) << (10 * r4);
+        nvalid += has ? 1 : 0;
+    }
+    found = m < INF;
     const int lv_new = found ? (int)(bo >> 5) : -1;
     if (laneL == 27 / RE && lv_new != lv_raw) c.pc_pb[32 * (size_t)i + 27] = lv_new;
-    // The answer row keeps the TWO nearest candidates (the runner-up bounded 93 % of the rows when only the winner was kept,
-    // and the dropped boxes usually allow much more): second = the best of what is left after the winner - the winning
-    // lane offers its second-best, the others their best.  Everybody else - the lanes' remaining candidates, what lost to
-    // both inside a lane, the boxes of the dropped voxels - is at least sqrt(D2) away from s.
-    const double od = win ? b2d : bd;
-    const unsigned oo = win ? b2o : border;
-    const double m2 = group_minL<LP>(od);
-    const unsigned o2 = group_minL<LP>((od == m2) ? oo : 0xFFFFFFFFu);
-    const bool has2 = m2 < 1.7976931348623157e308;
-    const bool win2 = has2 && od == m2 && oo == o2;
-    const double rest = (win || win2) ? ((win && win2) ? sd : b2d) : bd;
+    const double rest = taken == 0 ? bd : taken == 1 ? b2d : sd;
     const double D2 = group_minL<LP>(fmin(rest, gdrop));
 #ifdef GN_PHASE_CLOCKS
-    {   // what bounds everybody else: a candidate that was scanned (the third nearest) or the box of a dropped voxel?
+    {   // what bounds everybody else: a candidate that was scanned or the box of a dropped voxel?
         const double Dc = group_minL<LP>(rest), Dg = group_minL<LP>(gdrop);
         if (laneL == 0 && found) {
             atomicAdd((unsigned long long*)&c.wg_clk[44 + (Dc <= Dg ? 0 : 1)], 1ull);
@@ -1751,20 +1780,11 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
     double sl2 = -1.0;
     if (found && D2 < 1.0e300) sl2 = sqrt(D2) * (1.0 - 1e-6) - 1e-9;  // (a little less is stored: the margin of the test)
     else if (found) sl2 = 1.0e300;  // nobody else in reach of this voxel
-    const double row8[8] = {s.x, s.y, s.z, t.x, t.y, t.z, sl2, (double)ctot};
-#pragma unroll
-    for (int k = 0; k < 8 / LP; ++k) {
-        double av = row8[0];
-#pragma unroll
-        for (int e = 1; e < 8; ++e) av = ((8 / LP) * laneL + k == e) ? row8[e] : av;
-        c.pc_ans[GN8_ANS_ROW * (size_t)i + (8 / LP) * laneL + k] = av;
-    }
-    // entries 8..11: the runner-up and the two order ids (bo | o2 << 32; o2 = ~0: there is no runner-up)
-    if (win2 || (!has2 && laneL == 0)) {
-        const V3 p2 = win ? b2p : bp;
-        double* rw = c.pc_ans + GN8_ANS_ROW * (size_t)i + 8;
-        rw[0] = p2.x; rw[1] = p2.y; rw[2] = p2.z;
-        rw[3] = __longlong_as_double((long long)((unsigned long long)bo | ((unsigned long long)(has2 ? o2 : 0xFFFFFFFFu) << 32)));
+    if (laneL == 0) {  // s0 | ... | bound | order ids (10 bits each), candidate count of the 27 voxels, candidates in the row
+        arow[0] = s.x; arow[1] = s.y; arow[2] = s.z;
+        arow[GN8_ANS_D] = sl2;
+        meta |= (unsigned long long)(unsigned)ctot << 50 | (unsigned long long)(unsigned)nvalid << 60;
+        arow[GN8_ANS_D + 1] = __longlong_as_double((long long)meta);
     }
     SRCH_CLK(4);  // reductions + answer row
 #ifdef GN_PHASE_CLOCKS
@@ -1836,21 +1856,23 @@ __device__ __forceinline__ void gn8_accumulate(double (&M)[GN8_ROW_ENTRIES], V3 
 struct Gn8Pre {
     double px, py, pz;
     unsigned long long key;
-    double2 r0, r1, r2, r3, r4, r5;  // s0.xy | s0.z t.x | t.yz | bound, count | t2.xy | t2.z, order ids
+    double2 r[GN8_ANS_ROW / 2];  // the answer row
 };
 // want_pos: the point's previous position comes from memory (the scan's first iteration: src0; later: src_cur for the points
 // that do not fit the workgroup's LDS copy, gn8_body)
 __device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, bool first, bool want_pos) {
     Gn8Pre p;
     p.px = p.py = p.pz = 0.0; p.key = EMPTY_KEY;
-    p.r0 = p.r1 = p.r2 = p.r3 = p.r4 = p.r5 = make_double2(0.0, -1.0);
+#pragma unroll
+    for (int k = 0; k < GN8_ANS_ROW / 2; ++k) p.r[k] = make_double2(-1.0, -1.0);  // (bound < 0: no answer)
     if (valid) {
         const double* sp0 = first ? c.src0 : c.src_cur;
         if (want_pos) { p.px = sp0[3 * (size_t)i]; p.py = sp0[3 * (size_t)i + 1]; p.pz = sp0[3 * (size_t)i + 2]; }
         if (!first) {
             p.key = c.pc_key[i];
             const double2* row = (const double2*)(c.pc_ans + GN8_ANS_ROW * (size_t)i);
-            p.r0 = row[0]; p.r1 = row[1]; p.r2 = row[2]; p.r3 = row[3]; p.r4 = row[4]; p.r5 = row[5];
+#pragma unroll
+            for (int k = 0; k < GN8_ANS_ROW / 2; ++k) p.r[k] = row[k];
         }
     }
     return p;
@@ -1973,23 +1995,29 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     miss = i;
                     if (it > 0) {
                         const unsigned long long old_key = cur.key;
-                        const double2 r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, r3 = cur.r3, r4 = cur.r4, r5 = cur.r5;
                         const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
-                        const double ex = s.x - r0.x, ey = s.y - r0.y, ez = s.z - r1.x;
-                        const double delta2 = ex * ex + ey * ey + ez * ez;
                         if (old_key == pack_key(kx, ky, kz)) {
-                            V3 t = v3(r1.y, r2.x, r2.y);
-                            const double dx = t.x - s.x, dy = t.y - s.y, dz = t.z - s.z;
-                            double m = dx * dx + dy * dy + dz * dz;  // the expression the search evaluates for this candidate
-                            {   // the runner-up of the last search may have become the nearer one: same comparison as the search's
-                                const unsigned long long ids = (unsigned long long)__double_as_longlong(r5.y);
-                                const unsigned o1 = (unsigned)ids, o2 = (unsigned)(ids >> 32);
-                                const double ux = r4.x - s.x, uy = r4.y - s.y, uz = r5.x - s.z;
-                                const double mu = ux * ux + uy * uy + uz * uz;
-                                if (o2 != 0xFFFFFFFFu && (mu < m || (mu == m && o2 < o1))) { m = mu; t = v3(r4.x, r4.y, r5.x); }
+                            double row[GN8_ANS_ROW];
+#pragma unroll
+                            for (int k = 0; k < GN8_ANS_ROW / 2; ++k) { row[2 * k] = cur.r[k].x; row[2 * k + 1] = cur.r[k].y; }
+                            const double ex = s.x - row[0], ey = s.y - row[1], ez = s.z - row[2];
+                            const double delta2 = ex * ex + ey * ey + ez * ez;
+                            const unsigned long long meta = (unsigned long long)__double_as_longlong(row[GN8_ANS_D + 1]);
+                            const int nvalid = (int)(meta >> 60), ctot_row = (int)((meta >> 50) & 0x3FFull);
+                            // whichever of the row's candidates is nearest NOW, by the search's own comparison (distance, then visiting order)
+                            double m = 1.7976931348623157e308;
+                            unsigned mo = 0xFFFFFFFFu;
+                            V3 t = v3(0.0, 0.0, 0.0);
+#pragma unroll
+                            for (int j = 0; j < GN8_KCAND; ++j) {
+                                const V3 cj = v3(row[3 + 3 * j], row[4 + 3 * j], row[5 + 3 * j]);
+                                const double dx = cj.x - s.x, dy = cj.y - s.y, dz = cj.z - s.z;
+                                const double d2 = dx * dx + dy * dy + dz * dz;  // the expression the search evaluates for this candidate
+                                const unsigned oj = (unsigned)((meta >> (10 * j)) & 0x3FFull);
+                                if (j < nvalid && (d2 < m || (d2 == m && oj < mo))) { m = d2; mo = oj; t = cj; }
                             }
-                            if (sqrt(m) + sqrt(delta2) < r3.x) {  // (bound < 0: no answer stored)
-                                M[17] += r3.y;
+                            if (nvalid > 0 && sqrt(m) + sqrt(delta2) < row[GN8_ANS_D]) {  // (bound < 0: no answer stored)
+                                M[17] += (double)ctot_row;
                                 if (m < gate2) gn8_accumulate(M, s, t, kern, k2);
                                 miss = -1;
                             }
@@ -2055,7 +2083,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                         const int kx0 = voxel_index(s.x, c.vs, inv_vs), ky0 = voxel_index(s.y, c.vs, inv_vs), kz0 = voxel_index(s.z, c.vs, inv_vs);
                         old_same_key = c.pc_key[i] == pack_key(kx0, ky0, kz0);
                         old_t[0] = c.pc_ans[GN8_ANS_ROW * (size_t)i + 3]; old_t[1] = c.pc_ans[GN8_ANS_ROW * (size_t)i + 4]; old_t[2] = c.pc_ans[GN8_ANS_ROW * (size_t)i + 5];
-                        old_sl = c.pc_ans[GN8_ANS_ROW * (size_t)i + 6];
+                        old_sl = c.pc_ans[GN8_ANS_ROW * (size_t)i + GN8_ANS_D];
                     }
 #endif
                     gn8_search<PC, LPB>(c, i, it, s, inv_vs, laneL, gb, t, m, found, ctot, xcnt);
