@@ -267,8 +267,8 @@ def free_running(args, S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--seqs-per-gpu", type=int, default=DEFAULT_SEQS,
                     help="independent sequences per GPU (SURVEY.md 8(e), second level), batched runner.  The sequences s = x (mod 8) "
                          "live on XCD x, whose teams of workgroups take their scans as they come free (--team-wgs).  1 = the "

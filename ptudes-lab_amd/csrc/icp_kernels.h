@@ -1456,8 +1456,9 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
 // point search above is VALU-issue-bound there - every lane executes the whole search for voxels that hold 7-8 points on
 // average.  Per iteration (gn8_body):
 //   * phase A, one LANE per point, one pass: apply the increment, test the point's answer row (exact answer cache: the
-//     neighbour of the last full search provably stays the nearest while the point has moved less than a slack derived
-//     from the second-nearest distance and the dropped voxels' boxes); settled points go straight into the lane's sums;
+//     GN8_KCAND nearest candidates of the last full search and a bound on everybody else - whichever of them is nearest
+//     now provably is what a search would return while the point has moved less than the bound allows); settled points
+//     go straight into the lane's sums;
 //   * the others are compacted in point order (deterministic) and get the full 27-voxel search with 8 lanes per point
 //     (gn8_search): 128-byte probe row per point in memory (lane l holds entries 4 l .. 4 l + 3; entry 27 = the voxel of
 //     the last winner, entry 28 = the candidate count of the 27 voxels), box distances from the point alone, first round
@@ -1967,10 +1968,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             // this lane's sums.  The test uses the CURRENT distance to t: Gauss-Newton moves a point towards its neighbour
             // more often than away from it, and a move towards t costs no margin at all (with the distance at s0 instead,
             // d0 + 2 delta < D, 88 % of the repeated searches returned the neighbour they already had).  The row keeps the
-            // two nearest candidates of the search, "t" is whichever of them is nearer NOW (the search's own comparison,
-            // order ids included) and D bounds everybody else.  Row: s0 (3) | winner (3) | D less a safety margin, < 0 =
-            // no answer | candidate count of the 27 voxels | runner-up (3) | order ids.  The distance, the gate and the
-            // weight come from the current s either way - same values as after a search.
+            // GN8_KCAND nearest candidates of the search, "t" is whichever of them is nearest NOW (the search's own comparison,
+            // order ids included) and D bounds everybody else.  Row: s0 (3) | the candidates (3 each) | D less a safety
+            // margin, < 0 = no answer | order ids, candidate count of the 27 voxels, candidates in the row (packed).  The
+            // distance, the gate and the weight come from the current s either way - same values as after a search.
             {
                 int i;
                 const bool valid = chunk_point(qb, i);

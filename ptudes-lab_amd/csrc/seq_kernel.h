@@ -4,21 +4,20 @@
 // The lockstep driver (ptl_batch_enqueue, one launch per stage for all sequences) makes every step wait for the
 // sequence whose Gauss-Newton loop takes longest: over 16 sequences the slowest loop of a step runs 1.8 x the mean
 // number of iterations (tools/lockstep.py), and the workgroups of the other sequences idle meanwhile.  Here the
-// workgroups of an XCD form TEAMS (1, 2 or 4 of 32, 16 or 8 workgroups), and a team walks the whole per-scan pipeline of
+// workgroups of an XCD form TEAMS (of 32, 16, 8, 4, 2 workgroups or one), and a team walks the whole per-scan pipeline of
 // one sequence by itself - reference cli/ekf_bench.py:493-563 loop body = kiss.py:83-131 + ESEKF.processPose / processImu:
 //
 //     whole team:          K0 prologue | K1 deskew + vds1 | K2 vds2 | K3 compact fd | K4 compact src
 //     whole team:          --- barrier ---  K5 Gauss-Newton loop (gn8_body)  --- barrier ---
-//     filter wg:           ES-EKF: update with the scan's pose, predict through the IMU samples before the next scan
-//     team \ {filter wg}:  K7-K9 map insert a | b | c | K10 prune [| table reset | K11 rebuild]
+//     filter wg:           ES-EKF: update with the scan's pose, predict through the IMU samples before the next scan, K0 of the next scan
+//     whole team:          K7-K9 map insert a | b | c | K10 prune [| table reset | K11 rebuild]   (the filter workgroup joins when it is done)
 //
 // with team barriers where the lockstep driver has kernel boundaries.  Nothing is shared between teams, so a
 // sequence whose loop converges early simply starts its next scan.  Stage bodies, reduction trees and the exchange are
 // the ones of the per-stage kernels: results are bit-identical to the lockstep run and to the single-sequence run with
 // as many Gauss-Newton workgroups.
 //
-// Teams are not tied to sequences: the sequences s = x (mod 8) belong to XCD x (their maps stay in its L2), the XCD's
-// teams (1, 2 or 4) serve them scan by scan - a team that finishes a scan takes the next scan of the sequence of its
+// Teams are not tied to sequences: the sequences s = x (mod 8) belong to XCD x, the XCD's teams serve them scan by scan - a team that finishes a scan takes the next scan of the sequence of its
 // XCD that is furthest behind and not being worked on (SeqSched).  With more sequences than teams the sequences advance
 // evenly although their scans cost up to 40 % more or less than the average, and the run does not end with most
 // of the chip waiting for the slowest one.
