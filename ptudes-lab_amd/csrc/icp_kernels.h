@@ -1953,10 +1953,11 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         double M[GN8_ROW_ENTRIES];
 #pragma unroll
         for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
-        int nq = 0;  // queued points (uniform over the workgroup)
+        int nq = 0, nqr = 0;  // queued points: row valid (from the front of the queue) | row to be rebuilt (from the back); uniform over the workgroup
         for (int qb = 0; qb < my_blocks; qb += NW) {
             V3 sA;         // this lane's point of phase A
             int missA = -1;  // ... and its index when the answer row did not settle it
+            bool rebA = true;  // ... and whether its probe row has to be rebuilt (first iteration, or the point changed voxel)
 #ifdef GN_PHASE_CLOCKS
             const long long pa0 = GN_CLK();
 #endif
@@ -1998,6 +1999,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                         const unsigned long long old_key = cur.key;
                         const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
                         if (old_key == pack_key(kx, ky, kz)) {
+                            rebA = false;
                             double row[GN8_ANS_ROW];
 #pragma unroll
                             for (int k = 0; k < GN8_ANS_ROW / 2; ++k) { row[2 * k] = cur.r[k].x; row[2 * k + 1] = cur.r[k].y; }
@@ -2034,7 +2036,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             // workgroup with more points than threads (four sequences per XCD) walks them in chunks; the chunks' misses
             // share the search passes below - a pass costs its memory round trips whether 9 or 64 points ride on it.
             {
-                const int cnt = missA >= 0 ? 1 : 0;
+                // Two kinds, two ends of the queue: points whose probe row is still valid from the front, points that need the 27
+                // hash probes first from the back.  A wavefront of the search serves 8 points and pays for whatever ONE of them
+                // needs (profiles/r03_b_gn_phase_clocks...: 11 % of the repeated searches rebuild their row, 60 % of the
+                // wavefronts paid for it): sorted by kind only one wavefront per pass is mixed.  Both counts ride in one scan
+                // (low / high half of an int: at most 64 per wavefront, 1024 per workgroup).
+                const int cnt = missA < 0 ? 0 : (rebA ? (1 << 16) : 1);
                 int* wsum = wsum2[(qb / NW) & 1];  // (alternating: one barrier per chunk is enough)
                 int incl = cnt;
 #pragma unroll
@@ -2044,34 +2051,38 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 int woff = 0, total = 0;
                 for (int w = 0; w < NW; ++w) { const int v = wsum[w]; if (w < (tid >> 6)) woff += v; total += v; }
 #ifdef GN_PHASE_CLOCKS
-                ph_miss += total; ph_a += GN_CLK() - c0;
-                if (wg == 0 && tid == 0 && it < 24) st->dbg_sums[8 + it] += (double)total;  // misses by iteration index
+                ph_miss += (total & 0xFFFF) + (total >> 16); ph_a += GN_CLK() - c0;
+                if (wg == 0 && tid == 0 && it < 24) st->dbg_sums[8 + it] += (double)((total & 0xFFFF) + (total >> 16));  // misses by iteration index
 #endif
                 if (cnt) {
-                    const int pos = nq + woff + incl - 1;
+                    const int mine = woff + incl;
+                    const int pos = rebA ? GN8_QCAP - 1 - (nqr + (mine >> 16) - 1) : nq + (mine & 0xFFFF) - 1;
                     missq[pos] = missA;
                     miss_s[0][pos] = sA.x; miss_s[1][pos] = sA.y; miss_s[2][pos] = sA.z;
                 }
-                nq += total;
+                nq += total & 0xFFFF;
+                nqr += total >> 16;
             }
 #ifdef GN_PHASE_CLOCKS
             const long long pa2 = GN_CLK();
             if (wg == 0 && tid == 0 && it > 0) { atomicAdd((unsigned long long*)&c.wg_clk[56], (unsigned long long)(pa1 - pa0)); atomicAdd((unsigned long long*)&c.wg_clk[57], (unsigned long long)(pa2 - pa1)); atomicAdd((unsigned long long*)&c.wg_clk[59], 1ull); }
 #endif
-            if (qb + NW < my_blocks && nq + NT <= GN8_QCAP) continue;  // room for another chunk's misses
+            if (qb + NW < my_blocks && nq + nqr + NT <= GN8_QCAP) continue;  // room for another chunk's misses
             __syncthreads();
-            const int nmiss = nq;
-            nq = 0;
-            if (tid == 0) xcnt[0] += (unsigned)nmiss;
+            // search slots: [0, nq) the front of the queue, then - from the next wavefront's first slot on - the nqr entries of the back
+            const int nfront = nq, nback = nqr, kback0 = (nq + 7) & ~7, nmiss = kback0 + nqr;
+            nq = 0; nqr = 0;
+            if (tid == 0) xcnt[0] += (unsigned)(nfront + nback);
             // ---- phase B, GN8_LPB LANES PER POINT: the full search of the queued points (gn8_search)
             auto phaseB = [&](auto lp_tag) {
                 constexpr int LPB = decltype(lp_tag)::value;
                 const int laneL = tid & (LPB - 1), gb = (tid & 63) & ~(LPB - 1);
                 for (int k = tid / LPB; __any(k < nmiss); k += NT / LPB) {
-                  if (k < nmiss) {
+                  if (k < nfront || (k >= kback0 && k < nmiss)) {
                     [[maybe_unused]] const long long b0 = GN_CLK();
-                    const int i = missq[k];
-                    const V3 s = v3(miss_s[0][k], miss_s[1][k], miss_s[2][k]);  // (= src_cur[i], without the round trip)
+                    const int qi = k < nfront ? k : GN8_QCAP - 1 - (k - kback0);
+                    const int i = missq[qi];
+                    const V3 s = v3(miss_s[0][qi], miss_s[1][qi], miss_s[2][qi]);  // (= the point's position now, without a round trip)
                     V3 t;
                     double m;
                     bool found;
