@@ -2286,13 +2286,26 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         if (tid < 64) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (tid < 27) tot[tid] = sums_from_moments(tid, mom);
-            else if (tid == 27) tot[27] = mom[16];
-            else if (tid == 28) tot[28] = mom[17];
+            {   // every lane takes all 18 moments into registers (18 broadcast reads in flight together) and picks its entry of the
+                // 27 sums there: as a switch over LDS reads the 16 cases ran one after the other, each with its own wait
+                // (6.5 k ticks of the iteration's serial tail, profiles/r03_d_gn_phase_clocks...)
+                double mm[GN8_ROW_ENTRIES];
+#pragma unroll
+                for (int e = 0; e < GN8_ROW_ENTRIES; ++e) mm[e] = mom[e];
+                if (tid < 27) tot[tid] = sums_from_moments(tid, mm);
+                else if (tid == 27) tot[27] = mm[16];
+                else if (tid == 28) tot[28] = mm[17];
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#ifdef GN_PHASE_CLOCKS
+            const long long s1 = GN_CLK();
+#endif
             double dx[6];
             solve6_ldlt_wave(tot, tid, dx);
+#ifdef GN_PHASE_CLOCKS
+            const long long s2 = GN_CLK();
+#endif
             if (tid == 0) {
                 const Rt e = se3_exp_gn(dx);
                 for (int k = 0; k < 9; ++k) Esh2[it & 1][k] = e.R[k];
@@ -2301,6 +2314,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 for (int k = 0; k < 6; ++k) nn += dx[k] * dx[k];
                 flag_done2[it & 1] = (nn < conv2 || !ok) ? 1 : 0;
             }
+#ifdef GN_PHASE_CLOCKS
+            if (tid == 0 && wg == 0) { const long long s3 = GN_CLK(); atomicAdd((unsigned long long*)&c.wg_clk[67], (unsigned long long)(s1 - c3)); atomicAdd((unsigned long long*)&c.wg_clk[68], (unsigned long long)(s2 - s1));
+                                       atomicAdd((unsigned long long*)&c.wg_clk[69], (unsigned long long)(s3 - s2)); atomicAdd((unsigned long long*)&c.wg_clk[70], 1ull); }
+#endif
         }
         __syncthreads();
         const long long c5 = GN_CLK();

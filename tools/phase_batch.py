@@ -32,6 +32,8 @@ try:
     if w[59] > 0:
         print("workgroup 0 of sequence 0, iterations > 0: per chunk of phase A: wait for the loads + evaluation %.0f ticks, compaction %.0f; chunks per iteration %.1f;  per search pass %.0f ticks (%.1f passes per iteration)"
               % (w[56] / w[59], w[57] / w[59], w[59] / max(it - nscan_all, 1), w[58] / max(w[60], 1), w[60] / max(it - nscan_all, 1)))
+    if w[70] > 0:
+        print("serial tail of an iteration (workgroup 0 of sequence 0), ticks: sums from the moments %.0f | 6x6 solve %.0f | Exp + flags %.0f" % tuple(w[67:70] / w[70]))
     if w[66] > 0:
         print("one search (thread 0 of the first teams' workgroup 0, iterations > 0, every step waited out), ticks: row + key %.0f | rebuild %.0f | boxes + first round %.0f | survivors %.0f | reductions + answer row %.0f   (%d searches)"
               % tuple(list(w[61:66] / w[66]) + [int(w[66])]))
