@@ -292,6 +292,9 @@ int ptl_batch_profile(ptl_batch *b, int enable, double *gn_ms_total, int64_t *gn
  *   free_running == 0: lockstep, one launch per stage for all sequences; a step lasts as long as its slowest sequence.
  * Same results either way (bit-identical). */
 int ptl_batch_set_driver(ptl_batch *b, int32_t free_running, int64_t scans_per_launch);
+/* back to the cold start (empty maps, fresh filters, scan 0 next) without running anything - what ptl_batch_run does first;
+ * after it the driver and the team size may be chosen again for the same handle and the same uploaded sweeps */
+int ptl_batch_reset(ptl_batch *b);
 /* phase clocks of sequence s in the free-running kernel, 100 MHz wall-clock ticks summed since the cold start:
  * workgroup 0's K0-K4 | its wait before the Gauss-Newton loop | the loop | its wait after it | its map update;
  * out[5] the filter workgroup's step; out[6] scans */

@@ -127,6 +127,7 @@ PROTOTYPES = {
     "ptl_batch_icp": (C.c_int, [_vp, C.c_int32, _vpp]),
     "ptl_batch_profile": (C.c_int, [_vp, C.c_int, c_d_p, c_i64_p, C.c_int]),
     "ptl_batch_set_driver": (C.c_int, [_vp, C.c_int32, C.c_int64]),
+    "ptl_batch_reset": (C.c_int, [_vp]),
     "ptl_batch_seq_clocks": (C.c_int, [_vp, C.c_int32, c_i64_p]),
     "ptl_batch_set_team_workgroups": (C.c_int, [_vp, C.c_int32]),
     "ptl_batch_team_workgroups": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

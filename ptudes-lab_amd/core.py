@@ -383,6 +383,14 @@ class BatchRunner:
         if team_workgroups:
             L.check(L.lib().ptl_batch_set_team_workgroups(self._h, int(team_workgroups)))
 
+    def set_driver(self, free_running, scans_per_launch=0, team_workgroups=None):
+        """choose the driver (and the team size) again for the same handle and sweeps: back to the cold start first"""
+        L.check(L.lib().ptl_batch_reset(self._h))
+        L.check(L.lib().ptl_batch_set_driver(self._h, int(bool(free_running)), int(scans_per_launch)))
+        self.free_running = bool(free_running)
+        if team_workgroups is not None:
+            L.check(L.lib().ptl_batch_set_team_workgroups(self._h, int(team_workgroups)))
+
     def team_geometry(self):
         """(workgroups per team, teams that can get work) of the free-running kernel"""
         g, t = C.c_int32(), C.c_int32()

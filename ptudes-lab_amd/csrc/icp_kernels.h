@@ -1824,7 +1824,9 @@ __device__ __forceinline__ double sums_from_moments(int e, const double* M) {
 #ifndef GN8_LDS_PTS
 #define GN8_LDS_PTS (6 * 512) /* source-point positions a workgroup keeps in LDS (72 KB) */
 #endif
-#define GN8_QCAP (2 * GN8_MAX_THREADS)  /* queue of points awaiting the full search: the misses of several phase-A chunks share the search passes */
+#define GN8_QWAVE 512         /* queue of points awaiting the full search: one region per wavefront of phase A (8 chunks of 64 at most between two
+                                 flushes), filled from both ends by kind - no cross-wavefront prefix, no workgroup barrier per chunk */
+#define GN8_QCHUNKS (GN8_QWAVE / 64)
 #ifndef GN8_LPB
 #define GN8_LPB 8             /* lanes per point of the full search (8 or 4) */
 #endif
@@ -1881,9 +1883,8 @@ __device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, b
 template <int PC, int GC>
 __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt, const int wg) {
     const int G = GC > 0 ? GC : G_rt;
-    __shared__ int missq[GN8_QCAP];                   // points whose answer row did not settle them, in point order
-    __shared__ double miss_s[3][GN8_QCAP];            // ... and where they are now (phase A has just computed it)
-    __shared__ int wsum2[2][GN8_MAX_THREADS / 64];
+    __shared__ int2 missq[(GN8_MAX_THREADS / 64) * GN8_QWAVE];  // points whose answer row did not settle them: (index, slot of its position in posL or -1)
+    __shared__ int qcount[2][GN8_MAX_THREADS / 64];   // per wavefront: entries at the front / at the back of its region
     __shared__ double part[GN8_ROW_ENTRIES][16];
     __shared__ double redL8[64][GN8_ROW_ENTRIES];     // everybody's rows (G != 32)
     __shared__ double mom[GN8_ROW_ENTRIES];
@@ -1953,11 +1954,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         double M[GN8_ROW_ENTRIES];
 #pragma unroll
         for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
-        int nq = 0, nqr = 0;  // queued points: row valid (from the front of the queue) | row to be rebuilt (from the back); uniform over the workgroup
+        int nq = 0, nqr = 0;  // this WAVEFRONT's queued points: row valid (from the front of its region) | row to be rebuilt (from the back)
         for (int qb = 0; qb < my_blocks; qb += NW) {
             V3 sA;         // this lane's point of phase A
             int missA = -1;  // ... and its index when the answer row did not settle it
             bool rebA = true;  // ... and whether its probe row has to be rebuilt (first iteration, or the point changed voxel)
+            int liA = -1;      // ... and where its position lives: slot in posL, or -1 = src_cur
 #ifdef GN_PHASE_CLOCKS
             const long long pa0 = GN_CLK();
 #endif
@@ -1991,7 +1993,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     const int li = (qb / NW) * NT + tid;
                     const V3 p0 = (it == 0 || !lds) ? v3(cur.px, cur.py, cur.pz) : v3(posL[0][li], posL[1][li], posL[2][li]);
                     const V3 s = rt_apply(E, p0);
-                    if (lds) { posL[0][li] = s.x; posL[1][li] = s.y; posL[2][li] = s.z; }
+                    if (lds) { posL[0][li] = s.x; posL[1][li] = s.y; posL[2][li] = s.z; liA = li; }
                     else { c.src_cur[3 * (size_t)i] = s.x; c.src_cur[3 * (size_t)i + 1] = s.y; c.src_cur[3 * (size_t)i + 2] = s.z; }
                     sA = s;
                     miss = i;
@@ -2032,47 +2034,59 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
 #ifdef GN_PHASE_CLOCKS
             const long long pa1 = GN_CLK();
 #endif
-            // the noted points join the queue in point order (deterministic): wavefront scan, wavefront offsets.  A
-            // workgroup with more points than threads (four sequences per XCD) walks them in chunks; the chunks' misses
-            // share the search passes below - a pass costs its memory round trips whether 9 or 64 points ride on it.
+            // The noted points join the queue: every wavefront has its own region and fills it in point order - points whose probe
+            // row is still valid from the front, points that need the 27 hash probes first from the back (a wavefront of the
+            // search serves 8 points and pays for whatever ONE of them needs: sorted by kind only the wavefronts at the seams
+            // are mixed).  Positions come from a ballot: no shuffle, no LDS traffic, no workgroup barrier per chunk - a fast
+            // wavefront goes on to its next chunk while a slow one still waits for its loads (the barrier cost 3 k ticks per
+            // chunk, mostly that wait).  The order of the queue - wavefront by wavefront, chunk by chunk - depends on the
+            // data alone: deterministic.
             {
-                // Two kinds, two ends of the queue: points whose probe row is still valid from the front, points that need the 27
-                // hash probes first from the back.  A wavefront of the search serves 8 points and pays for whatever ONE of them
-                // needs (profiles/r03_b_gn_phase_clocks...: 11 % of the repeated searches rebuild their row, 60 % of the
-                // wavefronts paid for it): sorted by kind only one wavefront per pass is mixed.  Both counts ride in one scan
-                // (low / high half of an int: at most 64 per wavefront, 1024 per workgroup).
-                const int cnt = missA < 0 ? 0 : (rebA ? (1 << 16) : 1);
-                int* wsum = wsum2[(qb / NW) & 1];  // (alternating: one barrier per chunk is enough)
-                int incl = cnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if ((tid & 63) >= o) incl += u; }
-                if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-                __syncthreads();
-                int woff = 0, total = 0;
-                for (int w = 0; w < NW; ++w) { const int v = wsum[w]; if (w < (tid >> 6)) woff += v; total += v; }
-#ifdef GN_PHASE_CLOCKS
-                ph_miss += (total & 0xFFFF) + (total >> 16); ph_a += GN_CLK() - c0;
-                if (wg == 0 && tid == 0 && it < 24) st->dbg_sums[8 + it] += (double)((total & 0xFFFF) + (total >> 16));  // misses by iteration index
-#endif
-                if (cnt) {
-                    const int mine = woff + incl;
-                    const int pos = rebA ? GN8_QCAP - 1 - (nqr + (mine >> 16) - 1) : nq + (mine & 0xFFFF) - 1;
-                    missq[pos] = missA;
-                    miss_s[0][pos] = sA.x; miss_s[1][pos] = sA.y; miss_s[2][pos] = sA.z;
+                const unsigned long long bm = __ballot(missA >= 0), br = __ballot(missA >= 0 && rebA);
+                const unsigned long long bf = bm & ~br, below = (1ull << (tid & 63)) - 1ull;
+                if (missA >= 0) {
+                    const int base = (tid >> 6) * GN8_QWAVE;
+                    const int pos = rebA ? base + GN8_QWAVE - 1 - (nqr + __popcll(br & below)) : base + nq + __popcll(bf & below);
+                    missq[pos] = make_int2(missA, liA);
                 }
-                nq += total & 0xFFFF;
-                nqr += total >> 16;
+                nq += __popcll(bf);   // (this wavefront's counts)
+                nqr += __popcll(br);
+#ifdef GN_PHASE_CLOCKS
+                ph_miss += __popcll(bm); ph_a += GN_CLK() - c0;
+#endif
             }
 #ifdef GN_PHASE_CLOCKS
             const long long pa2 = GN_CLK();
             if (wg == 0 && tid == 0 && it > 0) { atomicAdd((unsigned long long*)&c.wg_clk[56], (unsigned long long)(pa1 - pa0)); atomicAdd((unsigned long long*)&c.wg_clk[57], (unsigned long long)(pa2 - pa1)); atomicAdd((unsigned long long*)&c.wg_clk[59], 1ull); }
 #endif
-            if (qb + NW < my_blocks && nq + nqr + NT <= GN8_QCAP) continue;  // room for another chunk's misses
-            __syncthreads();
-            // search slots: [0, nq) the front of the queue, then - from the next wavefront's first slot on - the nqr entries of the back
-            const int nfront = nq, nback = nqr, kback0 = (nq + 7) & ~7, nmiss = kback0 + nqr;
+            if (qb + NW < my_blocks && ((qb / NW + 1) % GN8_QCHUNKS) != 0) continue;  // (a region holds GN8_QCHUNKS chunks whatever they bring)
+            if ((tid & 63) == 0) { qcount[0][tid >> 6] = nq; qcount[1][tid >> 6] = nqr; }
             nq = 0; nqr = 0;
+            __syncthreads();
+            // search slots: the fronts of the regions, wavefront by wavefront, then - from the next wavefront's first slot on - the backs
+            int cf[GN8_MAX_THREADS / 64], cb[GN8_MAX_THREADS / 64];
+            int nfront = 0, nback = 0;
+#pragma unroll
+            for (int w = 0; w < GN8_MAX_THREADS / 64; ++w) {
+                cf[w] = w < NW ? qcount[0][w] : 0; cb[w] = w < NW ? qcount[1][w] : 0;
+                nfront += cf[w]; nback += cb[w];
+            }
+            const int kback0 = (nfront + 7) & ~7, nmiss = kback0 + nback;
             if (tid == 0) xcnt[0] += (unsigned)(nfront + nback);
+#ifdef GN_PHASE_CLOCKS
+            if (wg == 0 && tid == 0 && it < 24) st->dbg_sums[8 + it] += (double)(nfront + nback);  // misses by iteration index
+#endif
+            // queue slot of search slot k
+            auto qslot = [&](int k) -> int {
+                int j = k < nfront ? k : k - kback0, q = -1;
+#pragma unroll
+                for (int w = 0; w < GN8_MAX_THREADS / 64; ++w) {
+                    const int cw = k < nfront ? cf[w] : cb[w];
+                    if (q < 0 && j < cw) q = k < nfront ? w * GN8_QWAVE + j : w * GN8_QWAVE + GN8_QWAVE - 1 - j;
+                    j -= cw;
+                }
+                return q;
+            };
             // ---- phase B, GN8_LPB LANES PER POINT: the full search of the queued points (gn8_search)
             auto phaseB = [&](auto lp_tag) {
                 constexpr int LPB = decltype(lp_tag)::value;
@@ -2080,9 +2094,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 for (int k = tid / LPB; __any(k < nmiss); k += NT / LPB) {
                   if (k < nfront || (k >= kback0 && k < nmiss)) {
                     [[maybe_unused]] const long long b0 = GN_CLK();
-                    const int qi = k < nfront ? k : GN8_QCAP - 1 - (k - kback0);
-                    const int i = missq[qi];
-                    const V3 s = v3(miss_s[0][qi], miss_s[1][qi], miss_s[2][qi]);  // (= the point's position now, without a round trip)
+                    const int2 qe = missq[qslot(k)];
+                    const int i = qe.x;
+                    const V3 s = qe.y >= 0 ? v3(posL[0][qe.y], posL[1][qe.y], posL[2][qe.y])  // (the point's position now: from the LDS copy,
+                                           : v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]);  // or what phase A has just written)
                     V3 t;
                     double m;
                     bool found;

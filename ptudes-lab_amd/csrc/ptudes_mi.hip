@@ -1574,6 +1574,13 @@ static int batch_enqueue_free(ptl_batch* b, int64_t n) {
     HIPCHK(hipGetLastError());
     return PTL_OK;
 }
+// back to the cold start (empty maps, fresh filters, scan 0 next) without running anything: what ptl_batch_run does first; after it the
+// driver and the team size may be chosen again
+extern "C" int ptl_batch_reset(ptl_batch* b) {
+    if (!b) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    return batch_reset(b);
+}
 extern "C" int ptl_batch_set_driver(ptl_batch* b, int32_t free_running, int64_t scans_per_launch) {
     if (!b || scans_per_launch < 0) return set_err(PTL_ERR_ARG, "bad argument");
     if (b->next_scan != 0) return set_err(PTL_ERR_STATE, "choose the driver before the first scan of a run");

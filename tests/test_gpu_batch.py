@@ -324,3 +324,31 @@ def test_icp_only_batch_against_the_oracle():
         assert np.abs(out["kiss_poses"] - kiss).max() < 1e-9, s
         for k in range(n):
             assert all(out["stats"][k][q] == stats[k][q] for q in _INT_STATS), (s, k)
+
+
+def test_one_handle_both_drivers_and_several_team_sizes():
+    """the driver and the team size chosen again for the same handle and the same uploaded sweeps (ptl_batch_reset): lockstep and
+    the free-running kernel agree bit for bit; teams of 4 / 2 give what single runs with 4 / 2 workgroups give"""
+    S, n = 5, 5
+    seqs = [synth.make_sequence(seed=1700 + s, n_scans=n) for s in range(S)]
+    n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
+    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=True, with_ekf=True)
+    _load(b, seqs, n, n_imu)
+    b.run()
+    free = [b.results(s) for s in range(S)]
+    b.set_driver(False)
+    b.run()
+    for s in range(S):
+        lock = b.results(s)
+        assert np.array_equal(lock["res_poses"], free[s]["res_poses"]) and lock["stats"] == free[s]["stats"], s
+    for team in (4, 2):
+        b.set_driver(True, team_workgroups=team)
+        assert b.team_geometry()[0] == team
+        b.run()
+        sq = seqs[3]
+        r = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=True, with_ekf=True, gn_workgroups=team, gn_lanes_per_point=8, gn_threads=512)
+        for k in range(n):
+            r.upload_scan(k, sq.scan(k))
+        r.upload_imu(sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
+        r.run()
+        assert np.array_equal(b.results(3)["res_poses"], r.results()["res_poses"]) and b.results(3)["stats"] == r.results()["stats"], team
