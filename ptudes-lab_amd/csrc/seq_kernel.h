@@ -17,8 +17,9 @@
 // the ones of the per-stage kernels: results are bit-identical to the lockstep run and to the single-sequence run with
 // as many Gauss-Newton workgroups.
 //
-// Teams are not tied to sequences: the sequences s = x (mod 8) belong to XCD x, the XCD's teams serve them scan by scan - a team that finishes a scan takes the next scan of the sequence of its
-// XCD that is furthest behind and not being worked on (SeqSched).  With more sequences than teams the sequences advance
+// Teams are not tied to sequences: the sequences s = x (mod 8) belong to XCD x, whose teams serve them scan by scan - a team that
+// finishes a scan takes the next scan of the sequence of its XCD that is furthest behind and not being worked on (SeqSched), and
+// when its XCD has nothing for it, one of another XCD's.  With more sequences than teams the sequences advance
 // evenly although their scans cost up to 40 % more or less than the average, and the run does not end with most
 // of the chip waiting for the slowest one.
 #pragma once
@@ -217,8 +218,8 @@ __global__ void k_sched_init(SeqSched* sc, int S, int k0, int k1) {
 #define SCHED_DONE (-1)
 #define SCHED_RETRY (-2)
 #define SCHED_POLLS 256
-__device__ __forceinline__ int sched_pick(SeqSched* sc, int nslots, int k1, int* scan_out) {
-    for (unsigned polls = 0; polls < SCHED_POLLS; ++polls) {
+__device__ __forceinline__ int sched_pick(SeqSched* sc, int nslots, int k1, int* scan_out, unsigned max_polls = SCHED_POLLS) {
+    for (unsigned polls = 0; polls < max_polls; ++polls) {
         int best = -1, bestk = 0x7FFFFFFF;
         bool pending = false;
         for (int q = 0; q < nslots; ++q) {
@@ -284,15 +285,29 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, S
         const unsigned m = __hip_atomic_load(&tb[42], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         local = (m & (m - 1u)) == 0u;
     }
-    int q_mine = -1, k_mine = 0;
+    int q_mine = -1, k_mine = 0, x_mine = x;  // the leader's job: slot, scan, and the XCD whose scheduler holds the sequence
     unsigned idle = 0u;
     for (;;) {
         if (lead) {  // hand the finished scan back, take the next job
-            if (q_mine >= 0) sched_release(sc, q_mine, k_mine + 1);
-            int k = 0;
-            const int q = sched_pick(sc, nslots, r.k1, &k);
-            q_mine = q; k_mine = k;
-            __hip_atomic_store(&tb[40], q == SCHED_DONE ? JOB_DONE : q == SCHED_RETRY ? JOB_RETRY : (unsigned)(x + 8 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q_mine >= 0) sched_release(sched + x_mine, q_mine, k_mine + 1);
+            int k = 0, xs = x;
+            int q = sched_pick(sc, nslots, r.k1, &k, 16u);  // (a short wait at home, then a look at the neighbours, then round the team barrier and again)
+            if (q < 0) {
+                // Nothing to do at home: is a sequence of another XCD waiting for a team?  (24 sequences per XCD differ enough in cost
+                // that the XCDs finish 5-10 ms apart in a 150 ms run, and the L2 they would share is far too small for any of this
+                // to live there anyway.)  The hand-over of a sequence between teams is agent-scope either way (sched_release / pick).
+                bool all_done = q == SCHED_DONE;
+                for (int d = 1; d < 8 && q < 0; ++d) {
+                    const int xo = (x + d) & 7;
+                    if (xo >= r.S) continue;
+                    const int qo = sched_pick(sched + xo, (r.S - xo + 7) >> 3, r.k1, &k, 1u);
+                    if (qo >= 0) { q = qo; xs = xo; }
+                    else if (qo == SCHED_RETRY) all_done = false;
+                }
+                if (q < 0) q = all_done ? SCHED_DONE : SCHED_RETRY;
+            }
+            q_mine = q; k_mine = k; x_mine = xs;
+            __hip_atomic_store(&tb[40], q == SCHED_DONE ? JOB_DONE : q == SCHED_RETRY ? JOB_RETRY : (unsigned)(xs + 8 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&tb[41], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < 5; ++i) __hip_atomic_store(&tb[44 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the map update's block counters
         }
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) void kx_seq_run(const SeqCtx* a, S
         DevState* st = my->c.st;
         const TeamEnv te = {tb, &st->gn_abort, st, local};
         // (every exit below takes the sequence off the schedule first: the other teams must not wait for scans nobody will run)
-#define SEQ_LEAVE do { if (threadIdx.x == 0) sched_abandon(sc, q, r.k1); return; } while (0)
+#define SEQ_LEAVE do { if (threadIdx.x == 0) sched_abandon(sched + (s & 7), q, r.k1); return; } while (0)
         const long long c0 = (long long)wall_clock64();
         t_all = sq_prepare(a, s, k, wg, G, t_all, tb, local);  // (all G workgroups: the filter workgroup has nothing else to do here)
         if (t_all == SEQ_FAIL) SEQ_LEAVE;
