@@ -438,8 +438,23 @@ __device__ __forceinline__ int block_count_u(const bool (&f)[U]) {
 #else
 #define K1_CLK(i) do { } while (0)
 #endif
+// the raw f32 points of one block, as a pass of K1 wants them: the free-running kernel requests the NEXT pass's while the
+// current pass waits for its hash atomics (one dependent memory round trip per pass less)
+template <int U> struct RawF32 { float v[U][3]; };
 template <int U>
-__device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
+__device__ __forceinline__ RawF32<U> k1_load_raw(const Ctx& c, const Slice sl) {
+    RawF32<U> r;
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = base + u * BS;
+        const bool in = i < c.n_in;
+        r.v[u][0] = in ? c.in_f32[3 * (size_t)i] : 0.0f; r.v[u][1] = in ? c.in_f32[3 * (size_t)i + 1] : 0.0f; r.v[u][2] = in ? c.in_f32[3 * (size_t)i + 2] : 0.0f;
+    }
+    return r;
+}
+template <int U>
+__device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl, const RawF32<U>* pre = nullptr) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     DevState* st = c.st;
 #ifdef SEQ_STAGE_CLOCKS
@@ -475,7 +490,8 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl) {
                 const double* o = c.lut_off + 3 * (size_t)i;
                 p[u] = rg ? v3(r * d[0] + o[0], r * d[1] + o[1], r * d[2] + o[2]) : v3(0.0, 0.0, 0.0);
             } else if (c.in_f32) {
-                p[u] = v3((double)c.in_f32[3 * (size_t)i], (double)c.in_f32[3 * (size_t)i + 1], (double)c.in_f32[3 * (size_t)i + 2]);
+                if (pre) p[u] = v3((double)pre->v[u][0], (double)pre->v[u][1], (double)pre->v[u][2]);
+                else p[u] = v3((double)c.in_f32[3 * (size_t)i], (double)c.in_f32[3 * (size_t)i + 1], (double)c.in_f32[3 * (size_t)i + 2]);
             } else {
                 p[u] = v3(c.in_f64[3 * (size_t)i], c.in_f64[3 * (size_t)i + 1], c.in_f64[3 * (size_t)i + 2]);
             }

@@ -113,7 +113,20 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     SQ_CLK(0);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(1);
-    for (sl.b = wg; sl.b < nbs; sl.b += nw) d_deskew_vds1<SEQ_U>(c, sl);
+    if (c.in_f32 && !c.in_range) {  // (uniform) the next pass's raw points travel while this pass waits for its atomics
+        RawF32<SEQ_U> raw;
+        sl.b = wg;
+        if (wg < nbs) raw = k1_load_raw<SEQ_U>(c, sl);
+        for (sl.b = wg; sl.b < nbs; sl.b += nw) {
+            const RawF32<SEQ_U> cur = raw;
+            Slice nx = sl;
+            nx.b = sl.b + nw;
+            if (nx.b < nbs) raw = k1_load_raw<SEQ_U>(c, nx);
+            d_deskew_vds1<SEQ_U>(c, sl, &cur);
+        }
+    } else {
+        for (sl.b = wg; sl.b < nbs; sl.b += nw) d_deskew_vds1<SEQ_U>(c, sl);
+    }
     SQ_CLK(2);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(3);
