@@ -572,15 +572,25 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl, cons
     K1_CLK(25);
 }
 
+// the per-point word a pass of K2 / K3 / K4 starts from (slot1 / slot2), requested a pass ahead like K1's raw points
+template <int U> struct PreI32 { int v[U]; };
+template <int U>
+__device__ __forceinline__ PreI32<U> stage_load_i32(const int* arr, int n, const Slice sl) {
+    PreI32<U> r;
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int i = base + u * BS; r.v[u] = (i < n) ? arr[i] : -1; }
+    return r;
+}
 // ------------------------------------------------------------------------------------------------ K2
 template <int U>
-__device__ __forceinline__ void d_vds2(const Ctx& c, const Slice sl) {
+__device__ __forceinline__ void d_vds2(const Ctx& c, const Slice sl, const PreI32<U>* pre = nullptr) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     int idx[U], s1[U];
     bool w1[U];
     unsigned long long key[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s1[u] = (idx[u] < c.n_in) ? c.slot1[idx[u]] : -1; }
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s1[u] = pre ? pre->v[u] : ((idx[u] < c.n_in) ? c.slot1[idx[u]] : -1); }
     {
         unsigned vm[U];
 #pragma unroll
@@ -681,13 +691,13 @@ __device__ __forceinline__ void block_rank_u(const bool (&f)[U], int (&rk)[U], i
 
 // ------------------------------------------------------------------------------------------------ K3
 template <int U>
-__device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl) {
+__device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl, const PreI32<U>* pre = nullptr) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     int idx[U], s2[U], rk[U];
     bool w1[U], w2[U];
     const int off_part = block_offset_part(c.bcnt1, sl.b);
 #pragma unroll
-    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s2[u] = (idx[u] < c.n_in) ? c.slot2[idx[u]] : -1; }  // K2: slot2 >= 0 <=> pass-1 winner
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s2[u] = pre ? pre->v[u] : ((idx[u] < c.n_in) ? c.slot2[idx[u]] : -1); }  // K2: slot2 >= 0 <=> pass-1 winner
     {
         unsigned vm[U];
 #pragma unroll
@@ -728,13 +738,13 @@ __device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl) {
 
 // ------------------------------------------------------------------------------------------------ K4
 template <int U>
-__device__ __forceinline__ void d_compact_src(const Ctx& c, const Slice sl) {
+__device__ __forceinline__ void d_compact_src(const Ctx& c, const Slice sl, const PreI32<U>* pre = nullptr) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     int idx[U], rk[U];
     bool w2[U];
     const int off_part = block_offset_part(c.bcnt2, sl.b);
 #pragma unroll
-    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; w2[u] = (idx[u] < c.n_in) && c.slot2[idx[u]] >= 0; }  // K3: slot2 >= 0 <=> pass-2 winner
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; w2[u] = pre ? pre->v[u] >= 0 : ((idx[u] < c.n_in) && c.slot2[idx[u]] >= 0); }  // K3: slot2 >= 0 <=> pass-2 winner
     const int off = block_offset(off_part);
     int total;
     block_rank_u<U>(w2, rk, total);
