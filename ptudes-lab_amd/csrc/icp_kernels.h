@@ -1982,8 +1982,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
         int nq = 0, nqr = 0;  // this WAVEFRONT's queued points: row valid (from the front of its region) | row to be rebuilt (from the back)
         for (int qb = 0; qb < my_blocks; qb += NW) {
-            V3 sA;         // this lane's point of phase A
-            int missA = -1;  // ... and its index when the answer row did not settle it
+            int missA = -1;  // this lane's point of phase A when the answer row did not settle it
             bool rebA = true;  // ... and whether its probe row has to be rebuilt (first iteration, or the point changed voxel)
             int liA = -1;      // ... and where its position lives: slot in posL, or -1 = src_cur
 #ifdef GN_PHASE_CLOCKS
@@ -2010,7 +2009,6 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     if (qb + 2 * NW < my_blocks) pre2 = preload_chunk(qb + 2 * NW, it == 0);  // in flight while this chunk and the next are evaluated
                 } else if (qb + NW < my_blocks) pre = preload_chunk(qb + NW, it == 0);
                 int miss = -1;
-                sA = v3(0.0, 0.0, 0.0);
                 if (valid) {
                     Rt E;
                     for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
@@ -2021,7 +2019,6 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     const V3 s = rt_apply(E, p0);
                     if (lds) { posL[0][li] = s.x; posL[1][li] = s.y; posL[2][li] = s.z; liA = li; }
                     else { c.src_cur[3 * (size_t)i] = s.x; c.src_cur[3 * (size_t)i + 1] = s.y; c.src_cur[3 * (size_t)i + 2] = s.z; }
-                    sA = s;
                     miss = i;
                     if (it > 0) {
                         const unsigned long long old_key = cur.key;
