@@ -1531,10 +1531,16 @@ template <int LP> __device__ __forceinline__ double group_bcastL(double v) {  //
     return LP == 8 ? v + dpp_f64<0x141>(v) : v;
 }
 // entry q (group-uniform) of this lane's RE row entries
+// (the entries pass through an empty asm first: without it the compiler turns the chain of selects over VALUES into one load
+// through a select over ADDRESSES, the row then lives in scratch memory and every pick is a memory round trip in the search's
+// dependent chain - 16-byte store + up to five dependent loads per search in the round-3 build)
 template <int RE> __device__ __forceinline__ int sel_entry(const int (&r)[RE], int q) {
-    int v = r[0];
+    int a[RE];
 #pragma unroll
-    for (int k = 1; k < RE; ++k) v = (q == k) ? r[k] : v;
+    for (int k = 0; k < RE; ++k) { a[k] = r[k]; asm("" : "+v"(a[k])); }
+    int v = a[0];
+#pragma unroll
+    for (int k = 1; k < RE; ++k) v = (q == k) ? a[k] : v;
     return v;
 }
 // NV stored voxels against the point with LP lanes: lane l <-> stored points l, l + LP, ... - every load of the call in
@@ -1823,24 +1829,27 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
 // packed upper triangle of JTJ (21) + JTr (6) from the 16 moments
 //   M: 0 W | 1..3 W s | 4 xx 5 xy 6 xz 7 yy 8 yz 9 zz | 10..12 sum w r | 13..15 sum w s x r
 __device__ __forceinline__ double sums_from_moments(int e, const double* M) {
-    switch (e) {
-        case 0: case 6: case 11: return M[0];           // (0,0) (1,1) (2,2)
-        case 4: return M[3];                            // (0,4) = +W sz
-        case 5: return -M[2];                           // (0,5) = -W sy
-        case 8: return -M[3];                           // (1,3)
-        case 10: return M[1];                           // (1,5) = +W sx
-        case 12: return M[2];                           // (2,3) = +W sy
-        case 13: return -M[1];                          // (2,4)
-        case 15: return M[7] + M[9];                    // (3,3) = yy + zz
-        case 16: return -M[5];                          // (3,4) = -xy
-        case 17: return -M[6];                          // (3,5) = -xz
-        case 18: return M[4] + M[9];                    // (4,4) = xx + zz
-        case 19: return -M[8];                          // (4,5) = -yz
-        case 20: return M[4] + M[7];                    // (5,5) = xx + yy
-        case 21: case 22: case 23: return M[10 + (e - 21)];
-        case 24: case 25: case 26: return M[13 + (e - 24)];
-        default: return 0.0;                            // (0,1) (0,2) (0,3) (1,2) (1,4) (2,5)
-    }
+    // a chain of selects over constant indices: M stays in registers.  (As a switch with M[10 + (e - 21)] in it the array
+    // went to scratch memory - nine 16-byte stores and a load back per iteration, 6.5 k ticks of every iteration's serial tail.)
+    double r = 0.0;                                     // (0,1) (0,2) (0,3) (1,2) (1,4) (2,5)
+#define SFM(k, v) r = (e == (k)) ? (v) : r
+    SFM(0, M[0]); SFM(6, M[0]); SFM(11, M[0]);          // (0,0) (1,1) (2,2)
+    SFM(4, M[3]);                                       // (0,4) = +W sz
+    SFM(5, -M[2]);                                      // (0,5) = -W sy
+    SFM(8, -M[3]);                                      // (1,3)
+    SFM(10, M[1]);                                      // (1,5) = +W sx
+    SFM(12, M[2]);                                      // (2,3) = +W sy
+    SFM(13, -M[1]);                                     // (2,4)
+    SFM(15, M[7] + M[9]);                               // (3,3) = yy + zz
+    SFM(16, -M[5]);                                     // (3,4) = -xy
+    SFM(17, -M[6]);                                     // (3,5) = -xz
+    SFM(18, M[4] + M[9]);                               // (4,4) = xx + zz
+    SFM(19, -M[8]);                                     // (4,5) = -yz
+    SFM(20, M[4] + M[7]);                               // (5,5) = xx + yy
+    SFM(21, M[10]); SFM(22, M[11]); SFM(23, M[12]);
+    SFM(24, M[13]); SFM(25, M[14]); SFM(26, M[15]);
+#undef SFM
+    return r;
 }
 
 #define GN8_ROW_ENTRIES 18   /* 16 moments, pair count, candidate count */
@@ -1926,7 +1935,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     // points) keep theirs in src_cur.
     __shared__ double posL[3][GN8_LDS_PTS];
     DevState* st = c.st;
-    const int tid = threadIdx.x, lane32 = tid & 31, grp32 = tid >> 5;
+    const int tid = threadIdx.x;
     const int NT = blockDim.x, NG32 = blockDim.x >> 5, NW = blockDim.x >> 6;
     if (tid < 4) xcnt[tid] = 0u;
     const int n = st->n_src;
@@ -1966,7 +1975,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     [[maybe_unused]] long long ph_miss = 0, ph_a = 0, pb_t[5] = {0, 0, 0, 0, 0};
     long long ph[5] = {0, 0, 0, 0, 0};  // (only with -DGN_PHASE_CLOCKS) point loop | wg reduce + publish | exchange | - | totals + solve
     // this lane's point of chunk qb: block qb + wavefront of this workgroup, i.e. global block (qb + wavefront) G + wg
-    auto chunk_point = [&](int qb, int& i) -> bool { const int q = qb + (tid >> 6); i = ((q * G + wg) << 6) + (tid & 63); return q < my_blocks && i < n; };
+    // tl = tid, made opaque at the top of every iteration: what the loop derives from the lane number (LDS and row addresses of the
+    // reduction, the exchange and the solve, the first chunk's addresses) is then computed where it is used - a few integer
+    // instructions - instead of once before the loop.  Hoisted, those values outlived the point loop's 256 registers in scratch
+    // memory, and the serial tail of every iteration fetched them back one dependent round trip at a time (about 25 of them).
+    int tl = tid;
+    auto chunk_point = [&](int qb, int& i) -> bool { const int q = qb + (tl >> 6); i = ((q * G + wg) << 6) + (tl & 63); return q < my_blocks && i < n; };
     auto pos_in_lds = [&](int qb) -> bool { return (qb / NW + 1) * NT <= GN8_LDS_PTS; };
     // (two chunks ahead, GN8_PREFETCH = 2: tried - no faster, the loop got 3 % slower)
     auto preload_chunk = [&](int qb, bool first) -> Gn8Pre { int i2; const bool v2 = chunk_point(qb, i2); return gn8_preload(c, i2, v2, first, first || !pos_in_lds(qb)); };
@@ -1974,9 +1988,11 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     [[maybe_unused]] Gn8Pre pre2 = pre;
     if (GN8_PREFETCH > 1) pre2 = preload_chunk(NW, true);
     for (int it = 0; it < c.max_iter; ++it) {
+        asm volatile("" : "+v"(tl));
+        [[maybe_unused]] const int lane32 = tl & 31, grp32 = tl >> 5;
         const long long c0 = GN_CLK();
         const double* Esh = Esh2[(it + 1) & 1];
-        if (tid == 64 && it > 0) gn_compose(Esh, Tsh);
+        if (tl == 64 && it > 0) gn_compose(Esh, Tsh);
         double M[GN8_ROW_ENTRIES];
 #pragma unroll
         for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
@@ -2014,7 +2030,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     for (int k = 0; k < 9; ++k) E.R[k] = Esh[k];
                     for (int k = 0; k < 3; ++k) E.t[k] = Esh[9 + k];
                     const bool lds = pos_in_lds(qb);
-                    const int li = (qb / NW) * NT + tid;
+                    const int li = (qb / NW) * NT + tl;
                     const V3 p0 = (it == 0 || !lds) ? v3(cur.px, cur.py, cur.pz) : v3(posL[0][li], posL[1][li], posL[2][li]);
                     const V3 s = rt_apply(E, p0);
                     if (lds) { posL[0][li] = s.x; posL[1][li] = s.y; posL[2][li] = s.z; liA = li; }
@@ -2066,9 +2082,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             // data alone: deterministic.
             {
                 const unsigned long long bm = __ballot(missA >= 0), br = __ballot(missA >= 0 && rebA);
-                const unsigned long long bf = bm & ~br, below = (1ull << (tid & 63)) - 1ull;
+                const unsigned long long bf = bm & ~br, below = (1ull << (tl & 63)) - 1ull;
                 if (missA >= 0) {
-                    const int base = (tid >> 6) * GN8_QWAVE;
+                    const int base = (tl >> 6) * GN8_QWAVE;
                     const int pos = rebA ? base + GN8_QWAVE - 1 - (nqr + __popcll(br & below)) : base + nq + __popcll(bf & below);
                     missq[pos] = make_int2(missA, liA);
                 }
@@ -2080,10 +2096,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             }
 #ifdef GN_PHASE_CLOCKS
             const long long pa2 = GN_CLK();
-            if (wg == 0 && tid == 0 && it > 0) { atomicAdd((unsigned long long*)&c.wg_clk[56], (unsigned long long)(pa1 - pa0)); atomicAdd((unsigned long long*)&c.wg_clk[57], (unsigned long long)(pa2 - pa1)); atomicAdd((unsigned long long*)&c.wg_clk[59], 1ull); }
+            if (wg == 0 && tl == 0 && it > 0) { atomicAdd((unsigned long long*)&c.wg_clk[56], (unsigned long long)(pa1 - pa0)); atomicAdd((unsigned long long*)&c.wg_clk[57], (unsigned long long)(pa2 - pa1)); atomicAdd((unsigned long long*)&c.wg_clk[59], 1ull); }
 #endif
             if (qb + NW < my_blocks && ((qb / NW + 1) % GN8_QCHUNKS) != 0) continue;  // (a region holds GN8_QCHUNKS chunks whatever they bring)
-            if ((tid & 63) == 0) { qcount[0][tid >> 6] = nq; qcount[1][tid >> 6] = nqr; }
+            if ((tl & 63) == 0) { qcount[0][tl >> 6] = nq; qcount[1][tl >> 6] = nqr; }
             nq = 0; nqr = 0;
             __syncthreads();
             // search slots: the fronts of the regions, wavefront by wavefront, then - from the next wavefront's first slot on - the backs
@@ -2095,9 +2111,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 nfront += cf[w]; nback += cb[w];
             }
             const int kback0 = (nfront + 7) & ~7, nmiss = kback0 + nback;
-            if (tid == 0) xcnt[0] += (unsigned)(nfront + nback);
+            if (tl == 0) xcnt[0] += (unsigned)(nfront + nback);
 #ifdef GN_PHASE_CLOCKS
-            if (wg == 0 && tid == 0 && it < 24) st->dbg_sums[8 + it] += (double)(nfront + nback);  // misses by iteration index
+            if (wg == 0 && tl == 0 && it < 24) st->dbg_sums[8 + it] += (double)(nfront + nback);  // misses by iteration index
 #endif
             // queue slot of search slot k
             auto qslot = [&](int k) -> int {
@@ -2113,8 +2129,8 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             // ---- phase B, GN8_LPB LANES PER POINT: the full search of the queued points (gn8_search)
             auto phaseB = [&](auto lp_tag) {
                 constexpr int LPB = decltype(lp_tag)::value;
-                const int laneL = tid & (LPB - 1), gb = (tid & 63) & ~(LPB - 1);
-                for (int k = tid / LPB; __any(k < nmiss); k += NT / LPB) {
+                const int laneL = tl & (LPB - 1), gb = (tl & 63) & ~(LPB - 1);
+                for (int k = tl / LPB; __any(k < nmiss); k += NT / LPB) {
                   if (k < nfront || (k >= kback0 && k < nmiss)) {
                     [[maybe_unused]] const long long b0 = GN_CLK();
                     const int2 qe = missq[qslot(k)];
@@ -2157,7 +2173,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             else phaseB(std::integral_constant<int, GN8_LPB>{});
             __syncthreads();  // the queue is reused by the next chunk
 #ifdef GN_PHASE_CLOCKS
-            if (wg == 0 && tid == 0 && it > 0) { atomicAdd((unsigned long long*)&c.wg_clk[58], (unsigned long long)(GN_CLK() - pa2)); atomicAdd((unsigned long long*)&c.wg_clk[60], (unsigned long long)((nmiss + NT / GN8_LPB - 1) / (NT / GN8_LPB))); }
+            if (wg == 0 && tl == 0 && it > 0) { atomicAdd((unsigned long long*)&c.wg_clk[58], (unsigned long long)(GN_CLK() - pa2)); atomicAdd((unsigned long long*)&c.wg_clk[60], (unsigned long long)((nmiss + NT / GN8_LPB - 1) / (NT / GN8_LPB))); }
 #endif
             {   // (queue flushed before the last chunk: its loads are requested again rather than carried across the search;
                 // after the last chunk nothing is loaded - chunk_point says so - and the stale values are dead for the compiler too)
@@ -2183,21 +2199,21 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             v += __shfl_xor(v, 32);
             M[e] = v;
         }
-        if ((tid & 63) == 0) {
+        if ((tl & 63) == 0) {
 #pragma unroll
-            for (int e = 0; e < GN8_ROW_ENTRIES; ++e) part[e][tid >> 6] = M[e];
+            for (int e = 0; e < GN8_ROW_ENTRIES; ++e) part[e][tl >> 6] = M[e];
         }
         __syncthreads();
         const unsigned flag = gn_flag(epoch, it);
         const int par = it & 1, ngroups = G < 8 ? G : 8;
         bool ok = true;
-        if (tid < 2 * GN8_ROW_ENTRIES) {
-            const int e = tid >> 1;
+        if (tl < 2 * GN8_ROW_ENTRIES) {
+            const int e = tl >> 1;
             double rowv = 0.0;
             for (int j = 0; j < NW; ++j) rowv += part[e][j];
             const unsigned long long bits = (unsigned long long)__double_as_longlong(rowv);
-            const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
-            __hip_atomic_store(&c.gn_rows_ll[((size_t)par * G + wg) * GN_LL_WORDS + tid],
+            const unsigned half = (tl & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+            __hip_atomic_store(&c.gn_rows_ll[((size_t)par * G + wg) * GN_LL_WORDS + tl],
                                (unsigned long long)half | ((unsigned long long)flag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const long long c2 = GN_CLK();
@@ -2207,8 +2223,8 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         // factorisation.  Other G: every 32-lane group polls one row into LDS, then the sums.
         long long c3 = c2;
         if (GC > 0) {
-            if (tid < 64) {
-                const bool mine = tid < 2 * GN8_ROW_ENTRIES;
+            if (tl < 64) {
+                const bool mine = tl < 2 * GN8_ROW_ENTRIES;
                 unsigned h[GC > 0 ? GC : 32];
                 unsigned spins = 0;
                 for (;;) {
@@ -2216,7 +2232,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
 #pragma unroll
                     for (int j = 0; j < (GC > 0 ? GC : 32); ++j) {
                         unsigned long long vv = (unsigned long long)flag << 32;
-                        if (mine) vv = __hip_atomic_load(c.gn_rows_ll + ((size_t)par * G + j) * GN_LL_WORDS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (mine) vv = __hip_atomic_load(c.gn_rows_ll + ((size_t)par * G + j) * GN_LL_WORDS + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         bad |= (unsigned)(vv >> 32) ^ flag;
                         h[j] = (unsigned)vv;
                     }
@@ -2232,8 +2248,8 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     if (GC > 16) { sg += gn_ll_join(h[(g + 16) % (GC > 0 ? GC : 32)]); sg += gn_ll_join(h[(g + 24) % (GC > 0 ? GC : 32)]); }
                     t += sg;
                 }
-                if (mine && (tid & 1) == 0) mom[tid >> 1] = t;
-                if (!ok && tid == 0) gn_raise_abort(st);
+                if (mine && (tl & 1) == 0) mom[tl >> 1] = t;
+                if (!ok && tl == 0) gn_raise_abort(st);
                 c3 = GN_CLK();
             }
         } else if (G <= 64) {
@@ -2250,14 +2266,14 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             if (!ok) gn_raise_abort(st);
             ok = __syncthreads_or(ok ? 0 : 1) == 0;
             c3 = GN_CLK();
-            if (tid < GN8_ROW_ENTRIES) {
+            if (tl < GN8_ROW_ENTRIES) {
                 double t = 0.0;
                 for (int g = 0; g < ngroups; ++g) {
                     double sg = 0.0;
-                    for (int j = g; j < G; j += 8) sg += redL8[j][tid];
+                    for (int j = g; j < G; j += 8) sg += redL8[j][tl];
                     t += sg;
                 }
-                mom[tid] = t;
+                mom[tl] = t;
             }
         } else {
             // one sequence over the whole chip (G up to 512): the two-hop exchange of the 32-lane kernel - rows -> the
@@ -2276,21 +2292,21 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 }
                 if (!ok) gn_raise_abort(st);
                 __syncthreads();
-                if (tid < GN8_ROW_ENTRIES) {  // sum in member order; both halves of the entry to every consumer slot
+                if (tl < GN8_ROW_ENTRIES) {  // sum in member order; both halves of the entry to every consumer slot
                     double sm = 0.0;
-                    for (int j = 0; j < nmem; ++j) sm += redL8[j][tid];
+                    for (int j = 0; j < nmem; ++j) sm += redL8[j][tl];
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(sm), fl = (unsigned long long)flag << 32;
                     const unsigned long long lo = (bits & 0xFFFFFFFFull) | fl, hi = (bits >> 32) | fl;
 #pragma unroll
                     for (int r = 0; r < GN_XSUM_COPIES; ++r) {
-                        unsigned long long* dst = c.gn_xsum_ll + (((size_t)par * 8 + r) * 8 + wg) * GN_LL_WORDS + 2 * tid;
+                        unsigned long long* dst = c.gn_xsum_ll + (((size_t)par * 8 + r) * 8 + wg) * GN_LL_WORDS + 2 * tl;
                         __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
-            if (tid < 64) {  // everybody: the group sums addressed to this workgroup's slot, added in group order
-                const bool mine = tid < 2 * GN8_ROW_ENTRIES;
+            if (tl < 64) {  // everybody: the group sums addressed to this workgroup's slot, added in group order
+                const bool mine = tl < 2 * GN8_ROW_ENTRIES;
                 bool ok2 = true;
                 unsigned h[8];
                 unsigned spins = 0;
@@ -2300,7 +2316,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     for (int g = 0; g < 8; ++g) {
                         unsigned long long vv = (unsigned long long)flag << 32;
                         if (mine && g < ngroups)
-                            vv = __hip_atomic_load(c.gn_xsum_ll + (((size_t)par * 8 + (wg & (GN_XSUM_COPIES - 1))) * 8 + g) * GN_LL_WORDS + tid,
+                            vv = __hip_atomic_load(c.gn_xsum_ll + (((size_t)par * 8 + (wg & (GN_XSUM_COPIES - 1))) * 8 + g) * GN_LL_WORDS + tl,
                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         bad |= (unsigned)(vv >> 32) ^ flag;
                         h[g] = (unsigned)vv;
@@ -2315,13 +2331,13 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                     const double v = gn_ll_join(h[g]);
                     if (g < ngroups) t += v;
                 }
-                if (mine && (tid & 1) == 0) mom[tid >> 1] = t;
-                if (!ok2 && tid == 0) gn_raise_abort(st);
+                if (mine && (tl & 1) == 0) mom[tl >> 1] = t;
+                if (!ok2 && tl == 0) gn_raise_abort(st);
                 ok = ok && ok2;
                 c3 = GN_CLK();
             }
         }
-        if (tid < 64) {
+        if (tl < 64) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             {   // every lane takes all 18 moments into registers (18 broadcast reads in flight together) and picks its entry of the
@@ -2330,9 +2346,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 double mm[GN8_ROW_ENTRIES];
 #pragma unroll
                 for (int e = 0; e < GN8_ROW_ENTRIES; ++e) mm[e] = mom[e];
-                if (tid < 27) tot[tid] = sums_from_moments(tid, mm);
-                else if (tid == 27) tot[27] = mm[16];
-                else if (tid == 28) tot[28] = mm[17];
+                if (tl < 27) tot[tl] = sums_from_moments(tl, mm);
+                else if (tl == 27) tot[27] = mm[16];
+                else if (tl == 28) tot[28] = mm[17];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -2340,11 +2356,11 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             const long long s1 = GN_CLK();
 #endif
             double dx[6];
-            solve6_ldlt_wave(tot, tid, dx);
+            solve6_ldlt_wave(tot, tl, dx);
 #ifdef GN_PHASE_CLOCKS
             const long long s2 = GN_CLK();
 #endif
-            if (tid == 0) {
+            if (tl == 0) {
                 const Rt e = se3_exp_gn(dx);
                 for (int k = 0; k < 9; ++k) Esh2[it & 1][k] = e.R[k];
                 for (int k = 0; k < 3; ++k) Esh2[it & 1][9 + k] = e.t[k];
@@ -2353,7 +2369,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
                 flag_done2[it & 1] = (nn < conv2 || !ok) ? 1 : 0;
             }
 #ifdef GN_PHASE_CLOCKS
-            if (tid == 0 && wg == 0) { const long long s3 = GN_CLK(); atomicAdd((unsigned long long*)&c.wg_clk[67], (unsigned long long)(s1 - c3)); atomicAdd((unsigned long long*)&c.wg_clk[68], (unsigned long long)(s2 - s1));
+            if (tl == 0 && wg == 0) { const long long s3 = GN_CLK(); atomicAdd((unsigned long long*)&c.wg_clk[67], (unsigned long long)(s1 - c3)); atomicAdd((unsigned long long*)&c.wg_clk[68], (unsigned long long)(s2 - s1));
                                        atomicAdd((unsigned long long*)&c.wg_clk[69], (unsigned long long)(s3 - s2)); atomicAdd((unsigned long long*)&c.wg_clk[70], 1ull); }
 #endif
         }
@@ -2361,9 +2377,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         const long long c5 = GN_CLK();
         ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += c5 - c3;
 #if defined(GN_PHASE_CLOCKS) || defined(GN_IT0_CLOCK)
-        if (tid == 0 && wg == 0) atomicAdd((unsigned long long*)&c.wg_clk[52 + (it == 0 ? 0 : 1)], (unsigned long long)(c1 - c0));  // point loop of the first iteration / of the others
+        if (tl == 0 && wg == 0) atomicAdd((unsigned long long*)&c.wg_clk[52 + (it == 0 ? 0 : 1)], (unsigned long long)(c1 - c0));  // point loop of the first iteration / of the others
 #endif
-        if (tid == NT - 1) cand_total_sh += (long long)tot[28];
+        if (tl == NT - 1) cand_total_sh += (long long)tot[28];
         iters = it + 1;
         if (flag_done2[it & 1]) break;
     }
