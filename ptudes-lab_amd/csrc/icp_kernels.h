@@ -193,23 +193,6 @@ __device__ __forceinline__ unsigned long long pack_key(int kx, int ky, int kz) {
            (unsigned long long)(kz + KEY_OFF);
 }
 
-// find-or-claim a slot for `key` in a per-scan VDS table; returns slot or -1 when the table is full
-__device__ __forceinline__ int vds_claim(VdsEnt* tab, unsigned mask, unsigned long long key) {
-    unsigned s = brick_slot(key, mask);
-    for (unsigned probe = 0; probe <= mask; ++probe) {
-        // A plain (L2-cached) read: within a kernel a slot only ever goes EMPTY -> key, so the worst a stale line can
-        // show is EMPTY, and then the CAS below - performed at device scope - decides.
-        unsigned long long cur = tab[s].key;
-        if (cur == key) return (int)s;
-        if (cur == EMPTY_KEY) {
-            unsigned long long old = atomicCAS(&tab[s].key, EMPTY_KEY, key);
-            if (old == EMPTY_KEY || old == key) return (int)s;
-        }
-        s = (s + 1) & mask;
-    }
-    return -1;
-}
-
 // ------------------------------------------------------------------------------------------------ K0
 // One thread.  kiss_icp.KissICP: deskew twist from its own last two poses, get_adaptive_threshold()
 // (Threshold.cpp ComputeThreshold, stateful), initial guess (reference kiss.py:102-105 or the caller's).
@@ -386,24 +369,39 @@ __device__ __forceinline__ Slice launch_slice() { Slice s; s.b = (int)blockIdx.x
 
 // U find-or-claims in a per-scan VDS table in flight together: the compare-and-swap on the hashed slot straight away (it
 // returns what was there: empty -> claimed, the key -> found; a look at the slot first would be one more dependent memory
-// round trip per pass), and whatever that does not settle (a collision) goes through vds_claim
+// round trip per pass).  What that does not settle (the slot holds another voxel) walks on by linear probing IN ROUNDS: every
+// unsettled point of the thread sends its next compare-and-swap, then all are looked at - a round trip per probe distance.
+// (Point by point it was three dependent round trips per collision and u: some lane of a wavefront collides
+// for nearly every u, and the claims of a K1 pass took 58 us.)
 template <int U>
 __device__ __forceinline__ void vds_claim_u(VdsEnt* tab, unsigned mask, const unsigned long long (&key)[U], const bool (&want)[U],
                                             int (&slot)[U]) {
-    unsigned s0[U];
+    unsigned sp[U];
     unsigned long long old[U];
+    bool pend[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        s0[u] = brick_slot(key[u], mask);
+        sp[u] = brick_slot(key[u], mask);
         slot[u] = -1;
         old[u] = key[u];
-        if (want[u]) old[u] = atomicCAS(&tab[s0[u]].key, EMPTY_KEY, key[u]);
+        if (want[u]) old[u] = atomicCAS(&tab[sp[u]].key, EMPTY_KEY, key[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        if (!want[u]) continue;
-        if (old[u] == EMPTY_KEY || old[u] == key[u]) slot[u] = (int)s0[u];
-        else slot[u] = vds_claim(tab, mask, key[u]);
+        pend[u] = want[u] && !(old[u] == EMPTY_KEY || old[u] == key[u]);
+        if (want[u] && !pend[u]) slot[u] = (int)sp[u];
+    }
+    for (unsigned probe = 1; probe <= mask; ++probe) {
+        bool anyp = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) anyp = anyp || pend[u];
+        if (!anyp) break;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (pend[u]) { sp[u] = (sp[u] + 1) & mask; old[u] = atomicCAS(&tab[sp[u]].key, EMPTY_KEY, key[u]); }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (pend[u] && (old[u] == EMPTY_KEY || old[u] == key[u])) { slot[u] = (int)sp[u]; pend[u] = false; }
     }
 }
 // the claimed slots' bids: slot value = the smallest point index that maps to the voxel (no result is needed: the
@@ -1646,22 +1644,31 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
                 eq[q].key = EMPTY_KEY; eq[q].blk = -1; eq[q].head = -1;
                 if (ee < 27) eq[q] = c.tab[sq[q]];
             }
+            bool pend[RE];
 #pragma unroll
             for (int q = 0; q < RE; ++q) {
-                int b = -1;
-                if (eq[q].key == kq[q]) b = eq[q].blk;
-                else if (eq[q].key != EMPTY_KEY) {  // occupied by another voxel (or a tombstone): linear probing from the next slot
-                    unsigned sp = (sq[q] + 1) & c.tmask;
-                    for (unsigned probe = 1; probe <= c.tmask; ++probe) {
-                        const TabEnt e = c.tab[sp];
-                        if (e.key == kq[q]) { b = e.blk; break; }
-                        if (e.key == EMPTY_KEY) break;
-                        sp = (sp + 1) & c.tmask;
-                    }
-                }
-                r[q] = b;
-                cs += (b < 0) ? 0 : (int)((unsigned)b >> 24);
+                r[q] = -1;
+                pend[q] = false;
+                if (eq[q].key == kq[q]) r[q] = eq[q].blk;
+                else if (eq[q].key != EMPTY_KEY) pend[q] = true;  // occupied by another voxel (or a tombstone): linear probing from the next slot
             }
+            for (unsigned probe = 1; probe <= c.tmask; ++probe) {  // ... in rounds: the next slots of all unsettled probes travel together
+                bool anyp = false;
+#pragma unroll
+                for (int q = 0; q < RE; ++q) anyp = anyp || pend[q];
+                if (!anyp) break;
+#pragma unroll
+                for (int q = 0; q < RE; ++q)
+                    if (pend[q]) { sq[q] = (sq[q] + 1) & c.tmask; eq[q] = c.tab[sq[q]]; }
+#pragma unroll
+                for (int q = 0; q < RE; ++q) {
+                    if (!pend[q]) continue;
+                    if (eq[q].key == kq[q]) { r[q] = eq[q].blk; pend[q] = false; }
+                    else if (eq[q].key == EMPTY_KEY) pend[q] = false;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RE; ++q) cs += (r[q] < 0) ? 0 : (int)((unsigned)r[q] >> 24);
         }
         cs = group_sumL<LP>(cs);
         if (laneL == 28 / RE) r[28 % RE] = cs;  // entry 28: candidates of the 27 voxels (entry 27: no last winner yet = -1)
@@ -2081,10 +2088,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
             // chunk, mostly that wait).  The order of the queue - wavefront by wavefront, chunk by chunk - depends on the
             // data alone: deterministic.
             {
+                int tq = tl;  // (opaque per chunk: the region's base and the lane mask are two instructions, not a spilled register each)
+                asm volatile("" : "+v"(tq));
                 const unsigned long long bm = __ballot(missA >= 0), br = __ballot(missA >= 0 && rebA);
-                const unsigned long long bf = bm & ~br, below = (1ull << (tl & 63)) - 1ull;
+                const unsigned long long bf = bm & ~br, below = (1ull << (tq & 63)) - 1ull;
                 if (missA >= 0) {
-                    const int base = (tl >> 6) * GN8_QWAVE;
+                    const int base = (tq >> 6) * GN8_QWAVE;
                     const int pos = rebA ? base + GN8_QWAVE - 1 - (nqr + __popcll(br & below)) : base + nq + __popcll(bf & below);
                     missq[pos] = make_int2(missA, liA);
                 }
@@ -2450,36 +2459,52 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
         keyed[u] = vox_key(p[u], c.vs, key[u], kx, ky, kz);
         if (!keyed[u]) { atomicOr(&st->err_flags, ERR_KEY_RANGE); continue; }
         s0[u] = brick_slot(key[u], c.tmask);
-        cur[u] = c.tab[s0[u]].key;  // plain read, as in vds_claim: EMPTY -> key is the only change in this kernel
+        cur[u] = c.tab[s0[u]].key;  // plain (L2-cached) read: EMPTY -> key is the only change in this kernel, so the worst a stale line shows is EMPTY - and then the swap decides
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         old[u] = key[u];
         if (keyed[u] && cur[u] == EMPTY_KEY) old[u] = atomicCAS(&c.tab[s0[u]].key, EMPTY_KEY, key[u]);
     }
-    bool created[U];
+    bool created[U], pend[U];
+    unsigned sp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        created[u] = false;
+        created[u] = false; pend[u] = false; sp[u] = s0[u];
         if (!keyed[u]) continue;
-        unsigned s = s0[u];
-        if (cur[u] == key[u] || (cur[u] == EMPTY_KEY && old[u] == key[u])) slot[u] = (int)s;
-        else if (cur[u] == EMPTY_KEY && old[u] == EMPTY_KEY) { slot[u] = (int)s; created[u] = true; }
-        else {  // occupied by another voxel or a tombstone (or the swap lost to another key): linear probing goes on
-            s = (s + 1) & c.tmask;
-            for (unsigned probe = 1; probe <= c.tmask; ++probe) {
-                const unsigned long long ck = c.tab[s].key;
-                if (ck == key[u]) { slot[u] = (int)s; break; }
-                if (ck == EMPTY_KEY) {
-                    const unsigned long long o = atomicCAS(&c.tab[s].key, EMPTY_KEY, key[u]);
-                    if (o == EMPTY_KEY) { slot[u] = (int)s; created[u] = true; break; }
-                    if (o == key[u]) { slot[u] = (int)s; break; }
-                }
-                s = (s + 1) & c.tmask;
-            }
-        }
-        if (slot[u] < 0) atomicOr(&st->err_flags, ERR_TABLE);
+        if (cur[u] == key[u] || (cur[u] == EMPTY_KEY && old[u] == key[u])) slot[u] = (int)s0[u];
+        else if (cur[u] == EMPTY_KEY && old[u] == EMPTY_KEY) { slot[u] = (int)s0[u]; created[u] = true; }
+        else pend[u] = true;  // occupied by another voxel or a tombstone (or the swap lost to another key): linear probing goes on
     }
+    // ... in rounds: the next slot of every unsettled point is read, then the swaps on the empty ones are sent, then all are
+    // looked at (point by point it was two to three dependent round trips per collision and u)
+    for (unsigned probe = 1; probe <= c.tmask; ++probe) {
+        bool anyp = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) anyp = anyp || pend[u];
+        if (!anyp) break;
+        unsigned long long ck[U], o[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ck[u] = 0ull;
+            if (pend[u]) { sp[u] = (sp[u] + 1) & c.tmask; ck[u] = c.tab[sp[u]].key; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            o[u] = key[u];
+            if (pend[u] && ck[u] == EMPTY_KEY) o[u] = atomicCAS(&c.tab[sp[u]].key, EMPTY_KEY, key[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!pend[u]) continue;
+            if (ck[u] == key[u]) { slot[u] = (int)sp[u]; pend[u] = false; }
+            else if (ck[u] == EMPTY_KEY && o[u] == EMPTY_KEY) { slot[u] = (int)sp[u]; created[u] = true; pend[u] = false; }
+            else if (ck[u] == EMPTY_KEY && o[u] == key[u]) { slot[u] = (int)sp[u]; pend[u] = false; }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (keyed[u] && slot[u] < 0) atomicOr(&st->err_flags, ERR_TABLE);
     {   // the new voxels take their blocks from the pool: every step for all U points at once (the pops, then the reads of the
         // free stack, then the headers) - step by step per point it is a chain of dependent memory round trips per u, and some
         // lane of a wavefront creates a voxel for nearly every u
