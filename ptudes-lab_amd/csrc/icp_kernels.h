@@ -1496,6 +1496,12 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
 //   * wavefront reduction by DPP, workgroup reduction through LDS in wavefront order, one 18-entry row per workgroup;
 //     exchange in one hop (<= 64 workgroups: the first wavefront polls every row itself and solves straight away) or in
 //     two hops through 8 group leaders (one sequence over the whole chip).
+#ifndef GN8_KEEP
+#define GN8_KEEP 1.5          /* a voxel is dropped from the search when its box lies farther than sqrt(GN8_KEEP) x the best distance so far.  1 = exactly what
+                                 cannot hold a closer point; > 1 also scans voxels that cannot win, and what is found there replaces the box distance in
+                                 the bound of the answer row: fewer repeated searches later.  1 / 1.5 / 2.25 / 3: Gauss-Newton 2566 / 2493 / 2520 / 2564 us
+                                 per scan (make KEEP=x) */
+#endif
 #ifndef GN8_KCAND
 #define GN8_KCAND 4           /* candidates an answer row keeps (2..5); a CPU simulation of the policy on the bench's sweeps: repeated searches per scan
                                  32 k (1) | 11.5 k (2) | 6.5 k (3) | 4.4 k (4) | 2.4 k (6) for ~6800 source points x 36 iterations */
@@ -1747,7 +1753,7 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
 #pragma unroll
         for (int q = 0; q < RE; ++q) {
             if (!(gap2[q] < 1.0e300)) continue;
-            if (gap2[q] > m0) gdrop = fmin(gdrop, gap2[q]); else mine |= 1u << q;
+            if (gap2[q] > GN8_KEEP * m0) gdrop = fmin(gdrop, gap2[q]); else mine |= 1u << q;
         }
     }
     for (;;) {  // the surviving voxels, two at a time (their loads in flight together)
