@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
 #define GN8_ANS_ROW ((3 + 3 * GN8_KCAND + 2 + 1) & ~1)  /* doubles per answer row: s0 (3) | the K nearest candidates (3 each) | bound | ids, counts (packed) [| pad] */
 #define GN8_ANS_D (3 + 3 * GN8_KCAND)
 #ifndef GN8_SPEC
-#define GN8_SPEC 1            /* first search round takes the two nearest other boxes along (speculatively): 7.14 k against 7.07 k scans/s for 16 sequences */
+#define GN8_SPEC 2            /* how many of the nearest other boxes the first search round takes along, their loads in flight with the own voxel's (0 .. 3; make SPEC=n) */
 #endif
 // ---- group primitives for LP = 8 or 4 lanes per point: DPP steps inside the VALU (quad permutes, for 8 lanes the half-row
 // mirror on top - every quad holds its result already, so pairing mirrored lanes is as good as xor 4); nothing goes through
@@ -1717,28 +1717,31 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
             gap2[q] = (gx + gy) + gz;
         }
     }
-    if (LP == 8 && GN8_SPEC) {
+    if (LP == 8 && GN8_SPEC > 0) {
         // first round: the own voxel, the last winner's and the two nearest other boxes, all loads in flight together (a
         // voxel scanned although its box turns out to lie beyond the best distance is harmless: it is one of the 27)
-        int vsel[2], psel[2];
+        constexpr int NS = GN8_SPEC > 0 ? GN8_SPEC : 1;  // nearest other boxes taken along
+        int pbN[2 + NS], vxN[2 + NS];
+        pbN[0] = pbc; pbN[1] = pbl; vxN[0] = 13; vxN[1] = lv;
+        unsigned npts = pb_count(pbc) + pb_count(pbl);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NS; ++u) {
             double gl = 1.7976931348623157e308;
             int ql = 0;
 #pragma unroll
             for (int q = 0; q < RE; ++q) if (gap2[q] < gl) { gl = gap2[q]; ql = q; }
             const double gmin = group_minL<LP>(gl);
             const unsigned v = group_minL<LP>((gl == gmin && gmin < 1.0e300) ? (unsigned)(RE * laneL + ql) : 0xFFu);
-            vsel[u] = (v == 0xFFu) ? -1 : (int)v;
-            psel[u] = (v == 0xFFu) ? -1 : __shfl(sel_entry<RE>(r, (int)(v % RE)), gb + (int)((v / RE) & (LP - 1)));
+            vxN[2 + u] = (v == 0xFFu) ? -1 : (int)v;
+            pbN[2 + u] = (v == 0xFFu) ? -1 : __shfl(sel_entry<RE>(r, (int)(v % RE)), gb + (int)((v / RE) & (LP - 1)));
+            npts += pb_count(pbN[2 + u]);
             if (v != 0xFFu && (int)(v / RE) == laneL) {
 #pragma unroll
                 for (int q = 0; q < RE; ++q) if (q == (int)(v % RE)) gap2[q] = 1.7976931348623157e308;
             }
         }
-        const int pb4[4] = {pbc, pbl, psel[0], psel[1]}, vx4[4] = {13, lv, vsel[0], vsel[1]};
-        if (laneL == 0) atomicAdd(xc + 2, pb_count(pbc) + pb_count(pbl) + pb_count(psel[0]) + pb_count(psel[1]));
-        scan_voxelsL<PC, LP, 4>(c, pb4, vx4, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
+        if (laneL == 0) atomicAdd(xc + 2, npts);
+        scan_voxelsL<PC, LP, 2 + NS>(c, pbN, vxN, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
     } else {
         const int pb2[2] = {pbc, pbl}, vx2[2] = {13, lv};
         if (laneL == 0) atomicAdd(xc + 2, pb_count(pbc) + pb_count(pbl));
