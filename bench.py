@@ -58,8 +58,9 @@ EXEC_COST = {
     # src_cur every iteration; after the first iteration phase A also reads the voxel key (8) and the 144-byte answer row
     # (position of the last search, its four nearest candidates, the bound on everybody else, ids: GN8_KCAND = 4)
     "source_read": 24, "point_iteration_in_memory": 48, "point_iteration_later": 152, "lds_points_per_workgroup": 3072,
-    # a full search reads the probe row (128) + key (8), writes the answer row (144) + the winner's voxel (4)
-    "search": 284,
+    # a full search reads the probe row (128) + key (8), writes the answer row (144) + the winner's voxel (4); the searches of a scan's
+    # first iteration (every source point once) read neither: their rows are rebuilt whatever they hold
+    "search": 284, "search_first_iteration_not_read": 136,
     # a rebuilt probe row: 27 hash-table entries of 16 B, the row (128) and the key (8) written
     "row_rebuilt": 27 * 16 + 136,
     "map_point_read": 24,
@@ -93,6 +94,7 @@ def executed_bytes(cnt, stats, n_raw, G, cols=1024):
     first = sum(s["n_src"] for s in stats if s["iterations"] > 0)
     in_mem = sum(max(s["n_src"] - max(G, 1) * c["lds_points_per_workgroup"], 0) * s["iterations"] for s in stats)  # point-iterations through src_cur
     gn = (c["source_read"] * first + c["point_iteration_in_memory"] * in_mem + c["point_iteration_later"] * max(pi - first, 0) + c["search"] * cnt["searches"]
+          - c["search_first_iteration_not_read"] * min(first, cnt["searches"])
           + c["row_rebuilt"] * cnt["rows_rebuilt"] + c["map_point_read"] * cnt["map_points_read"]
           + cnt["gn_iterations"] * G * (1 + G) * c["exchange_words_per_row"] * c["exchange_word"])
     st = 0

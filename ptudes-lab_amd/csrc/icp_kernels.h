@@ -1629,7 +1629,9 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
     const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
     const unsigned long long key = pack_key(kx, ky, kz);
     int r[RE];
-    {
+#pragma unroll
+    for (int k = 0; k < RE; ++k) r[k] = -1;
+    if (it > 0) {  // (uniform; a scan's first iteration rebuilds every row: nothing to read, nothing to wait for)
         const int4* rp = (const int4*)(c.pc_pb + 32 * (size_t)i + RE * laneL);  // (requested together with the key that validates it)
 #pragma unroll
         for (int k = 0; k < RE / 4; ++k) { const int4 v = rp[k]; r[4 * k] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w; }

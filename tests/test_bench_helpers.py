@@ -74,14 +74,14 @@ def test_executed_byte_model():
     """the as-executed model of the free-running kernel: unit costs x the kernel's counters + the per-scan statistics"""
     b = _bench()
     c = b.EXEC_COST
-    cnt = dict(searches=100, rows_rebuilt=10, map_points_read=5000, gn_iterations=7, vds1_claims=300, vds2_claims=40, point_iterations=7000, scans=1)
+    cnt = dict(searches=5000, rows_rebuilt=10, map_points_read=5000, gn_iterations=7, vds1_claims=300, vds2_claims=40, point_iterations=7000, scans=1)
     st = [dict(iterations=7, n_src=1000, n_valid=100000, n_down=30000, map_voxels=20000)]
     tot, gn, stages = b.executed_bytes(cnt, st, 131072, 8, 1024)
-    assert gn == 24 * 1000 + 152 * 6000 + c["search"] * 100 + c["row_rebuilt"] * 10 + 24 * 5000 + 7 * 8 * 9 * 36 * 8
+    assert gn == 24 * 1000 + 152 * 6000 + c["search"] * 5000 - 136 * 1000 + c["row_rebuilt"] * 10 + 24 * 5000 + 7 * 8 * 9 * 36 * 8  # (the 1000 searches of the first iteration read no row)
     # a scan with more source points than the team's LDS holds (1 workgroup: 3072): the rest goes through src_cur every iteration
     big = [dict(st[0], n_src=4072)]
     _, gn_big, _ = b.executed_bytes(dict(cnt, point_iterations=7 * 4072), big, 131072, 1, 1024)
-    assert gn_big == 24 * 4072 + 48 * 1000 * 7 + 152 * 6 * 4072 + c["search"] * 100 + c["row_rebuilt"] * 10 + 24 * 5000 + 7 * 1 * 2 * 36 * 8
+    assert gn_big == 24 * 4072 + 48 * 1000 * 7 + 152 * 6 * 4072 + c["search"] * 5000 - 136 * 4072 + c["row_rebuilt"] * 10 + 24 * 5000 + 7 * 1 * 2 * 36 * 8
     assert stages == c["raw_point"] * 131072 + c["valid_point"] * 100000 + c["down_point"] * 30000 + c["source_point"] * 1000 \
         + 32 * 20000 + 96 * 1024 + 24 * 340
     assert tot == gn + stages
