@@ -1502,6 +1502,9 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
                                  the bound of the answer row: fewer repeated searches later.  1 / 1.5 / 2.25 / 3: Gauss-Newton 2566 / 2493 / 2520 / 2564 us
                                  per scan (make KEEP=x) */
 #endif
+#ifndef GN8_SURV
+#define GN8_SURV 2            /* voxels per survivor round of the search (make SURV=n) */
+#endif
 #ifndef GN8_KCAND
 #define GN8_KCAND 4           /* candidates an answer row keeps (2..5); a CPU simulation of the policy on the bench's sweeps: repeated searches per scan
                                  32 k (1) | 11.5 k (2) | 6.5 k (3) | 4.4 k (4) | 2.4 k (6) for ~6800 source points x 36 iterations */
@@ -1761,22 +1764,24 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
             if (gap2[q] > GN8_KEEP * m0) gdrop = fmin(gdrop, gap2[q]); else mine |= 1u << q;
         }
     }
-    for (;;) {  // the surviving voxels, two at a time (their loads in flight together)
-        unsigned cand = mine ? (unsigned)(RE * laneL + __ffs(mine) - 1) : 0xFFu;
-        const unsigned v0 = group_minL<LP>(cand);
-        if (v0 == 0xFFu) break;  // uniform over the group
+    for (;;) {  // the surviving voxels, GN8_SURV at a time (their loads in flight together)
+        int pbS[GN8_SURV], vxS[GN8_SURV];
+        unsigned npts = 0u;
+#pragma unroll
+        for (int j = 0; j < GN8_SURV; ++j) {
+            const unsigned cand = mine ? (unsigned)(RE * laneL + __ffs(mine) - 1) : 0xFFu;
+            const unsigned v = group_minL<LP>(cand);  // uniform over the group; 0xFF: nothing left
+            if (v != 0xFFu && (int)(v / RE) == laneL) mine &= mine - 1u;
+            vxS[j] = (int)v;
+            pbS[j] = (v != 0xFFu) ? __shfl(sel_entry<RE>(r, (int)(v % RE)), gb + (int)((v / RE) & (LP - 1))) : -1;
+            npts += pb_count(pbS[j]);
+        }
+        if (vxS[0] == 0xFF) break;
 #ifdef GN_PHASE_CLOCKS
         if (laneL == 0) atomicAdd((unsigned long long*)&c.wg_clk[41], 1ull);  // survivor rounds (wg_clk[40]: searches)
 #endif
-        if ((int)(v0 / RE) == laneL) mine &= mine - 1u;
-        cand = mine ? (unsigned)(RE * laneL + __ffs(mine) - 1) : 0xFFu;
-        const unsigned v1 = group_minL<LP>(cand);
-        if (v1 != 0xFFu && (int)(v1 / RE) == laneL) mine &= mine - 1u;
-        const int p0 = __shfl(sel_entry<RE>(r, (int)(v0 % RE)), gb + (int)(v0 / RE));
-        const int p1 = (v1 != 0xFFu) ? __shfl(sel_entry<RE>(r, (int)(v1 % RE)), gb + (int)((v1 / RE) & (LP - 1))) : -1;
-        const int pb2[2] = {p0, p1}, vx2[2] = {(int)v0, (int)v1};
-        if (laneL == 0) atomicAdd(xc + 2, pb_count(p0) + pb_count(p1));
-        scan_voxelsL<PC, LP, 2>(c, pb2, vx2, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
+        if (laneL == 0) atomicAdd(xc + 2, npts);
+        scan_voxelsL<PC, LP, GN8_SURV>(c, pbS, vxS, s, laneL, bd, sd, border, bp, b2d, b2o, b2p);
     }
 #ifdef GN_PHASE_CLOCKS
     if (laneL == 0) { atomicAdd((unsigned long long*)&c.wg_clk[40], 1ull); if (!same_voxel) atomicAdd((unsigned long long*)&c.wg_clk[42], 1ull); }
