@@ -974,6 +974,13 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// a value that is the same in every lane, moved to scalar registers
+__device__ __forceinline__ double uniform_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ void solve6_ldlt_wave(const double* s, int lane, double dx[6]) {
     const int i = lane < 6 ? lane : 5;  // lanes >= 6 shadow row 5 (their results are never read)
     double A[6], L[6], D[6];
@@ -1961,8 +1968,8 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
     const int tid = threadIdx.x;
     const int NT = blockDim.x, NG32 = blockDim.x >> 5, NW = blockDim.x >> 6;
     if (tid < 4) xcnt[tid] = 0u;
-    const int n = st->n_src;
-    const unsigned epoch = st->gn_epoch;
+    const int n = __builtin_amdgcn_readfirstlane(st->n_src);
+    const unsigned epoch = (unsigned)__builtin_amdgcn_readfirstlane((int)st->gn_epoch);
     if (wg == 0 && tid == 0 && mode == 0) flush_map_stats(c, st);
     if (st->n_live == 0) {  // voxel_map.Empty() => return initial_guess
         if (wg == 0 && tid == 0) {
@@ -1974,10 +1981,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt,
         return;
     }
     if (wg == st->dbg_dead_wg) return;  // test hook: a workgroup that never arrives
-    const double kern = st->gn_kernel, k2 = kern * kern;
-    const double gate2 = sqrt_gate(st->gn_max_dist);
-    const double conv2 = sqrt_gate(c.conv);
-    const double inv_vs = 1.0 / c.vs;
+    // the loop's uniform values sit in scalar registers (they arrive through vector loads: left alone, each would hold a vector
+    // register pair for the whole loop - at the 256-register cap that is what gets spilled)
+    const double kern = uniform_f64(st->gn_kernel), k2 = uniform_f64(kern * kern);
+    const double gate2 = uniform_f64(sqrt_gate(st->gn_max_dist));
+    const double conv2 = uniform_f64(sqrt_gate(c.conv));
+    const double inv_vs = uniform_f64(1.0 / c.vs);
     if (tid < 12) Tsh[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.0 : 0.0) : 0.0;
     if (tid == 64) {  // the guess as a Sophus::SE3d would hold it (rotation through a unit quaternion)
         const Rt g = rt_project(rt_from16(guess_src(c)));
