@@ -974,6 +974,12 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+template <class T> __device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long u = (unsigned long long)(size_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return (T*)(size_t)(((unsigned long long)hi << 32) | lo);
+}
 // a value that is the same in every lane, moved to scalar registers
 __device__ __forceinline__ double uniform_f64(double v) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
@@ -1946,7 +1952,14 @@ __device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, b
     return p;
 }
 template <int PC, int GC>
-__device__ __forceinline__ void gn8_body(const Ctx& c, int mode, const int G_rt, const int wg) {
+__device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_rt, const int wg) {
+    // the base pointers of the loop's arrays in scalar registers (the free-running kernel's accesses are flat_*: left alone, each
+    // base sits in a vector register pair for the whole loop)
+    Ctx c = c_in;
+    c.pc_ans = uniform_ptr(c.pc_ans); c.pc_key = uniform_ptr(c.pc_key); c.pc_pb = uniform_ptr(c.pc_pb);
+    c.tab = uniform_ptr(c.tab); c.blocks = uniform_ptr(c.blocks);
+    c.src0 = uniform_ptr(c.src0); c.src_cur = uniform_ptr(c.src_cur);
+    c.gn_rows_ll = uniform_ptr(c.gn_rows_ll);
     const int G = GC > 0 ? GC : G_rt;
     __shared__ int2 missq[(GN8_MAX_THREADS / 64) * GN8_QWAVE];  // points whose answer row did not settle them: (index, slot of its position in posL or -1)
     __shared__ int qcount[2][GN8_MAX_THREADS / 64];   // per wavefront: entries at the front / at the back of its region
