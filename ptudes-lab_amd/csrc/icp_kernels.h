@@ -2823,6 +2823,13 @@ __device__ __forceinline__ Ctx load_seq_ctx(const SeqCtx* a, int s, int scan_k) 
     const float* p = a[s].scan_base + (size_t)scan_k * (size_t)a[s].scan_stride_floats;
     if (a[s].input_is_range) { c.in_range = (const unsigned*)p; c.in_f32 = nullptr; }
     else { c.in_f32 = p; c.in_range = nullptr; }
+    // the stage bodies' base pointers as explicit scalars (see gn8_body)
+    c.in_f32 = uniform_ptr(c.in_f32); c.in_range = uniform_ptr(c.in_range);
+    c.pts = uniform_ptr(c.pts); c.slot1 = uniform_ptr(c.slot1); c.slot2 = uniform_ptr(c.slot2);
+    c.vtab1 = uniform_ptr(c.vtab1); c.vtab2 = uniform_ptr(c.vtab2); c.bcnt1 = uniform_ptr(c.bcnt1); c.bcnt2 = uniform_ptr(c.bcnt2);
+    c.fd = uniform_ptr(c.fd); c.fdw = uniform_ptr(c.fdw); c.src0 = uniform_ptr(c.src0); c.coltab = uniform_ptr(c.coltab);
+    c.pslot = uniform_ptr(c.pslot); c.nxt = uniform_ptr(c.nxt); c.prank = uniform_ptr(c.prank); c.plen = uniform_ptr(c.plen);
+    c.tab = uniform_ptr(c.tab); c.blocks = uniform_ptr(c.blocks); c.free_stack = uniform_ptr(c.free_stack); c.st = uniform_ptr(c.st);
     return c;
 }
 __global__ __launch_bounds__(1024) void k_scan_prologue(Ctx c) { d_scan_prologue(c); }
