@@ -26,8 +26,9 @@ sys.path.insert(0, ROOT)
 
 GN_EVENT_EVERY = 8
 DEFAULT_SEQS = 192
-PARITY_EXTRA_SEQS = 2     # sequences beside sequence 0 whose trajectories are checked against the oracle (single rank)
+PARITY_EXTRA_SEQS = 8     # sequences beside sequence 0 whose trajectories are checked against the oracle (single rank; all its threads)
 PARITY_EXTRA_SWEEPS = 40  # ... over their first sweeps
+DEFAULT_REPEATS = 3       # timed repeats of the K steps (>= 3, the median is reported)
 GATHER_TIMEOUT_S = 120
 CPU_MIN_SWEEPS = 300  # sweeps offered to the CPU baseline (it stops at its time budget)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -86,10 +87,32 @@ EXEC_COST = {
 }
 
 
-def executed_bytes(cnt, stats, n_raw, G, cols=1024):
+def exec_cost_for_build(info):
+    """EXEC_COST with the terms that follow compile-time constants of the LOADED library taken from ptl_build_info (the
+    table must not silently describe another build): answer-row size, positions kept in LDS, table entry sizes.  Returns the
+    table and a list of what differed from the default build."""
+    c = dict(EXEC_COST)
+    notes = []
+    row = 8 * info["ans_row_doubles"]
+    if row != 144:
+        notes.append(f"answer row {row} B (KCAND {info['kcand']})")
+    c["point_iteration_later"] = 8 + row
+    c["search"] = 128 + 8 + row + 4
+    c["lds_points_per_workgroup"] = info["lds_points"]
+    if info["lds_points"] != 3072:
+        notes.append(f"{info['lds_points']} positions in LDS")
+    c["row_rebuilt"] = 27 * info["tab_entry_bytes"] + 136
+    if (info["seq_u"], info["seq_u2"]) != (8, 16):
+        notes.append(f"SEQ_U {info['seq_u']}/{info['seq_u2']} (stage terms are per point: unchanged)")
+    if info["diagnostics"]:
+        notes.append("diagnostic clocks compiled in (their atomics are not in the model)")
+    return c, notes
+
+
+def executed_bytes(cnt, stats, n_raw, G, cols=1024, cost=None):
     """bytes the free-running kernel requested from memory for the scans in `stats` (ptl_icp_stats rows of the timed scans of
     one sequence), given the delta of its executed-work counters over those scans"""
-    c = EXEC_COST
+    c = cost or EXEC_COST
     pi = cnt["point_iterations"]
     first = sum(s["n_src"] for s in stats if s["iterations"] > 0)
     in_mem = sum(max(s["n_src"] - max(G, 1) * c["lds_points_per_workgroup"], 0) * s["iterations"] for s in stats)  # point-iterations through src_cur
@@ -222,7 +245,21 @@ def launch_ranks(n, argv, worker=None, timeout_s=3600.0, out=None):
     return worst
 
 
-def pmc_traffic_for(workload_key, scans_per_launch=None):
+def code_id():
+    """identity of the kernel sources the loaded library was built from (sha256 over csrc/*.hip, *.h and the Makefile, 12 hex
+    digits): recorded in the line and in every PMC summary, so that a counter pass collected on an older kernel is not taken
+    for this build's traffic without saying so"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ptudes-lab_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def pmc_traffic_for(workload_key, scans_per_launch=None, code=None):
     """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC pass (profiles/) whose recorded workload
     is THIS run's workload, or None: a counter value belongs to the workload it was collected on.  The free-running kernel's
     summaries record bytes per SCAN (a launch carries as many scans as the run asks for: the same workload at another step
@@ -237,10 +274,17 @@ def pmc_traffic_for(workload_key, scans_per_launch=None):
             continue
         if d.get("workload_key") != workload_key:
             continue
+        stale = code is not None and d.get("code_id") != code  # collected on other kernel sources than the loaded build's
         if d.get("traffic_bytes_per_scan") is not None and scans_per_launch:
-            best = (d["traffic_bytes_per_scan"] * scans_per_launch, os.path.basename(f))
+            cand = (d["traffic_bytes_per_scan"] * scans_per_launch, os.path.basename(f), stale)
         elif d.get("traffic_bytes_per_launch") is not None and not scans_per_launch:
-            best = (d["traffic_bytes_per_launch"], os.path.basename(f))
+            cand = (d["traffic_bytes_per_launch"], os.path.basename(f), stale)
+        else:
+            continue
+        if best is None or not stale or best[2]:  # a pass of this very build beats a later file of another build
+            best = cand
+    if best is not None and code is None:
+        return best[:2]
     return best
 
 
@@ -271,6 +315,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=DEFAULT_REPEATS,
+                    help="timed repeats: each one is a cold start, the W warm-up sweeps (untimed) and EXACTLY K timed steps; the line "
+                         "reports the median repeat (SURVEY.md 8(d)) and lists them all")
+    ap.add_argument("--verify-all", action="store_true",
+                    help="after the run: every sequence of the batch once more ALONE (single-sequence runner with a team's workgroup "
+                         "count) and compared bit for bit - minutes for 192 sequences")
     ap.add_argument("--seqs-per-gpu", type=int, default=DEFAULT_SEQS,
                     help="independent sequences per GPU (SURVEY.md 8(e), second level), batched runner.  The sequences s = x (mod 8) "
                          "live on XCD x, whose teams of workgroups take their scans as they come free (--team-wgs).  1 = the "
@@ -429,28 +479,49 @@ def main():
             torch.cuda.synchronize()
         core.device_sync(local_rank)
 
-    # warm-up: cold start + the first W sweeps (untimed)
-    t_warm = time.perf_counter()
-    runner.run(W)
-    print(f"bench.py rank {rank}: warm-up ({W} sweeps of every sequence) {time.perf_counter() - t_warm:.2f} s", file=sys.stderr, flush=True)
-    cnt0 = [runner.exec_counters(j) for j in range(S)] if free else None
     # HIP events around every 8th launch of the dominant kernel: two event records per scan cost ~18 us (4 %) of
     # command-processor time on the critical path
     ev_every = GN_EVENT_EVERY if S == 1 else 1  # (the batched runner times every launch)
-    runner.profile(enable=ev_every, reset=True)
-    barrier(); sync()
-    t0 = time.perf_counter()
-    runner.enqueue(K)
-    runner.wait()
-    sync()
-    dt_own = time.perf_counter() - t0  # this rank's own K steps
-    barrier()
-    dt = time.perf_counter() - t0
-    print(f"bench.py rank {rank}: timed region {dt_own:.3f} s own, {dt:.3f} s to the barrier", file=sys.stderr, flush=True)
+    # R timed repeats (>= 3, median).  Each: cold start + the first W sweeps (untimed, they build the local map),
+    # then EXACTLY K steps between barrier + synchronize on both sides, max over ranks.  The kernel events cover the timed
+    # launches of all repeats (warm-up launches excluded), the byte counters and results are the last repeat's; the runs are
+    # deterministic, so every repeat must reproduce the first one's trajectories bit for bit (checked, reported).
+    R = max(1, args.repeats)
+    rep_dt, rep_dt_own = [], []
+    first_traj, repeats_identical = None, True
+    cnt0 = None
+    for rep in range(R):
+        runner.profile(enable=False, reset=(rep == 0))
+        t_warm = time.perf_counter()
+        runner.run(W)
+        if rep == 0:
+            print(f"bench.py rank {rank}: warm-up ({W} sweeps of every sequence) {time.perf_counter() - t_warm:.2f} s", file=sys.stderr, flush=True)
+        cnt0 = [runner.exec_counters(j) for j in range(S)] if free else None
+        runner.profile(enable=ev_every, reset=False)
+        barrier(); sync()
+        t0 = time.perf_counter()
+        runner.enqueue(K)
+        runner.wait()
+        sync()
+        dt_own = time.perf_counter() - t0  # this rank's own K steps
+        barrier()
+        dt = time.perf_counter() - t0
+        print(f"bench.py rank {rank}: repeat {rep}: timed region {dt_own:.3f} s own, {dt:.3f} s to the barrier", file=sys.stderr, flush=True)
+        if dist is not None:
+            from ptudes_lab_amd import parallel
+            dt = parallel.max_over_ranks(dt, dist, device="cpu", group=ctl)
+        rep_dt.append(dt); rep_dt_own.append(dt_own)
+        if R > 1:
+            probe = [runner.results(j)["kiss_poses"] for j in sorted({0, S // 2, S - 1})]
+            if first_traj is None:
+                first_traj = probe
+            else:
+                repeats_identical = repeats_identical and all(np.array_equal(a, b) for a, b in zip(first_traj, probe))
+    order = sorted(range(R), key=lambda i: rep_dt[i])
+    med = order[(R - 1) // 2]  # the median repeat (the lower one of an even count)
+    dt, dt_own = rep_dt[med], rep_dt_own[med]
     per_rank = [K * S / dt_own]
     if dist is not None:
-        from ptudes_lab_amd import parallel
-        dt = parallel.max_over_ranks(dt, dist, device="cpu", group=ctl)
         box = [None] * world
         dist.all_gather_object(box, K * S / dt_own, group=ctl)
         per_rank = [float(v) for v in box]
@@ -471,12 +542,15 @@ def main():
             iters.append(s["iterations"])
     seq_clk = [runner.seq_clocks(j) for j in range(S)] if free else None
     exec_bytes, exec_gn, exec_stages, cnt_tot = 0.0, 0.0, 0.0, None
+    exec_cost, exec_notes, migr = None, [], None
     if free:  # the as-executed byte model over the timed scans: counters now minus counters after the warm-up
+        exec_cost, exec_notes = exec_cost_for_build(core.build_info())
+        migr = [runner.sched_counters(j) for j in range(S)]
         cnt_tot = {k: 0 for k in core.BatchRunner.EXEC_COUNTERS}
         for j, o in enumerate(outs):
             c1 = runner.exec_counters(j)
             d = {k: c1[k] - cnt0[j][k] for k in c1}
-            tot, gnb, stb = executed_bytes(d, o["stats"][W:], pps, team_g, args.cols)
+            tot, gnb, stb = executed_bytes(d, o["stats"][W:], pps, team_g, args.cols, exec_cost)
             exec_bytes += tot; exec_gn += gnb; exec_stages += stb
             for k in d:
                 cnt_tot[k] += d[k]
@@ -528,7 +602,7 @@ def main():
         ate_r, ate_t = calc_ate(list(est), list(gt_rel[: len(est)]))
         rmse_gt = float(np.sqrt(np.mean(np.sum((est[:, :3, 3] - gt_rel[: len(est), :3, 3]) ** 2, 1))))
         avg_gn_s = (gn_ms / 1e3) / max(gn_n, 1)
-        avg_gn_bytes = gn_bytes / max(gn_n, 1)  # one launch carries the GN loops (free-running: the whole scans) of all S sequences
+        avg_gn_bytes = R * gn_bytes / max(gn_n, 1)  # one launch carries the GN loops (free-running: the whole scans) of all S sequences; gn_bytes: one repeat's
         achieved = avg_gn_bytes / avg_gn_s if avg_gn_s > 0 else 0.0
         if args.equal_work:
             seeds_txt = f"{args.seed_base}..{args.seed_base + S - 1}" + (", a private copy on every rank (equal work per GPU)" if world > 1 else "")
@@ -537,13 +611,14 @@ def main():
         mode_txt = "ICP only, constant-velocity guess" if not with_ekf else \
             f"ICP + IMU-EKF ({'--use-imu-prediction' if use_imu else 'constant-velocity guess'})"
         wkey = workload_key(args, S)
-        launches = max(gn_n, 1)
-        scans_per_launch_mean = (K * S / launches) if free else None
-        pmc = pmc_traffic_for(wkey, scans_per_launch_mean) if world == 1 else None
+        launches = max(gn_n, 1)  # (the timed launches of all R repeats)
+        scans_per_launch_mean = (R * K * S / launches) if free else None
+        cid = code_id()
+        pmc = pmc_traffic_for(wkey, scans_per_launch_mean, cid) if world == 1 else None
         alg_frac = achieved / HBM_PEAK  # SURVEY 8(d)'s brute-force bytes / launch time / peak
         if free:
             # what the kernel itself requested from memory (EXEC_COST x its own counters): the roofline figure of the line
-            avg_exec = exec_bytes / launches
+            avg_exec = R * exec_bytes / launches
             achieved = avg_exec / avg_gn_s if avg_gn_s > 0 else 0.0
         roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
@@ -552,37 +627,48 @@ def main():
                               "algorithmic bytes of SURVEY 8(d) (27 probes x 16 B + every candidate x 12 B + the source, per iteration) / "
                               "launch time / peak; the kernel prunes the search exactly and skips ~3/4 of the candidate bytes"),
                 "algorithmic_frac": alg_frac, "algorithmic_bytes_per_launch": avg_gn_bytes,
-                "executed_bytes_per_launch": (exec_bytes / launches) if free else None,
+                "executed_bytes_per_launch": (R * exec_bytes / launches) if free else None,
+                "executed_model_build": ({"info": core.build_info(), "differs_from_default_build": exec_notes} if free else None),
                 "executed_bytes_per_scan": (exec_bytes / max(n_timed, 1)) if free else None,
                 "executed_split_per_scan": ({"gauss_newton": exec_gn / max(n_timed, 1), "stages": exec_stages / max(n_timed, 1)} if free else None),
                 "executed_counters_per_scan": ({k: v / max(n_timed, 1) for k, v in cnt_tot.items()} if free else None),
                 "traffic": pmc[0] if pmc else None, "traffic_source": pmc[1] if pmc else None,
+                "traffic_stale": (pmc[2] if pmc else None),  # true: the PMC pass was collected on other kernel sources than this build's (config.code_id)
                 "measured_frac": (pmc[0] / avg_gn_s / HBM_PEAK) if (pmc and avg_gn_s > 0) else None,
                 "kernel": ("k_gn_loop8" if args.gn_lanes == 8 else "k_gn_loop") if S == 1 else
                           "kx_seq_run" if free else ("kx_gn_loop" if args.gn_lanes == 32 else "kx_gn_loop8"),
                 "avg_launch_us": 1e6 * avg_gn_s, "launches": gn_n,
                 "scans_per_launch": scans_per_launch_mean,
-                "timed_launches": (f"all {gn_n} persistent launches of the {K} steps (HIP events)" if free else
-                                   f"every {ev_every}th of {K} (HIP events)"),
+                "timed_launches": (f"all {gn_n} persistent launches of the {R} x {K} timed steps (HIP events)" if free else
+                                   f"every {ev_every}th of {R} x {K} (HIP events)"),
                 "note": ("the free-running kernel carries the WHOLE per-scan pipeline of every sequence.  frac = executed bytes / launch time "
                          "/ peak; algorithmic_frac = B_scan of SURVEY 8(d) (brute-force 27-voxel search) the same way - above 1 because the "
                          "answer cache settles most point-iterations without the probes and candidate reads that formula charges; "
                          "traffic = HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE) of a committed pass of this workload, per scan x this run's "
-                         "scans per launch; measured_frac = traffic / launch time / peak" if free else
+                         "scans per launch; measured_frac = traffic / launch time / peak.  FETCH_SIZE counts what the L2s request from the "
+                         "fabric: reads served by the 256 MiB Infinity Cache are in it, so `of the HBM peak` is an upper bound on what HBM itself served" if free else
                          "measured_frac = PMC HBM bytes of the same workload / launch time / peak")}
         line = {
             "metric": f"lidar scans/sec (ICP+EKF) on {args.rows}x{args.cols} sweeps",
             "value": K * S * world / dt, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "repeats": {"n": R, "reported": "median", "ms_per_step": [1e3 * v / K for v in rep_dt],
+                        "values": [K * S * world / v for v in rep_dt], "spread_rel": (max(rep_dt) - min(rep_dt)) / dt,
+                        "bit_identical_trajectories": (repeats_identical if R > 1 else None),
+                        "note": "each repeat = cold start + W untimed warm-up sweeps + exactly K timed steps (barrier + synchronize on both sides)"},
             "config": {"workload": f"synthetic {args.rows}x{args.cols} sweeps, random-walk SE(3) GT, {mode_txt}, "
                                    f"min/max range {args.min_range}/{args.max_range} m, voxel {(args.voxel_size or args.max_range / 100):.2f} m"
                                    + (f" [{args.workload_name}]" if args.workload_name else ""),
-                       "workload_key": wkey,
+                       "workload_key": wkey, "code_id": cid,
                        "sequences_per_gpu": S, "sequence_seeds": seeds_txt,
                        "driver": "single sequence" if S == 1 else
                                  "free-running (one persistent launch, every sequence at its own pace)" if free else "lockstep (one launch per stage)",
                        "team_workgroups": team_g if free else None, "teams": teams if free else None,
+                       "scheduling": (None if migr is None else {
+                           "scans_run_by_a_team_of_another_xcd": sum(m["stolen"] for m in migr),
+                           "cross_xcd_handovers": sum(m["cross_xcd_handovers"] for m in migr),
+                           "note": "last repeat, warm-up included; a sequence whose previous scan ran on another XCD is handed over at agent scope"}),
                        "scans_per_sequence": n_total, "parallelism": f"{world} independent sequence shard(s), no data-path collective"},
             "per_rank_scans_per_s": {"values": per_rank, "min": min(per_rank), "mean": float(np.mean(per_rank)), "max": max(per_rank),
                                      "note": "each rank's own K steps / its own wall time; `value` uses the max-over-ranks clock"},
@@ -628,6 +714,23 @@ def main():
                                                                "sweeps_each": m2, "max_dpos_m": worst}
         else:
             line["cpu_baseline"] = None
+        if world == 1 and S > 1 and free and args.verify_all:
+            # every sequence of the batch once more alone, with a team's workgroup count: bit for bit
+            bad = []
+            for j in range(S):
+                one = core.SeqRunner(n_total, pps, n_imu, max_range=args.max_range, min_range=args.min_range, use_imu_prediction=use_imu,
+                                     with_ekf=with_ekf, device_id=local_rank,
+                                     **dict(icp_over, gn_workgroups=team_g, gn_lanes_per_point=8, gn_threads=args.gn_threads or 512))
+                for k in range(n_total):
+                    one.upload_scan(k, seqs[j].scan(k))
+                one.upload_imu(seqs[j].imu[:n_imu] if with_ekf else np.zeros((0, 7)),
+                               [seqs[j].imu_range_for_scan(k)[1] if with_ekf else 0 for k in range(n_total)])
+                one.run(n_total)
+                o1 = one.results()
+                if not (np.array_equal(o1["kiss_poses"], outs[j]["kiss_poses"]) and o1["stats"] == outs[j]["stats"]):
+                    bad.append(j)
+                one.close()
+            line["verify_all"] = {"sequences": S, "differ_from_their_single_runs": bad}
         if world == 1 and S > 1 and not args.no_single_sequence:
             # SURVEY.md 8(e) wants both figures: k sequences per GPU (`value`) and one.  Sequence 0 alone, same sweeps, through
             # the single-sequence latency pipeline (one sequence over the whole chip, 32-lane kernel), after the timed region.

@@ -311,6 +311,37 @@ int ptl_batch_team_workgroups(ptl_batch *b, int32_t *team_workgroups, int32_t *t
  * settle), [1] probe rows rebuilt (27 hash probes each), [2] stored map points read by the searches, [3] Gauss-Newton
  * iterations, [4] / [5] voxel claims of down-sampling pass 1 / 2, [6] source point-iterations, [7] scans. */
 int ptl_batch_exec_counters(ptl_batch *b, int32_t seq, uint64_t out[8]);
+/* Where the scans of sequence `seq` ran in the free-running kernel, cumulative since the cold start: out[0] scans run by a
+ * team of another XCD than the sequence's home XCD (seq & 7) - a team whose own XCD had nothing for it; out[1] scans that
+ * ran on another XCD than the sequence's previous scan (the cross-XCD hand-overs: the previous scan's data sits in another
+ * L2); out[2] XCC id of the last scan + 1; out[3] reserved. */
+int ptl_batch_sched_counters(ptl_batch *b, int32_t seq, uint64_t out[4]);
+/* Sticky status word of the free-running driver (cleared by ptl_batch_run / ptl_batch_reset): why teams left a launch
+ * other than "all scans done" - 1 a teammate never reached the head-of-launch barrier, 2 ... the job barrier, 4 a team
+ * found no work for its whole idle budget while sequences were pending, 8 a team gave up on a sequence (see that
+ * sequence's error flags), 16 a sequence did not reach the last scan of a launch (it gets the time-out flag).
+ * ptl_batch_wait returns PTL_ERR_CAPACITY for a flagged sequence and PTL_ERR_STATE for a non-zero status without one:
+ * no exit of the persistent kernel is silent. */
+int ptl_batch_status(ptl_batch *b, uint32_t *status);
+/* test hook: workgroup `block` of the free-running grid returns right before the job barrier of its `round`-th job of every
+ * launch from now on (0 = the first); block < 0 switches it off */
+int ptl_batch_debug_stall_block(ptl_batch *b, int32_t block, int32_t round);
+/* Environment: PTL_TEAM_SYNC=agent when the batch is created keeps the agent-scope release (L2 write-back) at every team
+ * barrier of the free-running kernel instead of the XCD-local shortcut (same results; a diagnostic switch).
+ *
+ * Memory: one sequence of a batch holds ~736 B per point of points_per_scan of work buffers (two 8-slots-per-point voxel
+ * tables, probe and answer rows, ...: 96 MB at 128x1024), map_table_capacity x 16 B, map_block_capacity x (block
+ * size + 4) B (512-B blocks at 20 points per voxel: 256 MB at the default 512 k blocks) and its resident sweeps
+ * (n_scans x points_per_scan x 12 B): ~390 MB + sweeps at the defaults.  ptl_batch_create checks the sum against
+ * hipMemGetInfo and fails with PTL_ERR_CAPACITY and the numbers when it does not fit. */
+
+/* Compile-time constants of the loaded build that a caller's byte model depends on (bench.py EXEC_COST): [0] candidates
+ * per answer row, [1] doubles per answer row, [2] source positions a workgroup keeps in LDS, [3] / [4] points per thread
+ * and pass of K1 + map update / K2-K4 in the free-running kernel, [5] threads per workgroup of the 8-lane kernels,
+ * [6] lanes per point of the full search, [7] nearest other boxes in its first round, [8] voxels per survivor round,
+ * [9] chunks phase A requests ahead, [10] 1000 x the pruning margin, [11] / [12] bytes per map-table / voxel-table
+ * entry, [13] 1 when diagnostic clocks are compiled in. */
+int ptl_build_info(int32_t out[16]);
 
 #ifdef __cplusplus
 }

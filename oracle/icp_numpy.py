@@ -48,10 +48,35 @@ def se3_log(T):
 
 
 def as_se3(T):
-    """what a Sophus::SE3d holds of a 4x4: a UNIT quaternion and the translation"""
+    """what a Sophus::SE3d holds of a 4x4: a UNIT quaternion and the translation.  The quaternion comes from Eigen's
+    matrix -> quaternion conversion (positive trace: w = sqrt(1 + tr) / 2 and the antisymmetric part; otherwise the branch of
+    the largest diagonal entry), normalised by Sophus - NOT from an SVD: for a matrix that is not a rotation the two differ
+    at second order (scipy's Rotation.from_matrix would orthogonalise first)."""
+    m = np.asarray(T, float)[:3, :3]
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    q = np.zeros(4)  # x, y, z, w
+    if tr > 0.0:
+        t = np.sqrt(tr + 1.0)
+        q[3] = 0.5 * t
+        t = 0.5 / t
+        q[0], q[1], q[2] = (m[2, 1] - m[1, 2]) * t, (m[0, 2] - m[2, 0]) * t, (m[1, 0] - m[0, 1]) * t
+    else:
+        i = 0
+        if m[1, 1] > m[0, 0]:
+            i = 1
+        if m[2, 2] > m[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0)
+        q[i] = 0.5 * t
+        t = 0.5 / t
+        q[3] = (m[k, j] - m[j, k]) * t
+        q[j] = (m[j, i] + m[i, j]) * t
+        q[k] = (m[k, i] + m[i, k]) * t
+    q /= np.linalg.norm(q)
     out = np.eye(4)
-    out[:3, :3] = Rotation.from_matrix(T[:3, :3]).as_matrix()
-    out[:3, 3] = T[:3, 3]
+    out[:3, :3] = Rotation.from_quat(q).as_matrix()
+    out[:3, 3] = np.asarray(T, float)[:3, 3]
     return out
 
 
@@ -221,9 +246,12 @@ class KissICP:
         if guess is None:
             guess = (self.poses[-1] if self.poses else np.eye(4)) @ self.prediction()
         pose, iters, ncorr, ncand = register(src, self.map, guess, 3.0 * sigma, sigma / 3.0)
-        self.model_deviation = inv(np.asarray(guess, float)) @ pose  # kiss.py:128
+        gain = np.linalg.inv(np.asarray(guess, float)) @ pose       # kiss.py:116, :128 - the RAW guess, a general 4x4 inverse
+        err_dt = float(np.linalg.norm(gain[:3, 3]))                 # kiss.py:118
+        err_drot = float(np.linalg.norm(Rotation.from_matrix(gain[:3, :3]).as_rotvec()))  # kiss.py:119-120
+        self.model_deviation = as_se3(gain)                         # update_model_deviation takes it as a Sophus::SE3d
         self.map.update(fd, pose)
         self.poses.append(pose)
-        self.stats.append(dict(sigma=float(sigma), iterations=iters, n_corr_last=ncorr, n_valid=len(frame), n_down=len(fd), n_src=len(src),
+        self.stats.append(dict(sigma=float(sigma), err_dt=err_dt, err_drot=err_drot, iterations=iters, n_corr_last=ncorr, n_valid=len(frame), n_down=len(fd), n_src=len(src),
                                sum_cand=ncand, map_voxels=len(self.map.vox), map_points=self.map.num_points()))
         return pose

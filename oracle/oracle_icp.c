@@ -670,6 +670,8 @@ int orc_icp_register_frame(orc_icp *h, const double *xyz, const double *t01, int
         else T_identity(last);
         orc_se3_mul(last, pred, guess);
     }
+    double guess_raw[16]; /* :116, :128 invert the guess as the caller handed it over */
+    memcpy(guess_raw, guess, sizeof guess);
     so3_project16(guess); /* the registration works on the SE3d of it (orc_register does the same to its copy) */
     /* :108-114 */
     double new_pose[16];
@@ -678,10 +680,23 @@ int orc_icp_register_frame(orc_icp *h, const double *xyz, const double *t01, int
     orc_register(h->map, h->source, h->n_src, guess, 3.0 * sigma, sigma / 3.0, c->max_iterations,
                  c->convergence, new_pose, &iters, &nc, &cand);
     /* :116-124 innovation; :128 model deviation */
+    /* pose_gain = np.linalg.inv(initial_guess) @ new_pose with the RAW guess (a general 4x4 inverse and product).  dt is the
+     * norm of its translation column; drot = |Rotation.from_matrix(gain[:3,:3]).as_rotvec()| and the model deviation -
+     * a Sophus::SE3d on the C++ side - see its rotation block through a unit quaternion. */
     double gi[16], gain[16];
-    orc_se3_inv(guess, gi);
-    orc_se3_mul(gi, new_pose, gain);
+    m4_inv(guess_raw, gi);
+    m4_mul(gi, new_pose, gain);
     double t[3] = {gain[3], gain[7], gain[11]};
+    double drot;
+    {   /* :119-120 scipy: Rotation.from_matrix orthogonalises (SVD = the polar factor), then the rotation vector's norm */
+        double Rg[9], Qg[9], Tq[16];
+        T_get_R(gain, Rg);
+        m3_polar(Rg, Qg);
+        T_set(Tq, Qg, t);
+        drot = orc_rot_angle(Tq);
+    }
+    so3_project16(gain); /* :128 the model deviation as the Sophus::SE3d the C++ side makes of it (Eigen: matrix -> quaternion, normalised) */
+    gain[3] = t[0]; gain[7] = t[1]; gain[11] = t[2];
     memcpy(h->model_deviation, gain, sizeof gain);
     /* :129 map update with frame_downsample */
     orc_map_update(h->map, h->frame_down, h->n_down, new_pose);
@@ -696,7 +711,7 @@ int orc_icp_register_frame(orc_icp *h, const double *xyz, const double *t01, int
     if (st) {
         st->sigma = sigma;
         st->err_dt = norm3(t);
-        st->err_drot = orc_rot_angle(gain);
+        st->err_drot = drot;
         st->iterations = iters;
         st->n_corr_last = nc;
         st->n_in = n;

@@ -132,4 +132,63 @@ static inline void so3_log(const double R[9], double v[3]) {
     quat_to_rotvec(q, v);
 }
 
+/* np.linalg.inv of a general 4x4 and a plain 4x4 product: the reference forms the innovation as
+ * np.linalg.inv(initial_guess) @ new_pose on the caller's RAW guess (kiss.py:116, :128), whatever its
+ * rotation block and last row look like.  Gauss-Jordan with partial pivoting (first largest pivot);
+ * returns 0 for a singular matrix (the identity is written then). */
+static inline int m4_inv(const double A[16], double out[16]) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = A[4 * i + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r)
+            if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+        if (a[piv][col] == 0.0) {
+            for (int i = 0; i < 16; ++i) out[i] = (i % 5 == 0) ? 1.0 : 0.0;
+            return 0;
+        }
+        if (piv != col)
+            for (int j = 0; j < 8; ++j) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
+        const double p = a[col][col];
+        for (int j = 0; j < 8; ++j) a[col][j] = a[col][j] / p;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            for (int j = 0; j < 8; ++j) a[r][j] = a[r][j] - f * a[col][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = a[i][4 + j];
+    return 1;
+}
+/* nearest rotation to a 3x3 with positive determinant - the orthogonal polar factor U V^T, which is what scipy's
+ * Rotation.from_matrix makes of a matrix that is not orthogonal (SVD) before kiss.py:119 takes its rotation vector.  Newton's
+ * iteration X <- (X + X^-T) / 2 (Higham), X^-T = cof(X) / det(X); eight steps (quadratic convergence: exact to rounding from
+ * anything within a few per cent of a rotation; an exact rotation is a fixed point). */
+static inline void m3_polar(const double A[9], double Q[9]) {
+    double X[9];
+    memcpy(X, A, sizeof X);
+    for (int it = 0; it < 8; ++it) {
+        double C[9];
+        C[0] = X[4] * X[8] - X[5] * X[7]; C[1] = X[5] * X[6] - X[3] * X[8]; C[2] = X[3] * X[7] - X[4] * X[6];
+        C[3] = X[2] * X[7] - X[1] * X[8]; C[4] = X[0] * X[8] - X[2] * X[6]; C[5] = X[1] * X[6] - X[0] * X[7];
+        C[6] = X[1] * X[5] - X[2] * X[4]; C[7] = X[2] * X[3] - X[0] * X[5]; C[8] = X[0] * X[4] - X[1] * X[3];
+        const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+        if (!(det > 0.0)) break;
+        for (int i = 0; i < 9; ++i) X[i] = 0.5 * (X[i] + C[i] / det);
+    }
+    memcpy(Q, X, sizeof X);
+}
+static inline void m4_mul(const double A[16], const double B[16], double C[16]) {
+    double r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j];
+            r[4 * i + j] = s;
+        }
+    memcpy(C, r, sizeof r);
+}
+
 #endif

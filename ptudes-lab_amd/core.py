@@ -406,6 +406,21 @@ class BatchRunner:
         L.check(L.lib().ptl_batch_exec_counters(self._h, s, out))
         return dict(zip(self.EXEC_COUNTERS, (int(v) for v in out)))
 
+    def sched_counters(self, s):
+        """where the scans of sequence s ran: scans taken by a team of another XCD, cross-XCD hand-overs, last XCC id + 1"""
+        out = (C.c_uint64 * 4)()
+        L.check(L.lib().ptl_batch_sched_counters(self._h, s, out))
+        return dict(stolen=int(out[0]), cross_xcd_handovers=int(out[1]), last_xcc=int(out[2]) - 1)
+
+    def status(self):
+        """sticky status word of the free-running driver (include/ptudes_mi.h ptl_batch_status)"""
+        v = C.c_uint32()
+        L.check(L.lib().ptl_batch_status(self._h, C.byref(v)))
+        return v.value
+
+    def debug_stall_block(self, block, round=0):
+        L.check(L.lib().ptl_batch_debug_stall_block(self._h, int(block), int(round)))
+
     def close(self):
         if getattr(self, "_h", None):
             L.lib().ptl_batch_destroy(self._h)
@@ -472,3 +487,15 @@ class BatchRunner:
         ms, n = C.c_double(), C.c_int64()
         L.check(L.lib().ptl_batch_profile(self._h, int(enable), C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
+
+
+BUILD_INFO = ("kcand", "ans_row_doubles", "lds_points", "seq_u", "seq_u2", "gn8_threads", "lanes_per_point", "spec", "surv",
+              "prefetch", "keep_x1000", "tab_entry_bytes", "vds_entry_bytes", "diagnostics")
+
+
+def build_info():
+    """compile-time constants of the loaded library (include/ptudes_mi.h ptl_build_info)"""
+    out = (C.c_int32 * 16)()
+    L.check(L.lib().ptl_build_info(out))
+    return dict(zip(BUILD_INFO, (int(v) for v in out)))
+

@@ -68,6 +68,89 @@ PTL_HD Rt rt_inv(const Rt& a) {
     return c;
 }
 
+// np.linalg.inv of a general 4x4 (row-major) and a plain 4x4 product: the reference forms the innovation of a registration as
+// np.linalg.inv(initial_guess) @ new_pose on the caller's RAW guess (kiss.py:116, :128).  Gauss-Jordan with partial pivoting
+// (the first largest pivot); every index is a compile-time constant after unrolling, rows are exchanged by selects - nothing
+// here may end up in scratch memory (it is inlined into the tail of the Gauss-Newton kernels).  A singular matrix gives the
+// identity and false.
+PTL_HD bool mat4_inv(const double* A, double* out) {
+    double a[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[i][j] = A[4 * i + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    bool ok = true;
+#pragma unroll
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        double pv = fabs(a[col][col]);
+#pragma unroll
+        for (int r = col + 1; r < 4; ++r) {
+            const double v = fabs(a[r][col]);
+            if (v > pv) { pv = v; piv = r; }
+        }
+        if (pv == 0.0) ok = false;
+#pragma unroll
+        for (int r = col + 1; r < 4; ++r) {
+            const bool sw = piv == r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double x = a[col][j], y = a[r][j];
+                a[col][j] = sw ? y : x;
+                a[r][j] = sw ? x : y;
+            }
+        }
+        const double p = a[col][col];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[col][j] = a[col][j] / p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = a[r][col];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[r][j] = a[r][j] - f * a[col][j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = ok ? a[i][4 + j] : ((i == j) ? 1.0 : 0.0);
+    return ok;
+}
+// nearest rotation to a 3x3 with positive determinant: the orthogonal polar factor U V^T - what scipy's Rotation.from_matrix makes of a
+// matrix that is not orthogonal before kiss.py:119 takes its rotation vector.  Newton's iteration X <- (X + X^-T) / 2, eight steps.
+PTL_HD void mat3_polar(const double* A, double* Q) {
+    double X[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) X[i] = A[i];
+    for (int it = 0; it < 8; ++it) {
+        double C[9];
+        C[0] = X[4] * X[8] - X[5] * X[7]; C[1] = X[5] * X[6] - X[3] * X[8]; C[2] = X[3] * X[7] - X[4] * X[6];
+        C[3] = X[2] * X[7] - X[1] * X[8]; C[4] = X[0] * X[8] - X[2] * X[6]; C[5] = X[1] * X[6] - X[0] * X[7];
+        C[6] = X[1] * X[5] - X[2] * X[4]; C[7] = X[2] * X[3] - X[0] * X[5]; C[8] = X[0] * X[4] - X[1] * X[3];
+        const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+        if (!(det > 0.0)) break;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) X[i] = 0.5 * (X[i] + C[i] / det);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Q[i] = X[i];
+}
+PTL_HD void mat4_mul(const double* A, const double* B, double* C) {
+    double r[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j];
+            r[4 * i + j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) C[i] = r[i];
+}
+
 PTL_HD void skew(const double w[3], double K[9]) {
     K[0] = 0.0;   K[1] = -w[2]; K[2] = w[1];
     K[3] = w[2];  K[4] = 0.0;   K[5] = -w[0];

@@ -96,6 +96,9 @@ struct DevState {
     //   [2] stored map points read by those searches   [3] Gauss-Newton iterations   [4] voxel claims of VDS pass 1 (run heads)   [5] of pass 2
     //   [6] source point-iterations (phase A evaluations)   [7] scans
     unsigned long long exec_cnt[8];
+    // free-running kernel, cumulative since the cold start (ptl_batch_sched_counters): [0] scans run by a team of another XCD than the
+    // sequence's home XCD, [1] scans that ran on another XCD than the scan before (cross-XCD hand-overs), [2] XCC id of the last scan + 1
+    unsigned long long sched_cnt[4];
 };
 
 struct Ctx {
@@ -1066,12 +1069,32 @@ __device__ __forceinline__ PointWalk point_walk(int n, int G, int wg, int NG, in
 // row.  full != 0 => a real scan (trajectory + stats row, closes with finish_pending); 0 => ptl_icp_align.
 __device__ __forceinline__ const double* guess_src(const Ctx& c) { return c.ext_guess ? c.ext_guess : c.st->guess; }
 __device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_empty, int full) {
-    const Rt guess = rt_project(rt_from16(guess_src(c)));  // Sophus::SE3d initial_guess(T_guess): as the kernel registered it
+    double graw[16];  // the guess as the caller handed it over: kiss.py:116, :128 invert THAT
+    {
+        const double* g16 = guess_src(c);
+        for (int i = 0; i < 16; ++i) graw[i] = g16[i];
+    }
+    const Rt guess = rt_project(rt_from16(graw));  // Sophus::SE3d initial_guess(T_guess): as the kernel registered it
     rt_to16(guess, st->guess);
     const Rt np = map_empty ? guess : rt_project(rt_mul(rt_from16(st->T_icp), guess));  // (T_icp * initial_guess).matrix()
     rt_to16(np, st->new_pose);
     if (!full) return;
-    Rt gain = rt_mul(rt_inv(guess), np);  // kiss.py:116, :128
+    // pose_gain = np.linalg.inv(initial_guess) @ new_pose (kiss.py:116, :128): a general 4x4 inverse of the raw guess and a 4x4
+    // product.  err_dt is the norm of its translation column; err_drot (scipy's Rotation.from_matrix) and the model deviation
+    // (a Sophus::SE3d on the C++ side) see its rotation block through a unit quaternion.
+    Rt gain;
+    double drot;
+    {
+        double gi[16], np16[16], g16[16];
+        mat4_inv(graw, gi);
+        rt_to16(np, np16);
+        mat4_mul(gi, np16, g16);
+        gain = rt_from16(g16);
+        double Qg[9];
+        mat3_polar(gain.R, Qg);   // kiss.py:119-120: scipy orthogonalises (the polar factor), then the rotation vector's norm
+        drot = rot_angle(Qg);
+        gain = rt_project(gain);  // kiss.py:128: the Sophus::SE3d of it (matrix -> quaternion, normalised)
+    }
     rt_to16(gain, st->model_dev);
     const int k = st->n_poses;
     if (k < c.traj_cap) {
@@ -1079,7 +1102,7 @@ __device__ __forceinline__ void gn_post(const Ctx& c, DevState* st, bool map_emp
         ScanStats s;
         s.sigma = st->sigma;
         s.err_dt = sqrt(gain.t[0] * gain.t[0] + gain.t[1] * gain.t[1] + gain.t[2] * gain.t[2]);
-        s.err_drot = rot_angle(gain.R);
+        s.err_drot = drot;
         s.iterations = st->gn_iters; s.n_corr_last = st->gn_ncorr;
         s.n_in = st->n_in; s.n_valid = st->n_valid; s.n_down = st->n_down; s.n_src = st->n_src;
         s.sum_cand = st->gn_cand; s.map_voxels = 0; s.map_points = 0;  // filled by finish_pending

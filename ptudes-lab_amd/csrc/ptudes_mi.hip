@@ -268,6 +268,18 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     *out = h;
     return PTL_OK;
 }
+// device bytes one registration handle allocates (icp_create_impl above, term by term): per point of max_points_per_scan the work
+// buffers (deskewed points, slots, two 8-slots-per-point voxel tables, frame_down x 2, source x 2, world frame_down, list links,
+// probe rows, answer rows, the per-call input), plus the map table, the block pool and its free stack
+static size_t icp_footprint_bytes(const ptl_icp_cfg* cfg) {
+    const size_t n = (size_t)cfg->max_points_per_scan;
+    size_t vcap = 1024;
+    while (vcap < 8 * n) vcap <<= 1;
+    const size_t bstride = ((size_t)cfg->max_points_per_voxel * 24 + 16 + 127) / 128 * 128;
+    const size_t per_point = 24 + 4 + 4 + 24 * 2 + 24 + 24 + 24 + 4 * 4 + 8 + 128 + GN8_ANS_ROW * 8 + 24 + 8;
+    return n * per_point + 2 * vcap * sizeof(VdsEnt) + (size_t)cfg->map_table_capacity * sizeof(TabEnt) +
+           (size_t)cfg->map_block_capacity * (bstride + 4) + (size_t)4096 * (128 + sizeof(ScanStats)) + (1u << 20);
+}
 extern "C" int ptl_icp_create(const ptl_icp_cfg* cfg, ptl_icp** out) { return icp_create_impl(cfg, nullptr, out); }
 extern "C" int ptl_icp_destroy(ptl_icp* h) { return icp_free(h); }
 
@@ -1305,6 +1317,9 @@ struct ptl_batch {
     int* d_imu_end[GN_MAX_SEQ];
     unsigned* d_bar;            // [SEQ_MAX_TEAMS][64] barrier counters and job words of the free-running kernel's teams
     SeqSched* d_sched;          // [8] its per-XCD scan schedulers
+    unsigned* d_status;         // one sticky word: why teams of the free-running kernel left a launch early (SEQ_EXIT_*), cleared by a reset
+    int force_agent;            // PTL_TEAM_SYNC=agent in the environment when the batch was created: no XCD-local barrier shortcut
+    int dbg_dead_block, dbg_dead_round;  // test hook: ptl_batch_debug_stall_block
     bool free_running;
     int team_wgs;               // workgroups per team of the free-running kernel (0 = by the number of sequences, batch_gseq)
     bool seq_run_checked;
@@ -1378,6 +1393,7 @@ extern "C" int ptl_batch_destroy(ptl_batch* b) {
     if (b->d_ctx) (void)hipFree(b->d_ctx);
     if (b->d_bar) (void)hipFree(b->d_bar);
     if (b->d_sched) (void)hipFree(b->d_sched);
+    if (b->d_status) (void)hipFree(b->d_status);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->ev_gn) (void)hipEventDestroy(b->ev_gn);
     if (b->ev_side) (void)hipEventDestroy(b->ev_side);
@@ -1393,10 +1409,27 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     if ((cfg->icp.gn_workgroups & 31) || cfg->icp.gn_workgroups > 512) return set_err(PTL_ERR_ARG, "batched runs need gn_workgroups = a multiple of 32 (8 XCDs x up to 4 sequences each), at most 512");
     if (ptl_device_count() <= cfg->icp.device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->icp.device_id);
     HIPCHK(hipSetDevice(cfg->icp.device_id));
+    {   // the whole batch has to fit the device: say so here, with numbers, instead of failing part-way through the allocations
+        ptl_icp_cfg ic0 = cfg->icp;
+        if (ic0.max_points_per_scan < cfg->points_per_scan) ic0.max_points_per_scan = cfg->points_per_scan;
+        const size_t per_seq = icp_footprint_bytes(&ic0) + (size_t)cfg->n_scans * (size_t)cfg->points_per_scan * 12 +
+                               (size_t)(cfg->n_imu > 0 ? cfg->n_imu : 1) * 56 + (size_t)cfg->n_scans * (128 + 8 + 64 + 4) + (64u << 10);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && per_seq * (size_t)n_sequences > free_b)
+            return set_err(PTL_ERR_CAPACITY, "batch of %d sequences needs %.1f GB of device memory (%.0f MB per sequence: %.0f MB of work buffers, map table "
+                           "and block pool, %.0f MB of sweeps), %.1f GB are free of %.1f GB: fewer sequences, fewer resident sweeps or a smaller map_block_capacity",
+                           n_sequences, per_seq * (double)n_sequences / 1e9, per_seq / 1e6, icp_footprint_bytes(&ic0) / 1e6,
+                           (double)cfg->n_scans * cfg->points_per_scan * 12 / 1e6, free_b / 1e9, total_b / 1e9);
+    }
     ptl_batch* b = new ptl_batch();
     b->cfg = *cfg;
     b->S = n_sequences;
-    b->stream = nullptr; b->d_ctx = nullptr; b->lut = nullptr; b->is_range = 0; b->d_bar = nullptr; b->d_sched = nullptr;
+    b->stream = nullptr; b->d_ctx = nullptr; b->lut = nullptr; b->is_range = 0; b->d_bar = nullptr; b->d_sched = nullptr; b->d_status = nullptr;
+    b->dbg_dead_block = -1; b->dbg_dead_round = -1;
+    {   // PTL_TEAM_SYNC=agent: the teams of the free-running kernel keep the agent-scope release at every barrier (seq_kernel.h team_sync)
+        const char* e = getenv("PTL_TEAM_SYNC");
+        b->force_agent = (e && strcmp(e, "agent") == 0) ? 1 : 0;
+    }
     b->free_running = cfg->icp.gn_lanes_per_point == 8;
     b->team_wgs = 0; b->seq_run_checked = false;
     b->scans_per_launch = 256;
@@ -1429,7 +1462,8 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
         if (rc == PTL_OK && hipMemset(b->d_imu_end[s], 0, (size_t)cfg->n_scans * sizeof(int)) != hipSuccess) rc = set_err(PTL_ERR_HIP, "memset failed");
         b->imu_end[s].assign((size_t)cfg->n_scans, 0);
     }
-    if (rc == PTL_OK && (dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess || dalloc(&b->d_bar, (size_t)SEQ_MAX_TEAMS * 64) != hipSuccess || dalloc(&b->d_sched, (size_t)8) != hipSuccess))
+    if (rc == PTL_OK && (dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess || dalloc(&b->d_bar, (size_t)SEQ_MAX_TEAMS * 64) != hipSuccess || dalloc(&b->d_sched, (size_t)8) != hipSuccess ||
+                         dalloc(&b->d_status, (size_t)16) != hipSuccess || hipMemset(b->d_status, 0, 16 * sizeof(unsigned)) != hipSuccess))
         rc = set_err(PTL_ERR_HIP, "batch allocation failed");
     // (the free-running driver's own limits - co-residency of the persistent grid, team size - are checked when that driver is
     // chosen or first used: a batch that is switched to lockstep right after creation must not be refused on them)
@@ -1513,6 +1547,7 @@ static int batch_reset(ptl_batch* b) {
     }
     b->next_scan = 0;
     b->n_out = 0;
+    HIPCHK(hipMemsetAsync(b->d_status, 0, sizeof(unsigned), b->stream));
     HIPCHK(hipStreamSynchronize(b->side));
     HIPCHK(hipStreamSynchronize(b->stream));
     b->ev_side_valid = false;
@@ -1557,12 +1592,15 @@ static int batch_enqueue_free(ptl_batch* b, int64_t n) {
         r.S = S; r.k0 = (int)k0; r.k1 = (int)k1; r.with_ekf = with_ekf ? 1 : 0; r.rebuild_every = ic.rebuild_every;
         const int gseq = batch_gseq(b);
         r.G = gseq;
+        r.force_agent = b->force_agent; r.dbg_dead_block = b->dbg_dead_block; r.dbg_dead_round = b->dbg_dead_round;
         const bool p20 = ic.max_points_per_voxel == 20;
-#define KXR(GC) do { if (p20) kx_seq_run<20, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r, b->d_sched, b->d_bar); \
-                     else kx_seq_run<0, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r, b->d_sched, b->d_bar); } while (0)
+#define KXR(GC) do { if (p20) kx_seq_run<20, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r, b->d_sched, b->d_bar, b->d_status); \
+                     else kx_seq_run<0, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r, b->d_sched, b->d_bar, b->d_status); } while (0)
         GC_DISPATCH(gseq, KXR);
 #undef KXR
         if (b->prof) HIPCHK(hipEventRecord(e1, st));
+        // did every sequence reach scan k1?  (a team may have left the launch while holding one: no exit is silent)
+        k_sched_check<<<1, 8 * SEQ_SLOTS, 0, st>>>(b->d_ctx, b->d_sched, S, (int)k1, b->d_status);
         for (int s = 0; s < S; ++s) {
             if (with_ekf) b->imu_pos[s] = (k1 < b->cfg.n_scans) ? b->imu_end[s][(size_t)k1] : b->imu_end[s][(size_t)k1 - 1];
             b->icp[s]->scans_done += (k1 - k0);
@@ -1711,11 +1749,13 @@ extern "C" int ptl_batch_wait(ptl_batch* b) {
     if (!b) return set_err(PTL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
     int flags[GN_MAX_SEQ] = {0};
+    unsigned status = 0u;
     HIPCHK(hipStreamSynchronize(b->side));
     for (int s = 0; s < b->S; ++s) {
         k_finish_scan<<<1, 64, 0, b->stream>>>(b->icp[s]->c);
         HIPCHK(hipMemcpyAsync(&flags[s], &b->icp[s]->c.st->err_flags, sizeof(int), hipMemcpyDeviceToHost, b->stream));
     }
+    HIPCHK(hipMemcpyAsync(&status, b->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     for (size_t i = 0; i + 1 < b->ev_used; i += 2) {
         float ms = 0;
@@ -1723,7 +1763,48 @@ extern "C" int ptl_batch_wait(ptl_batch* b) {
     }
     b->ev_used = 0;
     for (int s = 0; s < b->S; ++s)
-        if (flags[s]) return set_err(PTL_ERR_CAPACITY, "sequence %d: device capacity/error flags 0x%x (1 key range, 2 block pool, 4 map table, 8 vds table, 16 gn barrier timeout)", s, flags[s]);
+        if (flags[s]) return set_err(PTL_ERR_CAPACITY, "sequence %d: device capacity/error flags 0x%x (1 key range, 2 block pool, 4 map table, 8 vds table, 16 gn barrier timeout); batch status 0x%x", s, flags[s], status);
+    // no sequence carries an error, but a team of the free-running kernel left a launch early (a workgroup that never reached a
+    // barrier; teams that never got work): the scans are complete, the launch was not healthy - said, not swallowed
+    if (status) return set_err(PTL_ERR_STATE, "free-running launch: teams left early, status 0x%x (1 head-of-launch barrier, 2 job barrier, 4 idle, 8 gave up on a sequence, 16 scans incomplete)", status);
+    return PTL_OK;
+}
+extern "C" int ptl_batch_status(ptl_batch* b, uint32_t* status) {
+    if (!b || !status) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(status, b->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PTL_OK;
+}
+// test hook: workgroup `block` of the free-running grid returns right before the job barrier of its `round`-th job (0 = the first
+// of every launch from now on); block < 0 = none
+extern "C" int ptl_batch_debug_stall_block(ptl_batch* b, int32_t block, int32_t round) {
+    if (!b) return set_err(PTL_ERR_ARG, "null argument");
+    b->dbg_dead_block = block; b->dbg_dead_round = block < 0 ? -1 : round;
+    return PTL_OK;
+}
+// where the scans of sequence s ran (free-running kernel), cumulative since the cold start: out[0] scans run by a team of another XCD than
+// the sequence's home XCD (s & 7), out[1] scans that ran on another XCD than the sequence's previous scan, out[2] XCC id of the last scan + 1
+extern "C" int ptl_batch_sched_counters(ptl_batch* b, int32_t s, uint64_t out[4]) {
+    if (!b || !out || s < 0 || s >= b->S) return set_err(PTL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    HIPCHK(hipStreamSynchronize(b->side));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(out, (char*)b->icp[s]->c.st + offsetof(DevState, sched_cnt), 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return PTL_OK;
+}
+// compile-time constants of this build that callers' byte models depend on (bench.py EXEC_COST):
+//   [0] GN8_KCAND  [1] doubles per answer row  [2] GN8_LDS_PTS  [3] SEQ_U  [4] SEQ_U2  [5] GN8_MAX_THREADS  [6] GN8_LPB  [7] GN8_SPEC
+//   [8] GN8_SURV  [9] GN8_PREFETCH  [10] 1000 x GN8_KEEP  [11] bytes per map table entry  [12] bytes per VDS entry  [13] diagnostics compiled in
+extern "C" int ptl_build_info(int32_t out[16]) {
+    if (!out) return set_err(PTL_ERR_ARG, "null argument");
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    out[0] = GN8_KCAND; out[1] = GN8_ANS_ROW; out[2] = GN8_LDS_PTS; out[3] = SEQ_U; out[4] = SEQ_U2; out[5] = GN8_MAX_THREADS;
+    out[6] = GN8_LPB; out[7] = GN8_SPEC; out[8] = GN8_SURV; out[9] = GN8_PREFETCH; out[10] = (int32_t)(1000.0 * GN8_KEEP + 0.5);
+    out[11] = (int32_t)sizeof(TabEnt); out[12] = (int32_t)sizeof(VdsEnt);
+#if defined(GN_PHASE_CLOCKS) || defined(SEQ_STAGE_CLOCKS) || defined(GN_IT0_CLOCK)
+    out[13] = 1;
+#endif
     return PTL_OK;
 }
 extern "C" int ptl_batch_run(ptl_batch* b, int64_t n) {

@@ -246,7 +246,19 @@ __device__ __noinline__ void sq_filter(const SeqCtx* a, int s, int k) {
     }
 }
 
-struct SeqRun { int S, k0, k1, with_ekf, rebuild_every, G; };  // G: workgroups per team (run-time value; the GC instances fix it at compile time)
+struct SeqRun {
+    int S, k0, k1, with_ekf, rebuild_every, G;  // G: workgroups per team (run-time value; the GC instances fix it at compile time)
+    int force_agent;     // PTL_TEAM_SYNC=agent: every team barrier keeps the agent-scope release (no XCD-local shortcut)
+    int dbg_dead_block;  // test hook (ptl_batch_debug_stall_block): this workgroup of the grid leaves right before the job barrier of its
+    int dbg_dead_round;  // dbg_dead_round-th job (0 = the first); -1 = none
+};
+// Why a team left the launch other than "all scans done".  Sticky bits in one word of device memory per batch (never cleared by a
+// launch; ptl_batch_wait reports them): no exit of the free-running kernel is silent.
+#define SEQ_EXIT_XCC_BARRIER 1u   /* a teammate never reached the head-of-launch barrier */
+#define SEQ_EXIT_JOB_BARRIER 2u   /* a teammate never reached the job barrier */
+#define SEQ_EXIT_IDLE 4u          /* TEAM_IDLE_ROUNDS rounds without work while sequences were still pending */
+#define SEQ_EXIT_SEQUENCE 8u      /* a team gave up on a sequence (its err_flags say why) */
+#define SEQ_EXIT_INCOMPLETE 16u   /* k_sched_check: a sequence did not reach the last scan of the launch */
 
 // scheduler state of one XCD's sequences (slot q <-> sequence x + 8 q): the next scan of each and whether a team is on it
 #define SEQ_SLOTS 32
@@ -256,6 +268,18 @@ __global__ void k_sched_init(SeqSched* sc, int S, int k0, int k1) {
     if (x >= 8) return;
     sc[x].next_scan[q] = (x + 8 * q < S) ? k0 : k1;
     sc[x].busy[q] = 0;
+}
+// After every launch of kx_seq_run: did every sequence get to scan k1?  A slot that did not (its team left while holding it,
+// or nobody was left to run it) gets ERR_GN_TIMEOUT on its sequence and SEQ_EXIT_INCOMPLETE on the batch: the host must not
+// report scans that never ran as done.  (A sequence taken off the schedule by sched_abandon stands at k1 and carries its
+// own error flag already.)
+__global__ void k_sched_check(const SeqCtx* a, const SeqSched* sc, int S, int k1, unsigned* status) {
+    const int x = threadIdx.x / SEQ_SLOTS, q = threadIdx.x % SEQ_SLOTS;
+    if (x >= 8 || x + 8 * q >= S) return;
+    if (sc[x].next_scan[q] < k1 || sc[x].busy[q] != 0) {
+        atomicOr(&a[x + 8 * q].c.st->err_flags, ERR_GN_TIMEOUT);
+        atomicOr(status, SEQ_EXIT_INCOMPLETE);
+    }
 }
 // The team leader's choice: the sequence of this XCD with the fewest scans done that nobody is working on.  Returns its slot,
 // SCHED_DONE when every sequence of the XCD has reached k1, SCHED_RETRY when all that is left is in other teams' hands right
@@ -311,7 +335,7 @@ template <int PC, int GC>
 #else
 #define SEQ_OCC
 #endif
-__global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_seq_run(const SeqCtx* a, SeqRun r, SeqSched* sched, unsigned* bar) {
+__global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_seq_run(const SeqCtx* a, SeqRun r, SeqSched* sched, unsigned* bar, unsigned* status) {
     const int x = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3), J = (int)(gridDim.x >> 3);
     const int G = GC > 0 ? GC : r.G;
     const int t = j / G, wg = j % G;
@@ -334,12 +358,21 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_seq_run(const SeqC
     bool local = solo;
     if (!solo) {
         if (threadIdx.x == 0) __hip_atomic_fetch_or(&tb[42], 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!team_sync(tb, (unsigned)G, t_all, team_abort, nullptr, false)) return;
+        if (!team_sync(tb, (unsigned)G, t_all, team_abort, nullptr, false)) {
+            if (threadIdx.x == 0) atomicOr(status, SEQ_EXIT_XCC_BARRIER);
+            return;
+        }
         const unsigned m = __hip_atomic_load(&tb[42], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        local = (m & (m - 1u)) == 0u;
+        // One bit = every workgroup of the team reported the same XCC_ID.  Hardware assumptions behind the shortcut (gfx950): the
+        // workgroups of one XCD share ONE L2, a store that has been counted out of vmcnt is visible to every later load that
+        // goes to that L2, and a workgroup stays on the XCD it was dispatched to for the whole launch.  PTL_TEAM_SYNC=agent
+        // (SeqRun::force_agent) keeps the agent-scope protocol regardless; tests compare the two bit for bit.
+        local = !r.force_agent && (m & (m - 1u)) == 0u;
     }
     int q_mine = -1, k_mine = 0, x_mine = x;  // the leader's job: slot, scan, and the XCD whose scheduler holds the sequence
     unsigned idle = 0u;
+    int round = 0;
+    const unsigned my_xcc = xcc_id();
     for (;;) {
         if (lead) {  // hand the finished scan back, take the next job
             if (q_mine >= 0) sched_release(sched + x_mine, q_mine, k_mine + 1);
@@ -364,11 +397,28 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_seq_run(const SeqC
             __hip_atomic_store(&tb[41], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < 5; ++i) __hip_atomic_store(&tb[44 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the map update's block counters
         }
-        // the job barrier: nobody is on a sequence here, so an expiry (a teammate that never came) is the team's own affair
-        if (!team_sync(tb, (unsigned)G, t_all, team_abort, nullptr, local)) return;
+        if ((int)blockIdx.x == r.dbg_dead_block && round == r.dbg_dead_round) return;  // test hook: a workgroup that dies between two scans
+        ++round;
+        // the job barrier.  An expiry (a teammate that never came) ends the team - visibly: the batch's status word says so, and
+        // the sequence the leader has just taken (busy, scans left) gets ERR_GN_TIMEOUT and goes off the schedule, so that the
+        // other teams neither wait for it nor find it stuck (this exit used to be silent)
+        if (!team_sync(tb, (unsigned)G, t_all, team_abort, nullptr, local)) {
+            if (threadIdx.x == 0) atomicOr(status, SEQ_EXIT_JOB_BARRIER);
+            if (lead && q_mine >= 0) {
+                gn_raise_abort(a[x_mine + 8 * q_mine].c.st);
+                sched_abandon(sched + x_mine, q_mine, r.k1);
+            }
+            return;
+        }
         const unsigned job = __hip_atomic_load(&tb[40], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (job == JOB_DONE) return;
-        if (job == JOB_RETRY) { if (++idle > TEAM_IDLE_ROUNDS) return; continue; }
+        if (job == JOB_RETRY) {
+            if (++idle > TEAM_IDLE_ROUNDS) {  // sequences are pending in other teams' hands and never come back
+                if (threadIdx.x == 0) atomicOr(status, SEQ_EXIT_IDLE);
+                return;
+            }
+            continue;
+        }
         idle = 0u;
         const int s = (int)job, k = (int)__hip_atomic_load(&tb[41], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int q = s >> 3;
@@ -376,7 +426,15 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_seq_run(const SeqC
         DevState* st = my->c.st;
         const TeamEnv te = {tb, &st->gn_abort, st, local};
         // (every exit below takes the sequence off the schedule first: the other teams must not wait for scans nobody will run)
-#define SEQ_LEAVE do { if (threadIdx.x == 0) sched_abandon(sched + (s & 7), q, r.k1); return; } while (0)
+#define SEQ_LEAVE do { if (threadIdx.x == 0) { sched_abandon(sched + (s & 7), q, r.k1); atomicOr(status, SEQ_EXIT_SEQUENCE); } return; } while (0)
+        if (lead) {
+            // where the sequence's scans run: [0] scans taken by a team of another XCD than the sequence's home, [1] scans that run
+            // on another XCD than the sequence's previous scan did (what the agent-scope hand-over of sched_release / sched_pick
+            // has to get right: the previous scan's data sits in another L2), [2] the XCC this scan runs on + 1
+            if ((s & 7) != x) st->sched_cnt[0] += 1ull;
+            if (st->sched_cnt[2] != 0ull && st->sched_cnt[2] != (unsigned long long)my_xcc + 1ull) st->sched_cnt[1] += 1ull;
+            st->sched_cnt[2] = (unsigned long long)my_xcc + 1ull;
+        }
         const long long c0 = (long long)wall_clock64();
         t_all = sq_prepare(a, s, k, wg, G, t_all, tb, local);  // (all G workgroups: the filter workgroup has nothing else to do here)
         if (t_all == SEQ_FAIL) SEQ_LEAVE;

@@ -50,6 +50,27 @@ def test_roofline_traffic_only_from_a_pmc_pass_of_the_same_workload(tmp_path, mo
     assert b.pmc_traffic_for(lock16) == (1.0e9, "r09_x_pmc_hbm_traffic_a.json")
     assert b.pmc_traffic_for(k8, scans_per_launch=160) == (1.6e10, "r09_x_pmc_hbm_traffic_b.json")  # 8 sequences x 20 steps in one launch
     assert b.pmc_traffic_for(k16, scans_per_launch=320) is None  # another workload's counters are not this run's
+    # ... and to the kernel sources it ran on: a pass of another build is reported as stale, a pass of this build wins
+    (prof / "r09_y_pmc_hbm_traffic_c.json").write_text(json.dumps({"workload_key": k8, "code_id": "abc", "traffic_bytes_per_scan": 2.0e8}))
+    assert b.pmc_traffic_for(k8, 160, code="abc") == (3.2e10, "r09_y_pmc_hbm_traffic_c.json", False)
+    assert b.pmc_traffic_for(k8, 160, code="zzz")[2] is True
+    (prof / "r09_z_pmc_hbm_traffic_d.json").write_text(json.dumps({"workload_key": k8, "code_id": "old", "traffic_bytes_per_scan": 3.0e8}))
+    assert b.pmc_traffic_for(k8, 160, code="abc") == (3.2e10, "r09_y_pmc_hbm_traffic_c.json", False)
+    assert len(b.code_id()) == 12
+
+
+def test_executed_byte_model_follows_the_loaded_build():
+    """bench.py's cost table must describe the library that is loaded - its build-dependent terms come from
+    ptl_build_info (a host-only call: no GPU needed)"""
+    from ptudes_lab_amd import core
+    b = _bench()
+    info = core.build_info()
+    assert info["kcand"] >= 2 and info["ans_row_doubles"] >= 3 + 3 * info["kcand"] + 2 and info["tab_entry_bytes"] == 16
+    cost, notes = b.exec_cost_for_build(info)
+    assert cost["point_iteration_later"] == 8 + 8 * info["ans_row_doubles"] and cost["lds_points_per_workgroup"] == info["lds_points"]
+    other = dict(info, ans_row_doubles=14, kcand=3, lds_points=1536, diagnostics=1)
+    cost2, notes2 = b.exec_cost_for_build(other)
+    assert cost2["point_iteration_later"] == 8 + 112 and cost2["search"] == 128 + 8 + 112 + 4 and len(notes2) == 3
 
 
 def test_committed_pmc_summaries_name_their_workload():

@@ -32,6 +32,19 @@ def test_launcher_runs_two_gloo_ranks_and_relays_one_line():
     assert abs(d["value"] - 6 * 2 * 2 / 0.02) < 1e-9  # max-over-ranks clock: rank 1's 0.02 s
 
 
+def test_launcher_runs_eight_gloo_ranks():
+    """the shape of the driver's 8-GPU run: eight ranks, three sequences each, sharded s % 8 == r, one gathered line"""
+    out = io.StringIO()
+    rc = _bench().launch_ranks(8, ["--gpus", "8", "--steps", "4", "--warmup", "1", "--seqs-per-gpu", "3"], worker=STUB,
+                               timeout_s=480, out=out)
+    assert rc == 0
+    lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
+    assert len(lines) == 1, out.getvalue()
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["gathered_trajectories"] == {"sequences": 24, "ok": True}
+    assert abs(d["value"] - 4 * 3 * 8 / 0.08) < 1e-9  # max-over-ranks clock: rank 7's 0.08 s
+
+
 def test_launcher_reports_a_dead_rank():
     out = io.StringIO()
     rc = _bench().launch_ranks(2, ["--gpus", "2", "--fail-rank", "1"], worker=STUB, timeout_s=240, out=out)

@@ -200,3 +200,36 @@ def test_independent_numpy_restatement_agrees_over_free_running_sweeps(mode):
     assert worst < 1e-9, worst
     assert moved  # the adaptive threshold left its initial value: that branch was compared too
     assert np.abs(pb[:3, :3] @ pb[:3, :3].T - np.eye(3)).max() < 1e-12
+
+
+def test_innovation_is_formed_with_the_raw_guess_like_the_reference():
+    """kiss.py:116-128: pose_gain = np.linalg.inv(initial_guess) @ new_pose on the guess AS THE CALLER HANDED IT OVER - the
+    registration itself works on the Sophus::SE3d of it.  A sheared, scaled caller's guess (rotation block 1e-3 off
+    orthonormal) tells the two apart: err_dt / err_drot / the next threshold of the C oracle must follow the numpy restatement,
+    which does literally what the reference line does (round 3 formed them with the re-normalised guess)."""
+    import ptudes_lab_amd  # noqa: F401
+    from oracle import icp_numpy as kn
+    from ptudes_lab_amd import synth
+    n = 12
+    seq = synth.make_sequence(seed=2003, n_scans=n, H=16, W=256, min_range=1.0, max_range=70.0)
+    t01 = seq.column_times()
+    gt = seq.gt_poses(0.5)
+    g0i = np.linalg.inv(gt[0])
+    rng = np.random.default_rng(7)
+    a = orc.ICP(max_range=70.0, min_range=1.0)
+    b = kn.KissICP(max_range=70.0, min_range=1.0)
+    differs = 0.0
+    for k in range(n):
+        x = seq.scan(k).astype(np.float64)
+        guess = g0i @ gt[k]
+        guess[:3, :3] = guess[:3, :3] @ (np.eye(3) + 1e-3 * rng.normal(size=(3, 3)))  # not a rotation any more
+        pa, pb = a.register_frame(x, t01, guess), b.register_frame(x, t01, guess)
+        sa, sb = a.stats[-1], b.stats[-1]
+        assert abs(sa["err_dt"] - sb["err_dt"]) < 1e-9 and abs(sa["err_drot"] - sb["err_drot"]) < 1e-7, (k, sa, sb)
+        assert abs(sa["sigma"] - sb["sigma"]) < 1e-9 and sa["iterations"] == sb["iterations"], (k, sa, sb)
+        assert np.abs(pa - pb).max() < 1e-9
+        # what round 3 computed: the innovation against the re-normalised guess
+        old = np.linalg.inv(kn.as_se3(guess)) @ pb
+        differs = max(differs, abs(float(np.linalg.norm(old[:3, 3])) - sb["err_dt"]))
+    assert differs > 1e-4  # the case does separate the two definitions
+

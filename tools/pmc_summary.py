@@ -20,6 +20,7 @@ out = {}
 try:
     line = json.loads([ln for ln in open(sys.argv[2]).read().splitlines() if ln.strip().startswith("{")][-1])
     out["workload_key"] = line["config"]["workload_key"]
+    out["code_id"] = line["config"].get("code_id")  # the kernel sources the pass ran on (bench.py code_id)
     out["dominant_kernel"] = line["roofline"]["kernel"]
     out["bench_value_under_profiler"] = line["value"]
     n_timed = line["roofline"]["launches"] if line["roofline"]["kernel"] == "kx_seq_run" else line["steps"]

@@ -14,9 +14,9 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" "$@" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 rm -rf "$OUT/prof_$TAG" "$OUT/pmc_${TAG}_fetch" "$OUT/pmc_${TAG}_write"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o kt -- python3 "$R/bench.py" --no-cpu-baseline "$@" > "$OUT/${TAG}_prof_bench.json" 2> "$OUT/${TAG}_prof.err"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_${TAG}_fetch" -o f -- python3 "$R/bench.py" --no-cpu-baseline "$@" > "$OUT/${TAG}_pmc_bench.json" 2> "$OUT/${TAG}_pmc_f.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_${TAG}_write" -o w -- python3 "$R/bench.py" --no-cpu-baseline "$@" > /dev/null 2> "$OUT/${TAG}_pmc_w.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o kt -- python3 "$R/bench.py" --no-cpu-baseline --repeats 1 "$@" > "$OUT/${TAG}_prof_bench.json" 2> "$OUT/${TAG}_prof.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_${TAG}_fetch" -o f -- python3 "$R/bench.py" --no-cpu-baseline --repeats 1 "$@" > "$OUT/${TAG}_pmc_bench.json" 2> "$OUT/${TAG}_pmc_f.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_${TAG}_write" -o w -- python3 "$R/bench.py" --no-cpu-baseline --repeats 1 "$@" > /dev/null 2> "$OUT/${TAG}_pmc_w.err"
 cd "$R"
 cp "$(find "$OUT/prof_$TAG" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
 # every dispatch of the dominant kernel (the free-running kernel has a short warm-up launch and the timed one: the stats' average mixes them)
