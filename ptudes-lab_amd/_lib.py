@@ -132,6 +132,7 @@ PROTOTYPES = {
     "ptl_batch_set_team_workgroups": (C.c_int, [_vp, C.c_int32]),
     "ptl_batch_team_workgroups": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ptl_batch_exec_counters": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
+    "ptl_batch_exec_counters2": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
     "ptl_batch_sched_counters": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
     "ptl_batch_status": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "ptl_batch_debug_stall_block": (C.c_int, [_vp, C.c_int32, C.c_int32]),
@@ -156,7 +157,10 @@ def lib():
         # when the runtime initialises, so this only helps if nothing touched the GPU yet.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = C.CDLL(LIB_PATH)
+        older = bool(os.environ.get("PTL_LIB_PATH")) and os.environ.get("PTL_LIB_ALLOW_OLDER") == "1"  # A/B runs against a library built from an older commit
         for name, (res, args) in PROTOTYPES.items():
+            if older and not hasattr(L, name):
+                continue
             f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             f.restype = res
             f.argtypes = args

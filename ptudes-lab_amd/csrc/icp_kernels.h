@@ -1918,8 +1918,10 @@ __device__ __forceinline__ double sums_from_moments(int e, const double* M) {
 #ifndef GN8_LDS_PTS
 #define GN8_LDS_PTS (6 * 512) /* source-point positions a workgroup keeps in LDS (72 KB) */
 #endif
+#ifndef GN8_QWAVE
 #define GN8_QWAVE 512         /* queue of points awaiting the full search: one region per wavefront of phase A (8 chunks of 64 at most between two
                                  flushes), filled from both ends by kind - no cross-wavefront prefix, no workgroup barrier per chunk */
+#endif
 #define GN8_QCHUNKS (GN8_QWAVE / 64)
 #ifndef GN8_LPB
 #define GN8_LPB 8             /* lanes per point of the full search (8 or 4) */
@@ -2481,8 +2483,15 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
 // GC = gridDim.x when that is 32 / 16 / 8 (the host picks the instance), else 0.  The exchange's association is the same
 // in every instance: a batch member equals the single run with as many workgroups.  (One body per kernel: each
 // instance of gn8_body has its own 40 KB of LDS.)
+// (make T256=1 / an occupancy experiment: the 8-lane kernels held to SEQ_WAVES_PER_EU wavefronts per SIMD explicitly - a launch bound
+// alone lets the register allocator plan for fewer)
+#ifdef SEQ_WAVES_PER_EU
+#define SEQ_OCC __attribute__((amdgpu_waves_per_eu(SEQ_WAVES_PER_EU, SEQ_WAVES_PER_EU)))
+#else
+#define SEQ_OCC
+#endif
 template <int PC, int GC>
-__global__ __launch_bounds__(GN8_MAX_THREADS) void k_gn_loop8(Ctx c, int mode) {
+__global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void k_gn_loop8(Ctx c, int mode) {
     gn8_body<PC, GC>(c, mode, (int)gridDim.x, (int)blockIdx.x);
 }
 
@@ -2927,7 +2936,7 @@ __device__ __forceinline__ bool kx_assign(int S, int& s, int& G, int& wg) {
     return s < S;
 }
 template <int PC, int GC>
-__global__ __launch_bounds__(GN8_MAX_THREADS) void kx_gn_loop8(const SeqCtx* a, int S, int scan_k) {
+__global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_gn_loop8(const SeqCtx* a, int S, int scan_k) {
     int s, G, wg;
     if (!kx_assign(S, s, G, wg)) return;
     const Ctx c = load_seq_ctx(a, s, scan_k);

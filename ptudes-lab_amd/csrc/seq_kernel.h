@@ -330,11 +330,6 @@ __device__ __forceinline__ void sched_abandon(SeqSched* sc, int q, int k1) {
 template <int PC, int GC>
 // (make T256=1: 256-thread workgroups, two per CU - the kernel then has to be held to 2 wavefronts per SIMD explicitly: a launch
 // bound of 256 threads alone would let the register allocator plan for one)
-#ifdef SEQ_WAVES_PER_EU
-#define SEQ_OCC __attribute__((amdgpu_waves_per_eu(SEQ_WAVES_PER_EU, SEQ_WAVES_PER_EU)))
-#else
-#define SEQ_OCC
-#endif
 __global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_seq_run(const SeqCtx* a, SeqRun r, SeqSched* sched, unsigned* bar, unsigned* status) {
     const int x = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3), J = (int)(gridDim.x >> 3);
     const int G = GC > 0 ? GC : r.G;
