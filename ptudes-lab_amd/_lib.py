@@ -132,7 +132,6 @@ PROTOTYPES = {
     "ptl_batch_set_team_workgroups": (C.c_int, [_vp, C.c_int32]),
     "ptl_batch_team_workgroups": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ptl_batch_exec_counters": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
-    "ptl_batch_exec_counters2": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
     "ptl_batch_sched_counters": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
     "ptl_batch_status": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "ptl_batch_debug_stall_block": (C.c_int, [_vp, C.c_int32, C.c_int32]),
