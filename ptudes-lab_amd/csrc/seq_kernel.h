@@ -113,6 +113,7 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     SQ_CLK(0);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(1);
+    int wave_valid = 0;  // this wavefront's valid points over all its blocks (integer sum: any grouping gives the same total)
     if (c.in_f32 && !c.in_range) {  // (uniform) the next pass's raw points travel while this pass waits for its atomics
         RawF32<SEQ_U> raw;
         sl.b = wg;
@@ -122,11 +123,12 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
             Slice nx = sl;
             nx.b = sl.b + nw;
             if (nx.b < nbs) raw = k1_load_raw<SEQ_U>(c, nx);
-            d_deskew_vds1<SEQ_U>(c, sl, &cur);
+            d_deskew_vds1<SEQ_U>(c, sl, &cur, &wave_valid);
         }
     } else {
-        for (sl.b = wg; sl.b < nbs; sl.b += nw) d_deskew_vds1<SEQ_U>(c, sl);
+        for (sl.b = wg; sl.b < nbs; sl.b += nw) d_deskew_vds1<SEQ_U>(c, sl, nullptr, &wave_valid);
     }
+    if ((threadIdx.x & 63) == 0 && wave_valid) atomicAdd(&st->n_valid, wave_valid);
     SQ_CLK(2);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(3);
