@@ -67,19 +67,19 @@ EXEC_COST = {
     "map_point_read": 24,
     # per iteration and workgroup of a team of G: its row stored (36 words of 8 B), G rows read once by its first wavefront
     "exchange_word": 8, "exchange_words_per_row": 36,
-    # stages, per raw point: K1 f32 xyz (12) + slot2 release read (4) + slot1 write (4) | K2 slot1 (4) + slot2 write (4) | K3 slot2 (4) | K4 slot2 (4)
-    "raw_point": 12 + 4 + 4 + 4 + 4 + 4 + 4,
-    # per valid point: K1 writes the deskewed point (24), K2 reads the slot's winner index (4)
+    # stages, per raw point: K1 f32 xyz (12) + slot1 write (4) | K3 slot1 (4)   (round 4: K3b / K4 walk the compact frame_downsample, not the raw indices)
+    "raw_point": 12 + 4 + 4,
+    # per valid point: K1 writes the deskewed point (24), K3 reads the slot's winner index (4)
     "valid_point": 24 + 4,
     # per voxel claim (run head) of either down-sampling pass: key read (8) + compare-and-swap (8) + index read (4) + atomicMin (4)
     "vds_claim": 24,
-    # per frame_down point: K2 reads it (24); K3 reads index (4) + slot (4) + point (24), writes fd (24), releases the pass-1 slot (12);
+    # per frame_down point: K3 reads the point (24), writes fd (24), releases the pass-1 slot (12); K3b reads fd (24), writes its pass-2 slot (4); K4 reads slot (4) + index (4);
     # map insert a: fd read (24), world point written (24), table key read (8), list push (4), slot + link written (8);
     # b: slot (4) + table entry (16) + list walk (~8) + block header (4) + world point (24) read, block written (24), rank + length written (8);
     # c: rank read (4)
-    "down_point": 24 + (4 + 4 + 24 + 24 + 12) + (24 + 24 + 8 + 4 + 8) + (4 + 16 + 8 + 4 + 24 + 24 + 8) + 4,
-    # per source point: K3 marks (4), K4 reads + writes it (48), the next K1 releases its pass-2 slot (12)
-    "source_point": 4 + 48 + 12,
+    "down_point": (24 + 24 + 12) + (24 + 4) + (4 + 4) + (24 + 24 + 8 + 4 + 8) + (4 + 16 + 8 + 4 + 24 + 24 + 8) + 4,
+    # per source point: K4 reads + writes it (48) and releases its pass-2 slot (12)
+    "source_point": 48 + 12,
     # prune: header (8) + first point (24) of every block below the pool's high-water mark (~ live voxels)
     "map_voxel": 32,
     # the per-column deskew table (12 doubles per column), written once per scan and read through the caches: counted once

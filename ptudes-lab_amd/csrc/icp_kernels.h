@@ -3,9 +3,10 @@
 // Replaces, on device, what reference src/ptudes/kiss.py:83-131 drives inside kiss-icp 0.2.10:
 //   K0 scan_prologue   deskew twist, adaptive threshold, initial guess          (kiss.py:90,99,102-105)
 //   K1 k_deskew_vds1   DeSkewScan + Preprocess + VoxelDownsample(0.5 vs) claim  (kiss.py:90,93,96)
-//   K2 k_vds2          first-point winners of pass 1 claim VoxelDownsample(1.5 vs)
+//   K2 k_count_w1      winners of pass 1 counted per block (only the drivers with one launch per stage; the free-running kernel looks back in K3)
 //   K3 k_compact_fd    ordered compaction -> frame_downsample
-//   K4 k_compact_src   ordered compaction -> source
+//   K3b k_vds2_fd      frame_downsample (compact) claims VoxelDownsample(1.5 vs)   [+ k_count_w2: its winners per block, as K2]
+//   K4 k_compact_src   ordered compaction -> source, pass-2 slots released
 //   K5 k_gn_loop       persistent Gauss-Newton loop: 27-voxel NN + robust 6x6 system + solve (kiss.py:108-114)
 //      (tail of K5)    new pose, innovation log, threshold model deviation      (kiss.py:116-130)
 //   K7-9 k_map_*       VoxelHashMap::AddPoints, order-preserving, cap per voxel (kiss.py:129)
@@ -462,21 +463,15 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl, cons
     long long k1_t = (long long)wall_clock64();
     const bool k1_me = sl.clk != 0 && threadIdx.x == 0;  // (workgroup 0 of the team)
 #endif
-    const int prev_n_in = st->prev_n_in, do_deskew = st->do_deskew;
+    const int do_deskew = st->do_deskew;
     int idx[U];
     bool valid[U], keyed[U];
     unsigned long long key[U];
     V3 p[U];
-    {   // release the previous scan's pass-2 slots: after K3 slot2[i] >= 0 marks exactly the winner of its slot (K4 still read them)
-        int s2[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s2[u] = (idx[u] < prev_n_in) ? c.slot2[idx[u]] : -1; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (s2[u] >= 0) { c.vtab2[s2[u]].key = EMPTY_KEY; c.vtab2[s2[u]].vmin = 0xFFFFFFFFu; }
-            if (idx[u] >= c.n_in && idx[u] < prev_n_in) c.slot2[idx[u]] = -1;
-        }
-    }
+    for (int u = 0; u < U; ++u) idx[u] = base + u * BS;
+    // (the pass-2 voxel slots of the previous scan are released by their winners in K4 since round 4 - until then this pass began
+    // with a read of every point's slot word and the stores that release the winners' entries: 34 of K1's 343 us)
     K1_CLK(20);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -592,67 +587,6 @@ __device__ __forceinline__ PreI32<U> stage_load_i32(const int* arr, int n, const
     for (int u = 0; u < U; ++u) { const int i = base + u * BS; r.v[u] = (i < n) ? arr[i] : -1; }
     return r;
 }
-// ------------------------------------------------------------------------------------------------ K2
-template <int U>
-__device__ __forceinline__ void d_vds2(const Ctx& c, const Slice sl, const PreI32<U>* pre = nullptr) {
-    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
-    int idx[U], s1[U];
-    bool w1[U];
-    unsigned long long key[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s1[u] = pre ? pre->v[u] : ((idx[u] < c.n_in) ? c.slot1[idx[u]] : -1); }
-    {
-        unsigned vm[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) vm[u] = (s1[u] >= 0) ? c.vtab1[s1[u]].vmin : 0u;
-#pragma unroll
-        for (int u = 0; u < U; ++u) w1[u] = (s1[u] >= 0) && (vm[u] == (unsigned)idx[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        key[u] = EMPTY_KEY;
-        if (w1[u]) {
-            const size_t i = (size_t)idx[u];
-            V3 p = v3(c.pts[3 * i], c.pts[3 * i + 1], c.pts[3 * i + 2]);
-            int kx, ky, kz;
-            vox_key(p, c.vds2, key[u], kx, ky, kz);
-        }
-    }
-    // As in pass 1, runs: consecutive pass-1 winners of a wavefront mostly share the coarser voxel.  Only the first winner
-    // of each run of equal keys - the lowest index of the run, the only one of them that can win - claims and bids; the
-    // others take the slot from it.
-    {
-        const int lane = threadIdx.x & 63;
-        bool head[U];
-        int slot[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned long long winners = __ballot(w1[u]);
-            const unsigned long long before = winners & ((1ull << lane) - 1ull);          // winners in lower lanes
-            const int prev_lane = before ? 63 - __clzll((long long)before) : lane;
-            const unsigned long long prev_key = __shfl(key[u], prev_lane);
-            head[u] = w1[u] && (!before || prev_key != key[u]);
-        }
-        vds_claim_u<U>(c.vtab2, c.vmask, key, head, slot);
-        {
-            int nh = 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u) nh += __popcll(__ballot(head[u]));
-            if (lane == 0 && nh) atomicAdd(&c.st->exec_cnt[5], (unsigned long long)nh);
-        }
-        vds_bid_u<U>(c.vtab2, slot, head, idx, &c.st->err_flags);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned long long heads = __ballot(head[u]);
-            const unsigned long long below = heads & (~0ull >> (63 - lane));               // heads at or below this lane
-            const int my_head = below ? 63 - __clzll((long long)below) : lane;
-            const int hs = __shfl(slot[u], my_head);
-            if (idx[u] < c.n_in) c.slot2[idx[u]] = w1[u] ? hs : -1;
-        }
-    }
-    const int n1 = block_count_u<U>(w1);
-    if (threadIdx.x == 0) c.bcnt1[sl.b] = n1;
-}
 
 // exclusive prefix of per-block counts + in-block rank (scan order preserved)
 // (integer sums: any grouping gives the same value)
@@ -698,80 +632,215 @@ __device__ __forceinline__ void block_rank_u(const bool (&f)[U], int (&rk)[U], i
     total = running;
     __syncthreads();
 }
+// Ordered compaction in ONE pass over the blocks (free-running kernel): a block publishes its own count as (tag << 16 | count) -
+// tag = the scan's number, so whatever an earlier scan left in the word is not taken for this scan's - and then adds up the counts
+// of the blocks before it, waiting for those that are not there yet.  The team's workgroups walk their blocks in ascending
+// order (block b of workgroup w: w, w + n, ...) and every workgroup is resident, so whoever is waited for is at work on an
+// earlier block of its own: no cycle.  The separate counting pass over all points (and its team barrier) is gone.
+// Bounded like every wait of the kernel: a budget of polls, then the sequence's time-out flag (the caller's next team barrier
+// sees the abort word and the team leaves).
+#define LOOKBACK_POLLS (1u << 22)
+__device__ __forceinline__ void lookback_publish(int* bcnt, int b, unsigned tag, int count) {
+    if (threadIdx.x == 0) __hip_atomic_store(&bcnt[b], (int)((tag << 16) | (unsigned)count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int lookback_offset(const int* bcnt, int b, unsigned tag, DevState* st) {
+    int s = 0;
+    bool bad = false;
+    for (int k = threadIdx.x; k < b; k += (int)blockDim.x) {
+        unsigned polls = 0;
+        for (;;) {
+            const unsigned v = (unsigned)__hip_atomic_load(&bcnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 16) == tag) { s += (int)(v & 0xFFFFu); break; }
+            if (++polls > LOOKBACK_POLLS || ((polls & 1023u) == 0u && __hip_atomic_load(&st->gn_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { bad = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (bad) { atomicOr(&st->err_flags, ERR_GN_TIMEOUT); __hip_atomic_store(&st->gn_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return block_offset(s);
+}
+__device__ __forceinline__ unsigned lookback_tag(int scan_k) { return ((unsigned)scan_k % 0xFFFFu) + 1u; }  // 1 .. 65535 (0 = never published: the arrays are zeroed at a reset); a block holds <= 16 x 1024 points: 16 bits of count
+static_assert(STAGE_MAX_U * 1024 < (1 << 16), "the look-back word keeps a block's count in 16 bits");
 
-// ------------------------------------------------------------------------------------------------ K3
+// ------------------------------------------------------------------------------------------------ K2
+// VoxelDownsample(0.5 vs) decided: the winner of a voxel is the point whose index stands in its slot.  The drivers that launch
+// every stage as a kernel of its own count the winners per block here (the prefix of K3); the free-running kernel does not run
+// this pass at all (K3 counts for itself and looks back).
 template <int U>
-__device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl, const PreI32<U>* pre = nullptr) {
+__device__ __forceinline__ void d_count_w1(const Ctx& c, const Slice sl) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
-    int idx[U], s2[U], rk[U];
-    bool w1[U], w2[U];
-    const int off_part = block_offset_part(c.bcnt1, sl.b);
+    int idx[U], s1[U];
+    bool w1[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s2[u] = pre ? pre->v[u] : ((idx[u] < c.n_in) ? c.slot2[idx[u]] : -1); }  // K2: slot2 >= 0 <=> pass-1 winner
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s1[u] = (idx[u] < c.n_in) ? c.slot1[idx[u]] : -1; }
     {
         unsigned vm[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { w1[u] = s2[u] >= 0; vm[u] = w1[u] ? c.vtab2[s2[u]].vmin : 0u; }
+        for (int u = 0; u < U; ++u) vm[u] = (s1[u] >= 0) ? c.vtab1[s1[u]].vmin : 0u;
 #pragma unroll
-        for (int u = 0; u < U; ++u) w2[u] = w1[u] && (vm[u] == (unsigned)idx[u]);
+        for (int u = 0; u < U; ++u) w1[u] = (s1[u] >= 0) && (vm[u] == (unsigned)idx[u]);
     }
-    const int off = block_offset(off_part);
+    const int n1 = block_count_u<U>(w1);
+    if (threadIdx.x == 0) c.bcnt1[sl.b] = n1;
+}
+
+// ------------------------------------------------------------------------------------------------ K3
+// frame_downsample = the pass-1 winners in scan order.  LB: one pass with look-back (tag = lookback_tag(scan)); else the block
+// counts of d_count_w1.
+template <int U, bool LB>
+__device__ __forceinline__ void d_compact_fd(const Ctx& c, const Slice sl, const PreI32<U>* pre = nullptr, unsigned tag = 0u) {
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
+    int idx[U], s1[U], rk[U];
+    bool w1[U];
+    int off_part = 0;
+    if (!LB) off_part = block_offset_part(c.bcnt1, sl.b);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s1[u] = pre ? pre->v[u] : ((idx[u] < c.n_in) ? c.slot1[idx[u]] : -1); }
+    {
+        unsigned vm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vm[u] = (s1[u] >= 0) ? c.vtab1[s1[u]].vmin : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) w1[u] = (s1[u] >= 0) && (vm[u] == (unsigned)idx[u]);
+    }
+    double q[U][3];  // every winner's point requested before anything waits or is stored
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = (size_t)idx[u];
+        if (w1[u]) { q[u][0] = c.pts[3 * i]; q[u][1] = c.pts[3 * i + 1]; q[u][2] = c.pts[3 * i + 2]; }
+    }
     int total;
     block_rank_u<U>(w1, rk, total);
+    int off;
+    if (LB) {
+        lookback_publish(c.bcnt1, sl.b, tag, total);
+        off = lookback_offset(c.bcnt1, sl.b, tag, c.st);
+    } else {
+        off = block_offset(off_part);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!w1[u]) continue;
+        const size_t o = (size_t)(off + rk[u]) * 3;
+        c.fd[o] = q[u][0]; c.fd[o + 1] = q[u][1]; c.fd[o + 2] = q[u][2];
+        // release the pass-1 slot for the next scan (only its winner touches it)
+        c.vtab1[s1[u]].key = EMPTY_KEY;
+        c.vtab1[s1[u]].vmin = 0xFFFFFFFFu;
+    }
+    if (threadIdx.x == 0 && sl.b == sl.nb - 1) c.st->n_down = off + total;
+}
+
+// ------------------------------------------------------------------------------------------------ K3b
+// VoxelDownsample(1.5 vs) of frame_downsample, on the COMPACT array (N_d ~ 35 k entries instead of a pass over the 131 k raw
+// indices of which a quarter are winners): entry j claims its coarse voxel, the smallest j in a voxel wins - the first in
+// scan order, as before (frame_downsample is in scan order).  slot2[j] = the voxel's slot.  Runs as in pass 1: consecutive
+// entries of a wavefront mostly share the coarser voxel; only the first of a run of equal keys claims and bids.
+template <int U>
+__device__ __forceinline__ void d_vds2_fd(const Ctx& c, const Slice sl) {
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
+    const int nd = c.st->n_down;
+    int idx[U];
+    bool act[U];
+    unsigned long long key[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; act[u] = idx[u] < nd; key[u] = EMPTY_KEY; }
     {
-        int s1[U];
         double q[U][3];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const size_t i = (size_t)idx[u];
-            s1[u] = w1[u] ? c.slot1[i] : -1;
-            if (w1[u]) { q[u][0] = c.pts[3 * i]; q[u][1] = c.pts[3 * i + 1]; q[u][2] = c.pts[3 * i + 2]; }
+            const size_t j = (size_t)idx[u];
+            q[u][0] = q[u][1] = q[u][2] = 0.0;
+            if (act[u]) { q[u][0] = c.fd[3 * j]; q[u][1] = c.fd[3 * j + 1]; q[u][2] = c.fd[3 * j + 2]; }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!w1[u]) continue;
-            const size_t o = (size_t)(off + rk[u]) * 3;
-            c.fd[o] = q[u][0]; c.fd[o + 1] = q[u][1]; c.fd[o + 2] = q[u][2];
-            // release the pass-1 slot for the next scan (only its winner touches it)
-            c.vtab1[s1[u]].key = EMPTY_KEY;
-            c.vtab1[s1[u]].vmin = 0xFFFFFFFFu;
-            // from here on slot2 >= 0 marks the pass-2 winners only (K4, and the next scan's K1 which releases their slots)
-            if (!w2[u]) c.slot2[idx[u]] = -1;
+            if (!act[u]) continue;
+            int kx, ky, kz;
+            vox_key(v3(q[u][0], q[u][1], q[u][2]), c.vds2, key[u], kx, ky, kz);
         }
     }
-    const int n2 = block_count_u<U>(w2);
-    if (threadIdx.x == 0) {
-        c.bcnt2[sl.b] = n2;
-        if (sl.b == sl.nb - 1) c.st->n_down = off + total;
+    const int lane = threadIdx.x & 63;
+    bool head[U];
+    int slot[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned long long prev = __shfl_up(key[u], 1);
+        const bool prev_act = __shfl_up(act[u] ? 1 : 0, 1) != 0;
+        head[u] = act[u] && (lane == 0 || !prev_act || prev != key[u]);
     }
+    vds_claim_u<U>(c.vtab2, c.vmask, key, head, slot);
+    {
+        int nh = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) nh += __popcll(__ballot(head[u]));
+        if (lane == 0 && nh) atomicAdd(&c.st->exec_cnt[5], (unsigned long long)nh);
+    }
+    vds_bid_u<U>(c.vtab2, slot, head, idx, &c.st->err_flags);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned long long heads = __ballot(head[u]);
+        const unsigned long long below = heads & (~0ull >> (63 - lane));  // heads at or below this lane
+        const int my_head = below ? 63 - __clzll((long long)below) : lane;
+        const int hs = __shfl(slot[u], my_head);
+        if (act[u]) c.slot2[idx[u]] = hs;
+    }
+}
+// ... and its winners counted per block (the drivers with one launch per stage; the free-running kernel looks back in K4)
+template <int U>
+__device__ __forceinline__ void d_count_w2(const Ctx& c, const Slice sl) {
+    const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
+    const int nd = c.st->n_down;
+    bool w2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = base + u * BS;
+        const int s2 = (j < nd) ? c.slot2[j] : -1;
+        w2[u] = s2 >= 0 && c.vtab2[s2].vmin == (unsigned)j;
+    }
+    const int n2 = block_count_u<U>(w2);
+    if (threadIdx.x == 0) c.bcnt2[sl.b] = n2;
 }
 
 // ------------------------------------------------------------------------------------------------ K4
-template <int U>
-__device__ __forceinline__ void d_compact_src(const Ctx& c, const Slice sl, const PreI32<U>* pre = nullptr) {
+// source = the pass-2 winners in scan order, over the compact frame_downsample; a winner releases its voxel slot for the next scan
+template <int U, bool LB>
+__device__ __forceinline__ void d_compact_src(const Ctx& c, const Slice sl, unsigned tag = 0u) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
-    int idx[U], rk[U];
+    const int nd = c.st->n_down;
+    int idx[U], s2[U], rk[U];
     bool w2[U];
-    const int off_part = block_offset_part(c.bcnt2, sl.b);
+    int off_part = 0;
+    if (!LB) off_part = block_offset_part(c.bcnt2, sl.b);
 #pragma unroll
-    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; w2[u] = pre ? pre->v[u] >= 0 : ((idx[u] < c.n_in) && c.slot2[idx[u]] >= 0); }  // K3: slot2 >= 0 <=> pass-2 winner
-    const int off = block_offset(off_part);
+    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; s2[u] = (idx[u] < nd) ? c.slot2[idx[u]] : -1; }
+    {
+        unsigned vm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vm[u] = (s2[u] >= 0) ? c.vtab2[s2[u]].vmin : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) w2[u] = (s2[u] >= 0) && (vm[u] == (unsigned)idx[u]);
+    }
+    double q[U][3];  // every winner's point requested before anything waits or is stored
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t j = (size_t)idx[u];
+        if (w2[u]) { q[u][0] = c.fd[3 * j]; q[u][1] = c.fd[3 * j + 1]; q[u][2] = c.fd[3 * j + 2]; }
+    }
     int total;
     block_rank_u<U>(w2, rk, total);
-    {   // every winner's point requested before the first one is stored (a load -> store pair per u would cost one dependent
-        // memory round trip per u: some lane of the wavefront holds a winner for nearly every u)
-        double q[U][3];
+    int off;
+    if (LB) {
+        lookback_publish(c.bcnt2, sl.b, tag, total);
+        off = lookback_offset(c.bcnt2, sl.b, tag, c.st);
+    } else {
+        off = block_offset(off_part);
+    }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const size_t i = (size_t)idx[u];
-            if (w2[u]) { q[u][0] = c.pts[3 * i]; q[u][1] = c.pts[3 * i + 1]; q[u][2] = c.pts[3 * i + 2]; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!w2[u]) continue;
-            const size_t o = (size_t)(off + rk[u]) * 3;
-            c.src0[o] = q[u][0]; c.src0[o + 1] = q[u][1]; c.src0[o + 2] = q[u][2];
-        }
+    for (int u = 0; u < U; ++u) {
+        if (!w2[u]) continue;
+        const size_t o = (size_t)(off + rk[u]) * 3;
+        c.src0[o] = q[u][0]; c.src0[o + 1] = q[u][1]; c.src0[o + 2] = q[u][2];
+        c.vtab2[s2[u]].key = EMPTY_KEY;
+        c.vtab2[s2[u]].vmin = 0xFFFFFFFFu;
     }
     if (threadIdx.x == 0 && sl.b == sl.nb - 1) c.st->n_src = off + total;
 }
@@ -2883,20 +2952,30 @@ __global__ __launch_bounds__(256) void kb_deskew_vds1(const SeqCtx* a, int scan_
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
     d_deskew_vds1<1>(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_vds2(Ctx c) { d_vds2<1>(c, launch_slice()); }
-__global__ __launch_bounds__(256) void kb_vds2(const SeqCtx* a, int scan_k) {
+__global__ __launch_bounds__(256) void k_count_w1(Ctx c) { d_count_w1<1>(c, launch_slice()); }
+__global__ __launch_bounds__(256) void kb_count_w1(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_vds2<1>(c, launch_slice());
+    d_count_w1<1>(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_compact_fd(Ctx c) { d_compact_fd<1>(c, launch_slice()); }
+__global__ __launch_bounds__(256) void k_compact_fd(Ctx c) { d_compact_fd<1, false>(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_compact_fd(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_compact_fd<1>(c, launch_slice());
+    d_compact_fd<1, false>(c, launch_slice());
 }
-__global__ __launch_bounds__(256) void k_compact_src(Ctx c) { d_compact_src<1>(c, launch_slice()); }
+__global__ __launch_bounds__(256) void k_vds2_fd(Ctx c) { d_vds2_fd<1>(c, launch_slice()); }
+__global__ __launch_bounds__(256) void kb_vds2_fd(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_vds2_fd<1>(c, launch_slice());
+}
+__global__ __launch_bounds__(256) void k_count_w2(Ctx c) { d_count_w2<1>(c, launch_slice()); }
+__global__ __launch_bounds__(256) void kb_count_w2(const SeqCtx* a, int scan_k) {
+    const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
+    d_count_w2<1>(c, launch_slice());
+}
+__global__ __launch_bounds__(256) void k_compact_src(Ctx c) { d_compact_src<1, false>(c, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_compact_src(const SeqCtx* a, int scan_k) {
     const Ctx c = load_seq_ctx(a, blockIdx.y, scan_k);
-    d_compact_src<1>(c, launch_slice());
+    d_compact_src<1, false>(c, launch_slice());
 }
 __global__ __launch_bounds__(256) void k_map_insert_a(Ctx c, const double* pts_in, const int* n_ptr, int n_fixed, int use_pose) { d_map_insert_a<1>(c, pts_in, n_ptr, n_fixed, use_pose, launch_slice()); }
 __global__ __launch_bounds__(256) void kb_map_insert_a(const SeqCtx* a, int scan_k) {

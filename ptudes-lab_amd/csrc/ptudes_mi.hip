@@ -142,6 +142,8 @@ static int icp_reset_device(ptl_icp* h) {
     HIPCHK(hipMemsetAsync(c.vtab2, 0xFF, vcap * sizeof(VdsEnt), h->stream));
     HIPCHK(hipMemsetAsync(c.tab, 0xFF, ((size_t)c.tmask + 1) * sizeof(TabEnt), h->stream));
     HIPCHK(hipMemsetAsync(c.blocks, 0, (size_t)c.pool_cap * c.bstride, h->stream));
+    HIPCHK(hipMemsetAsync(c.bcnt1, 0, (size_t)h->nblk_scan * sizeof(int), h->stream));  // look-back words of the compactions: tag 0 = never published
+    HIPCHK(hipMemsetAsync(c.bcnt2, 0, (size_t)h->nblk_scan * sizeof(int), h->stream));
     HIPCHK(hipMemsetAsync(c.gn_rows_ll, 0, (size_t)2 * c.G * 64 * 8, h->stream));  // the launch epoch restarts with the state
     HIPCHK(hipMemsetAsync(c.gn_xsum_ll, 0, (size_t)2 * 8 * 8 * 64 * 8, h->stream));
     k_fill_free_stack<<<(c.pool_cap + 255) / 256, 256, 0, h->stream>>>(c.free_stack, c.pool_cap);
@@ -339,8 +341,10 @@ static int icp_enqueue_scan(ptl_icp* h, const float* in_f32, const double* in_f6
     // runner, the EKF step (its own stream) - both are done before this chain is, so the waits below do not block
     k_scan_prologue<<<1, 1024, 0, s>>>(c);
     k_deskew_vds1<<<nb1, 256, 0, s>>>(c);
-    k_vds2<<<nb, 256, 0, s>>>(c);
+    k_count_w1<<<nb, 256, 0, s>>>(c);
     k_compact_fd<<<nb, 256, 0, s>>>(c);
+    k_vds2_fd<<<nb, 256, 0, s>>>(c);  // (over the compact frame_downsample: blocks beyond N_d find nothing to do)
+    k_count_w2<<<nb, 256, 0, s>>>(c);
     k_compact_src<<<nb, 256, 0, s>>>(c);
     if (h->ev_map_valid) HIPCHK(hipStreamWaitEvent(s, h->ev_map, 0));
     if (h->gn_wait) HIPCHK(hipStreamWaitEvent(s, h->gn_wait, 0));
@@ -1685,8 +1689,10 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
         const int ki = (int)k;
         kb_scan_prologue<<<dim3(1, S), 1024, 0, st>>>(b->d_ctx, ki);
         kb_deskew_vds1<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
-        kb_vds2<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        kb_count_w1<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
         kb_compact_fd<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        kb_vds2_fd<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
+        kb_count_w2<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
         kb_compact_src<<<dim3(nb, S), 256, 0, st>>>(b->d_ctx, ki);
         if (b->ev_side_valid) HIPCHK(hipStreamWaitEvent(st, b->ev_side, 0));  // the previous scan's map update and filter step
         hipEvent_t e0 = nullptr, e1 = nullptr;

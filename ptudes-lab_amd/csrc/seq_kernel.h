@@ -133,7 +133,8 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(3);
     sl.nb = nbs2;
-    {   // (the next pass's first loads a pass ahead, as in K1)
+    const unsigned tag = lookback_tag(k);
+    {   // K3: pass-1 winners -> frame_downsample, one pass with look-back (the next pass's first loads a pass ahead, as in K1)
         PreI32<SEQ_U2> pw;
         sl.b = wg;
         if (wg < nbs2) pw = stage_load_i32<SEQ_U2>(c.slot1, c.n_in, sl);
@@ -142,39 +143,20 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
             Slice nx = sl;
             nx.b = sl.b + nw;
             if (nx.b < nbs2) pw = stage_load_i32<SEQ_U2>(c.slot1, c.n_in, nx);
-            d_vds2<SEQ_U2>(c, sl, &cur);
+            d_compact_fd<SEQ_U2, true>(c, sl, &cur, tag);
         }
     }
     SQ_CLK(4);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(5);
-    {   // (the next pass's first loads a pass ahead, as in K1)
-        PreI32<SEQ_U2> pw;
-        sl.b = wg;
-        if (wg < nbs2) pw = stage_load_i32<SEQ_U2>(c.slot2, c.n_in, sl);
-        for (sl.b = wg; sl.b < nbs2; sl.b += nw) {
-            const PreI32<SEQ_U2> cur = pw;
-            Slice nx = sl;
-            nx.b = sl.b + nw;
-            if (nx.b < nbs2) pw = stage_load_i32<SEQ_U2>(c.slot2, c.n_in, nx);
-            d_compact_fd<SEQ_U2>(c, sl, &cur);
-        }
-    }
+    // K3b / K4 walk the COMPACT frame_downsample (N_d entries, a quarter of the raw indices)
+    const int nbf = (st->n_down + BS2 - 1) / BS2;
+    sl.nb = nbf;
+    for (sl.b = wg; sl.b < nbf; sl.b += nw) d_vds2_fd<SEQ_U2>(c, sl);
     SQ_CLK(6);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(7);
-    {   // (the next pass's first loads a pass ahead, as in K1)
-        PreI32<SEQ_U2> pw;
-        sl.b = wg;
-        if (wg < nbs2) pw = stage_load_i32<SEQ_U2>(c.slot2, c.n_in, sl);
-        for (sl.b = wg; sl.b < nbs2; sl.b += nw) {
-            const PreI32<SEQ_U2> cur = pw;
-            Slice nx = sl;
-            nx.b = sl.b + nw;
-            if (nx.b < nbs2) pw = stage_load_i32<SEQ_U2>(c.slot2, c.n_in, nx);
-            d_compact_src<SEQ_U2>(c, sl, &cur);
-        }
-    }
+    for (sl.b = wg; sl.b < nbf; sl.b += nw) d_compact_src<SEQ_U2, true>(c, sl, tag);
     SQ_CLK(8);
     return target;
 }
