@@ -39,8 +39,8 @@ ds = (C.c_double * 32)()
 L.check(L.lib().ptl_icp_debug_sums(icp, ds))
 d = np.array(list(ds)) / n / 100.0
 if d[:20].sum() > 0:
-    names = ["prologue", "w", "deskew+vds1", "w", "vds2", "w", "compact_fd", "w", "compact_src", "-", "insert_a", "w", "insert_b", "w", "insert_c", "w", "prune"]
+    names = ["prologue", "w", "deskew+vds1", "w", "compact_fd (look-back)", "w", "vds2 on frame_down", "w", "compact_src (look-back)", "-", "insert_a", "w", "insert_b", "w", "insert_c", "w", "prune"]
     print("stages of sequence 0 (workgroup 0), us/scan:", "  ".join("%s %.0f" % (nm, v) for nm, v in zip(names, d[:17])))
-    print("inside K1 (thread 0 of workgroup 0, its own waits): release %.0f | load + deskew + store %.0f | claim %.0f | bid %.0f | slot1 %.0f | count %.0f" % tuple(d[20:26]))
+    print("inside K1 (thread 0 of workgroup 0, its own waits): - %.0f | load + deskew + store %.0f | claim %.0f | bid %.0f | slot1 %.0f | count %.0f" % tuple(d[20:26]))
 else:
     print("(no stage clocks: not a STAGES=1 build)")
