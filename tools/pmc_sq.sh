@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS"; do
   rm -rf "$R/gpurun_out/pmc_sq"
   # shellcheck disable=SC2086
-  rocprofv3 --pmc $set --output-format csv -d "$R/gpurun_out/pmc_sq" -o s -- python3 "$R/bench.py" --no-cpu-baseline --steps 40 --warmup 10 "$@" > /dev/null 2> "$R/gpurun_out/pmc_sq.err"
+  rocprofv3 --pmc $set --output-format csv -d "$R/gpurun_out/pmc_sq" -o s -- python3 "$R/bench.py" --no-cpu-baseline --no-single-sequence --repeats 1 --steps 40 --warmup 10 "$@" > /dev/null 2> "$R/gpurun_out/pmc_sq.err"
   KP="$KP" D="$R/gpurun_out/pmc_sq" python3 - <<'PY'
 import collections, csv, glob, os
 f = glob.glob(os.environ["D"] + "/**/*counter_collection.csv", recursive=True)
