@@ -104,6 +104,12 @@ int ptl_icp_destroy(ptl_icp *h);
 int ptl_icp_register_frame(ptl_icp *h, const void *xyz, int dtype, int64_t n, const double *t01,
                            double scan_ts, const double *guess, double out_pose[16], ptl_icp_stats *stats);
 /* KissICPWrapper.poses / .pose (kiss.py:142-153): copies up to max poses (16 doubles each) */
+/* Per-call registrations (ptl_icp_register_frame / _range) normally return after the scan's MAP UPDATE, because the statistics
+ * row carries the map size.  on != 0: return as soon as the registration itself (the Gauss-Newton kernel) is done - what the
+ * reference's register_frame returns is the pose (kiss.py:74) - while the map update runs beside the caller's next steps and the
+ * next call's upload and K0-K4; stats->map_voxels / map_points are then -1 (ptl_icp_map_size gives them on demand) and an error
+ * flag raised by that update is reported by the next call. */
+int ptl_icp_set_lazy_map_stats(ptl_icp *h, int32_t on);
 int ptl_icp_num_poses(ptl_icp *h, int64_t *n);
 int ptl_icp_get_poses(ptl_icp *h, double *out, int64_t max_poses, int64_t *n_written);
 /* kiss_icp.KissICP.get_prediction_model, used at ekf_bench.py:545 */

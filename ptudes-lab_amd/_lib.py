@@ -59,6 +59,7 @@ PROTOTYPES = {
     "ptl_icp_destroy": (C.c_int, [_vp]),
     "ptl_icp_register_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, c_d_p, C.c_double, c_d_p, c_d_p,
                                          C.POINTER(IcpStats)]),
+    "ptl_icp_set_lazy_map_stats": (C.c_int, [_vp, C.c_int32]),
     "ptl_icp_num_poses": (C.c_int, [_vp, c_i64_p]),
     "ptl_icp_get_poses": (C.c_int, [_vp, c_d_p, C.c_int64, c_i64_p]),
     "ptl_icp_get_prediction": (C.c_int, [_vp, c_d_p]),

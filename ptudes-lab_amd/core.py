@@ -30,10 +30,14 @@ def ekf_cfg(init_grav=None, init_bacc=None, init_bgyr=None, device_id=0):
 
 
 class Icp:
-    def __init__(self, max_range=100.0, min_range=5.0, **over):
+    def __init__(self, max_range=100.0, min_range=5.0, lazy_map_stats=False, **over):
+        """lazy_map_stats: registrations return when the pose is there, before the scan's map update is complete (the per-scan rows then
+        carry map_voxels = map_points = -1; `map_size()` gives them on demand) - include/ptudes_mi.h ptl_icp_set_lazy_map_stats"""
         self.cfg = icp_cfg(max_range, min_range, **over)
         self._h = C.c_void_p()
         L.check(L.lib().ptl_icp_create(C.byref(self.cfg), C.byref(self._h)))
+        if lazy_map_stats:
+            L.check(L.lib().ptl_icp_set_lazy_map_stats(self._h, 1))
         self.stats = []
 
     def close(self):

@@ -51,7 +51,8 @@ struct ptl_icp {
     int64_t traj_cap;
     int64_t scans_done;
     unsigned char* d_row_mask;  // active-beam mask for range-image input, or null
-    int64_t last_n;      // points of the previous scan (its pass-2 VDS slots are released by the next K1)
+    int64_t last_n;      // points of the previous scan
+    bool lazy_map_stats; // per-call API: do not wait for the scan's map update before returning (ptl_icp_set_lazy_map_stats)
     // profiling of the dominant kernel
     bool prof;
     int prof_every;  // time every n-th GN launch (two event records cost ~18 us of command-processor time per scan)
@@ -195,6 +196,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     h->stream = shared_stream;
     h->prof = false; h->prof_every = 1; h->ev_used = 0; h->gn_ms = 0; h->gn_launches = 0;
     h->gn_wait = nullptr; h->gn_done = nullptr;
+    h->lazy_map_stats = false;
     h->n_src_hint = nullptr;
     h->map_stream = nullptr; h->ev_map = nullptr; h->ev_map_valid = false;
     h->ev_gn = nullptr;
@@ -408,6 +410,46 @@ static int icp_check_flags(ptl_icp* h) {
     return PTL_OK;
 }
 
+__global__ void k_finish_pose(Ctx c) {  // KissICP.poses.append of the scan just registered, WITHOUT the map statistics (its map update may still be running)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    finish_pending(c, c.st);
+}
+static void stats_out(const ScanStats& s, ptl_icp_stats* o);
+// what follows the enqueue of a per-call registration: close the scan, bring pose and statistics row back, check the error flags.
+// Default: after the scan's map update (map size is part of the row).  lazy_map_stats: as soon as the Gauss-Newton kernel is done -
+// the map update (K7-K10, ~80 us) then runs beside the caller's next steps and the next call's upload and K0-K4; the row's map_voxels /
+// map_points are -1 (ptl_icp_map_size gives them on demand) and an error flag raised by that update is reported by the next call.
+static int icp_percall_finish(ptl_icp* h, double out_pose[16], ptl_icp_stats* stats) {
+    const bool lazy = h->lazy_map_stats;
+    if (!lazy && h->ev_map_valid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_map, 0));  // map size is part of the row
+    if (lazy) k_finish_pose<<<1, 64, 0, h->stream>>>(h->c);
+    else k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);  // close the scan before its stats row is read back
+    const int64_t k = h->scans_done - 1;
+    double pose[16];
+    ScanStats ss;
+    int flags = 0;
+    HIPCHK(hipMemcpyAsync(pose, h->c.traj + 16 * k, sizeof pose, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&ss, h->c.sstats + k, sizeof ss, hipMemcpyDeviceToHost, h->stream));
+    int rc = PTL_OK;
+    if (lazy) {
+        HIPCHK(hipMemcpyAsync(&flags, &h->c.st->err_flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->prof) icp_collect_profile(h);
+        if (flags) rc = set_err(PTL_ERR_CAPACITY, "device capacity/error flags 0x%x (1 key range, 2 block pool, 4 map table, 8 vds table, 16 gn barrier timeout)", flags);
+        ss.map_voxels = -1; ss.map_points = -1;
+    } else {
+        rc = icp_check_flags(h);
+    }
+    if (rc) return rc;
+    if (out_pose) memcpy(out_pose, pose, sizeof pose);
+    if (stats) stats_out(ss, stats);
+    return PTL_OK;
+}
+extern "C" int ptl_icp_set_lazy_map_stats(ptl_icp* h, int32_t on) {
+    if (!h) return set_err(PTL_ERR_ARG, "null argument");
+    h->lazy_map_stats = on != 0;
+    return PTL_OK;
+}
 static void stats_out(const ScanStats& s, ptl_icp_stats* o) {
     o->sigma = s.sigma; o->err_dt = s.err_dt; o->err_drot = s.err_drot;
     o->iterations = s.iterations; o->n_corr_last = s.n_corr_last; o->n_in = s.n_in; o->n_valid = s.n_valid;
@@ -430,18 +472,7 @@ extern "C" int ptl_icp_register_frame(ptl_icp* h, const void* xyz, int dtype, in
                               dtype == PTL_F64 ? (const double*)h->d_in : nullptr, t01 ? h->d_t01 : nullptr, n,
                               guess ? h->d_ext : nullptr);
     if (rc) return rc;
-    if (h->ev_map_valid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_map, 0));  // map size is part of the row
-    k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);  // close the scan before its stats row is read back
-    const int64_t k = h->scans_done - 1;
-    double pose[16];
-    ScanStats ss;
-    HIPCHK(hipMemcpyAsync(pose, h->c.traj + 16 * k, sizeof pose, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&ss, h->c.sstats + k, sizeof ss, hipMemcpyDeviceToHost, h->stream));
-    rc = icp_check_flags(h);
-    if (rc) return rc;
-    if (out_pose) memcpy(out_pose, pose, sizeof pose);
-    if (stats) stats_out(ss, stats);
-    return PTL_OK;
+    return icp_percall_finish(h, out_pose, stats);
 }
 
 extern "C" int ptl_icp_num_poses(ptl_icp* h, int64_t* n) {
@@ -475,6 +506,7 @@ extern "C" int ptl_icp_map_size(ptl_icp* h, int64_t* voxels, int64_t* points) {
     if (!h) return set_err(PTL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     DevState st;
+    HIPCHK(hipStreamSynchronize(h->map_stream));  // (a map update may still be under way: lazy_map_stats, the sequence runner)
     HIPCHK(hipMemcpyAsync(&st, h->c.st, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (voxels) *voxels = st.n_live;
@@ -485,6 +517,7 @@ extern "C" int ptl_icp_map_points(ptl_icp* h, double* xyz_out, int64_t max_point
     if (!h || !xyz_out) return set_err(PTL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     double* d_out = nullptr;
+    HIPCHK(hipStreamSynchronize(h->map_stream));  // (a map update may still be under way)
     HIPCHK(dalloc(&d_out, (size_t)(max_points > 0 ? max_points : 1) * 3));
     HIPCHK(hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream));
     k_map_export<<<(h->c.pool_cap + 255) / 256, 256, 0, h->stream>>>(h->c, d_out, h->d_counter, (int)max_points);
@@ -809,18 +842,7 @@ extern "C" int ptl_icp_register_range(ptl_icp* h, ptl_lut* lut, const uint32_t* 
     if (guess) HIPCHK(hipMemcpyAsync(h->d_ext, guess, 16 * 8, hipMemcpyHostToDevice, h->stream));
     int rc = icp_enqueue_scan(h, nullptr, nullptr, nullptr, n, guess ? h->d_ext : nullptr, (const unsigned*)h->d_in, lut);
     if (rc) return rc;
-    if (h->ev_map_valid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_map, 0));
-    k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);
-    const int64_t k = h->scans_done - 1;
-    double pose[16];
-    ScanStats ss;
-    HIPCHK(hipMemcpyAsync(pose, h->c.traj + 16 * k, sizeof pose, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&ss, h->c.sstats + k, sizeof ss, hipMemcpyDeviceToHost, h->stream));
-    rc = icp_check_flags(h);
-    if (rc) return rc;
-    if (out_pose) memcpy(out_pose, pose, sizeof pose);
-    if (stats) stats_out(ss, stats);
-    return PTL_OK;
+    return icp_percall_finish(h, out_pose, stats);
 }
 
 // ------------------------------------------------------------------------------------------------ posed scans (flyby)

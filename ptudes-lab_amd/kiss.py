@@ -33,7 +33,7 @@ class _KissState:
 
 class KissICPWrapper:
     def __init__(self, metadata, *, _min_range: float = 5, _max_range: float = 100, _use_extrinsics: bool = False,
-                 device_id: int = 0, **icp_over):
+                 device_id: int = 0, lazy_map_stats: bool = False, **icp_over):
         self._metadata = metadata
         self._use_extrinsics = _use_extrinsics
         w = metadata.format.columns_per_frame
@@ -57,8 +57,10 @@ class KissICPWrapper:
         # per-pixel normalised time, reference kiss.py:34-35
         self._timestamps = np.tile(np.linspace(0, 1.0, w, endpoint=False), (h, 1))
         self._max_range, self._min_range = _max_range, _min_range
+        # lazy_map_stats: register_frame returns with the pose (what the reference's returns), the map update of the scan still under
+        # way on the device; the per-scan `stats` rows then carry no map size (core.Icp)
         self._icp = core.Icp(_max_range, _min_range, device_id=device_id, scan_cols=w,
-                             max_points_per_scan=max(h * w, 1024), **icp_over)
+                             max_points_per_scan=max(h * w, 1024), lazy_map_stats=lazy_map_stats, **icp_over)
         c = self._icp.cfg
         self._kiss_config = SimpleNamespace(
             data=SimpleNamespace(max_range=c.max_range, min_range=c.min_range, deskew=bool(c.deskew), preprocess=True),

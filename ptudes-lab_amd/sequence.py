@@ -17,12 +17,13 @@ from .kiss import KissICPWrapper
 
 
 def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use_imu_prediction=False,
-               guess_fn=None, logging=False, device_id=0, stats=None):
+               guess_fn=None, logging=False, device_id=0, stats=None, lazy_map_stats=True):
     """Returns dict(res_t, res_poses, kiss_poses, kiss_icp, ekf, timings).  `guess_fn(ts)` (optional) supplies an
     external guess (the reference's --use-gt-guess, ekf_bench.py:536-542); `stats` (optional) is the StreamStatsTracker
     the loop feeds (ekf_bench.py:497-499, :522-524), its time goes into timings["track"]."""
+    # (the loop reads poses only - ekf_bench.py:549-563: the registration need not wait for its map update, lazy_map_stats)
     kiss_icp = KissICPWrapper(metadata, _use_extrinsics=True, _min_range=kiss_min_range, _max_range=kiss_max_range,
-                              device_id=device_id)
+                              device_id=device_id, lazy_map_stats=lazy_map_stats)
     ekf = ESEKF(_logging=logging, device_id=device_id)
     res_t, res_poses, kiss_poses = [], [], []
     t_imu = t_corr = t_kiss = t_track = 0.0

@@ -93,6 +93,24 @@ def test_event_loop_equals_resident_runner(seq):
     assert np.abs(np.array(a["res_poses"]) - b["res_poses"]).max() < 1e-9
 
 
+def test_lazy_map_stats_gives_the_same_poses_without_waiting_for_the_map_update(seq):
+    """ptl_icp_set_lazy_map_stats: a registration returns when its pose is there, the map update still under way; poses and every
+    other statistic are those of the default mode, the rows carry no map size, ptl_icp_map_size gives it on demand"""
+    n = 6
+    meta = SimpleNamespace(format=SimpleNamespace(columns_per_frame=seq.W, pixels_per_column=seq.H))
+    a = KissICPWrapper(meta, _min_range=1.0, _max_range=70.0, lazy_map_stats=True)
+    b = KissICPWrapper(meta, _min_range=1.0, _max_range=70.0)
+    for k in range(n):
+        x = seq.scan(k)
+        Ta = a.register_frame(SimpleNamespace(xyz=x, ts=100.0 + 0.1 * k))
+        Tb = b.register_frame(SimpleNamespace(xyz=x, ts=100.0 + 0.1 * k))
+        assert np.array_equal(Ta, Tb), k
+        sa, sb = a.stats[-1], b.stats[-1]
+        assert (sa["map_voxels"], sa["map_points"]) == (-1, -1) and sb["map_voxels"] > 0
+        assert all(sa[q] == sb[q] for q in ("sigma", "err_dt", "err_drot", "iterations", "n_corr_last", "n_valid", "n_down", "n_src", "sum_cand"))
+    assert a._icp.map_size() == b._icp.map_size() == (b.stats[-1]["map_voxels"], b.stats[-1]["map_points"])
+
+
 def test_ouster_command_on_synthetic_writes_pose_files(tmp_path):
     fk, fn = tmp_path / "k.txt", tmp_path / "n.csv"
     res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "ouster", "--synthetic", "1002", "--end-scan", "5",
