@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GN_EVENT_EVERY = 8
-DEFAULT_SEQS = 192
+DEFAULT_SEQS = 240  # 30 per XCD on its 16 teams of 2: in the driver's 20-step form 33.9 k scans/s against 32.1 k for 192 (the end of the run is filled better), the same over 100 steps (profiles/r04_p_sequences_per_gpu.txt)
 PARITY_EXTRA_SEQS = 8     # sequences beside sequence 0 whose trajectories are checked against the oracle (single rank; all its threads)
 PARITY_EXTRA_SWEEPS = 40  # ... over their first sweeps
 DEFAULT_REPEATS = 3       # timed repeats of the K steps (>= 3, the median is reported)
@@ -320,7 +320,7 @@ def main():
                          "reports the median repeat (SURVEY.md 8(d)) and lists them all")
     ap.add_argument("--verify-all", action="store_true",
                     help="after the run: every sequence of the batch once more ALONE (single-sequence runner with a team's workgroup "
-                         "count) and compared bit for bit - minutes for 192 sequences")
+                         "count) and compared bit for bit - minutes for 240 sequences")
     ap.add_argument("--seqs-per-gpu", type=int, default=DEFAULT_SEQS,
                     help="independent sequences per GPU (SURVEY.md 8(e), second level), batched runner.  The sequences s = x (mod 8) "
                          "live on XCD x, whose teams of workgroups take their scans as they come free (--team-wgs).  1 = the "

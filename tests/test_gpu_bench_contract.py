@@ -104,9 +104,9 @@ def test_two_ranks_with_free_running_batches_share_the_gpu(tmp_path):
 
 @pytest.mark.gpu
 def test_bench_default_is_the_batched_runner():
-    """the driver's command (`--gpus 1 --steps 20 --warmup 5`, here with a short CPU budget): 192 independent sequences on the GPU
+    """the driver's command (`--gpus 1 --steps 20 --warmup 5`, here with a short CPU budget): 240 independent sequences on the GPU
     (seeds 1000..1191, 24 per XCD served by its 16 teams of 2 workgroups) in the free-running kernel (one persistent launch for
-    the timed steps), `value` = 192 scans per step; the roofline figure is the kernel's executed bytes and a fraction of the
+    the timed steps), `value` = 240 scans per step; the roofline figure is the kernel's executed bytes and a fraction of the
     peak, with the HBM traffic of a committed PMC pass of this workload beside it; sequence 0 and two more checked against
     the oracle inside the run"""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-budget", "3"],
@@ -115,16 +115,16 @@ def test_bench_default_is_the_batched_runner():
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 192 and d["config"]["sequence_seeds"].startswith("1000..1191")
+    assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 240 and d["config"]["sequence_seeds"].startswith("1000..1239")
     assert d["config"]["team_workgroups"] == 2 and d["config"]["teams"] == 128
-    assert abs(d["value"] - 192 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 240 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
     # three timed repeats, each one persistent launch for its 20 steps; the median is reported, all are listed,
     # and the repeats reproduce each other bit for bit
     rp = d["repeats"]
     assert rp["n"] == 3 and len(rp["values"]) == 3 and rp["reported"] == "median" and rp["bit_identical_trajectories"] is True
     assert sorted(rp["values"])[1] == pytest.approx(d["value"], rel=1e-9) and rp["spread_rel"] < 0.2
-    assert r["kernel"] == "kx_seq_run" and r["launches"] == 3 and r["scans_per_launch"] == 192 * 20
+    assert r["kernel"] == "kx_seq_run" and r["launches"] == 3 and r["scans_per_launch"] == 240 * 20
     assert r["executed_model_build"]["differs_from_default_build"] == [] and len(d["config"]["code_id"]) == 12
     sc = d["config"]["scheduling"]
     assert sc["cross_xcd_handovers"] >= 0 and sc["scans_run_by_a_team_of_another_xcd"] >= 0
@@ -171,14 +171,14 @@ def test_bench_under_the_launcher_gathers_over_rccl():
     s.close()
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8",
-                          "--warmup", "4", "--no-cpu-baseline"],  # the default 192 sequences: the gather's real tensor sizes
+                          "--warmup", "4", "--no-cpu-baseline"],  # the default 240 sequences: the gather's real tensor sizes
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, res.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 192
+    assert d["n_gpus"] == 1 and d["config"]["sequences_per_gpu"] == 240
     g = d["gathered_trajectories"]
-    assert g["sequences"] == 192 and g["rows_each"] == [12] and g["backend"].startswith("nccl")
+    assert g["sequences"] == 240 and g["rows_each"] == [12] and g["backend"].startswith("nccl")
     assert d["repeats"]["n"] == 3 and d["roofline"]["launches"] == 3
     assert "rendering" in res.stderr and "timed region" in res.stderr  # the per-rank start-up times a slow many-rank start is read from
