@@ -7,7 +7,7 @@
 // workgroups of an XCD form TEAMS (of 32, 16, 8, 4, 2 workgroups or one), and a team walks the whole per-scan pipeline of
 // one sequence by itself - reference cli/ekf_bench.py:493-563 loop body = kiss.py:83-131 + ESEKF.processPose / processImu:
 //
-//     whole team:          K0 prologue | K1 deskew + vds1 | K2 vds2 | K3 compact fd | K4 compact src
+//     whole team:          K0 prologue | K1 deskew + vds1 | K3 compact fd (look-back) | K3b vds2 on the compact frame_downsample | K4 compact src (look-back)
 //     whole team:          --- barrier ---  K5 Gauss-Newton loop (gn8_body)  --- barrier ---
 //     filter wg:           ES-EKF: update with the scan's pose, predict through the IMU samples before the next scan, K0 of the next scan
 //     whole team:          K7-K9 map insert a | b | c | K10 prune [| table reset | K11 rebuild]   (the filter workgroup joins when it is done)
@@ -88,7 +88,7 @@ __device__ __forceinline__ unsigned xcc_id() {
 #define SEQ_U 8  /* points per thread and pass in K1 and the map update (see Slice): 4 -> 8 took K0-K4 of a team of 2 from 1585 to 1406 us */
 #endif
 #ifndef SEQ_U2
-#define SEQ_U2 16  /* ... in K2-K4 (a few registers per point: an index, a slot, two flags); they share their block size through bcnt1 / bcnt2 */
+#define SEQ_U2 16  /* ... in K3 / K3b / K4 (a few registers per point: an index, a slot, two flags); they share their block size through bcnt1 / bcnt2 */
 #endif
 // make STAGES=1: workgroup 0 of every sequence adds the wall-clock ticks of every stage and of every barrier wait to
 // st->dbg_sums[0..19] (tools/free_vs_lockstep.py prints them)
