@@ -105,7 +105,7 @@ def test_two_ranks_with_free_running_batches_share_the_gpu(tmp_path):
 @pytest.mark.gpu
 def test_bench_default_is_the_batched_runner():
     """the driver's command (`--gpus 1 --steps 20 --warmup 5`, here with a short CPU budget): 240 independent sequences on the GPU
-    (seeds 1000..1191, 24 per XCD served by its 16 teams of 2 workgroups) in the free-running kernel (one persistent launch for
+    (seeds 1000..1239, 30 per XCD served by its 16 teams of 2 workgroups) in the free-running kernel (one persistent launch for
     the timed steps), `value` = 240 scans per step; the roofline figure is the kernel's executed bytes and a fraction of the
     peak, with the HBM traffic of a committed PMC pass of this workload beside it; sequence 0 and two more checked against
     the oracle inside the run"""
