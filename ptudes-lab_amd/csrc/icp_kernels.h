@@ -455,22 +455,8 @@ __device__ __forceinline__ RawF32<U> k1_load_raw(const Ctx& c, const Slice sl) {
     }
     return r;
 }
-// mcol: the thread's two column transforms, loaded once per scan by the caller (k1_columns_fixed) instead of once per pass here
-__device__ __forceinline__ bool k1_columns_fixed(const Ctx& c, int U) {
-    const int BS = (int)blockDim.x;  // (2 blockDim) % W == 0 and (U blockDim) % W == 0: the thread's points u, u + 2, ... of EVERY block lie in the column of u = 0, the odd ones in that of u = 1
-    return U > 2 && ((2 * BS) % c.W) == 0 && ((U * BS) % c.W) == 0;
-}
-__device__ __forceinline__ void k1_load_columns(const Ctx& c, Rt (&M)[2]) {
-    const int BS = (int)blockDim.x;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const double* m = c.coltab + (size_t)(((int)threadIdx.x + h * BS) % c.W);
-        for (int k = 0; k < 9; ++k) M[h].R[k] = m[(size_t)k * c.W];
-        for (int k = 0; k < 3; ++k) M[h].t[k] = m[(size_t)(9 + k) * c.W];
-    }
-}
 template <int U>
-__device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl, const RawF32<U>* pre = nullptr, int* wave_valid = nullptr, const Rt* mcol = nullptr) {
+__device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl, const RawF32<U>* pre = nullptr, int* wave_valid = nullptr) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     DevState* st = c.st;
 #ifdef SEQ_STAGE_CLOCKS
@@ -524,8 +510,7 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl, cons
                     // (2 blockDim) % W == 0 (512 threads, 1024 columns): the thread's points u, u + 2, ... lie in one column - its
                     // transform is loaded once for the even and once for the odd u instead of 12 words per point
                     Rt& M = (u & 1) ? Mcol[1] : Mcol[0];
-                    if (mcol) { if (u < 2) M = mcol[u & 1]; }
-                    else if (u < 2 || !col_period2) {
+                    if (u < 2 || !col_period2) {
                         const double* m = c.coltab + (size_t)(i % c.W);
                         for (int k = 0; k < 9; ++k) M.R[k] = m[(size_t)k * c.W];
                         for (int k = 0; k < 3; ++k) M.t[k] = m[(size_t)(9 + k) * c.W];

@@ -117,17 +117,13 @@ __device__ __noinline__ unsigned sq_prepare(const SeqCtx* a, int s, int k, int w
     if (c.in_f32 && !c.in_range) {  // (uniform) the next pass's raw points travel while this pass waits for its atomics
         RawF32<SEQ_U> raw;
         sl.b = wg;
-        // the thread's two column transforms are the same in every block: loaded once per scan (a dependent read per pass otherwise)
-        Rt Mcol[2];
-        const bool fixed_cols = st->do_deskew && !c.t01 && k1_columns_fixed(c, SEQ_U);
-        if (fixed_cols) k1_load_columns(c, Mcol);
         if (wg < nbs) raw = k1_load_raw<SEQ_U>(c, sl);
         for (sl.b = wg; sl.b < nbs; sl.b += nw) {
             const RawF32<SEQ_U> cur = raw;
             Slice nx = sl;
             nx.b = sl.b + nw;
             if (nx.b < nbs) raw = k1_load_raw<SEQ_U>(c, nx);
-            d_deskew_vds1<SEQ_U>(c, sl, &cur, &wave_valid, fixed_cols ? Mcol : nullptr);
+            d_deskew_vds1<SEQ_U>(c, sl, &cur, &wave_valid);
         }
     } else {
         for (sl.b = wg; sl.b < nbs; sl.b += nw) d_deskew_vds1<SEQ_U>(c, sl, nullptr, &wave_valid);
