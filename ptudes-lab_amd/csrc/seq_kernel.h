@@ -87,6 +87,9 @@ __device__ __forceinline__ unsigned xcc_id() {
 #ifndef SEQ_U
 #define SEQ_U 8  /* points per thread and pass in K1 and the map update (see Slice): 4 -> 8 took K0-K4 of a team of 2 from 1585 to 1406 us */
 #endif
+#ifndef SEQ_UM
+#define SEQ_UM SEQ_U  /* ... in the map update */
+#endif
 #ifndef SEQ_U2
 #define SEQ_U2 16  /* ... in K3 / K3b / K4 (a few registers per point: an index, a slot, two flags); they share their block size through bcnt1 / bcnt2 */
 #endif
@@ -174,26 +177,26 @@ __device__ __forceinline__ int sq_grab(unsigned* ctr) {
 __device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, int rebuild, unsigned* word, unsigned* ctr, bool local) {
     const Ctx c = load_seq_ctx(a, s, k);
     DevState* st = c.st;
-    const int BS = (int)blockDim.x, BU = BS * SEQ_U, nbd = (st->n_down_ins + BU - 1) / BU;
+    const int BS = (int)blockDim.x, BU = BS * SEQ_UM, nbd = (st->n_down_ins + BU - 1) / BU;
     Slice sl;
     sl.nb = nbd; sl.clk = 0;
     const TeamEnv te = {word, &st->gn_abort, st, local};
     SQ_CLK_DECL;
-    for (sl.b = sq_grab(ctr); sl.b < nbd; sl.b = sq_grab(ctr)) d_map_insert_a<SEQ_U>(c, c.fd, &st->n_down_ins, 0, 1, sl);
+    for (sl.b = sq_grab(ctr); sl.b < nbd; sl.b = sq_grab(ctr)) d_map_insert_a<SEQ_UM>(c, c.fd, &st->n_down_ins, 0, 1, sl);
     SQ_CLK(10);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(11);
-    for (sl.b = sq_grab(ctr + 1); sl.b < nbd; sl.b = sq_grab(ctr + 1)) d_map_insert_b<SEQ_U>(c, &st->n_down_ins, 0, sl);
+    for (sl.b = sq_grab(ctr + 1); sl.b < nbd; sl.b = sq_grab(ctr + 1)) d_map_insert_b<SEQ_UM>(c, &st->n_down_ins, 0, sl);
     SQ_CLK(12);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(13);
-    for (sl.b = sq_grab(ctr + 2); sl.b < nbd; sl.b = sq_grab(ctr + 2)) d_map_insert_c<SEQ_U>(c, &st->n_down_ins, 0, sl);
+    for (sl.b = sq_grab(ctr + 2); sl.b < nbd; sl.b = sq_grab(ctr + 2)) d_map_insert_c<SEQ_UM>(c, &st->n_down_ins, 0, sl);
     SQ_CLK(14);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(15);
     const int nbpu = (st->pool_hw + BU - 1) / BU;
     sl.nb = nbpu;
-    for (sl.b = sq_grab(ctr + 3); sl.b < nbpu; sl.b = sq_grab(ctr + 3)) d_map_prune<SEQ_U>(c, nullptr, 1, sl);
+    for (sl.b = sq_grab(ctr + 3); sl.b < nbpu; sl.b = sq_grab(ctr + 3)) d_map_prune<SEQ_UM>(c, nullptr, 1, sl);
     SQ_CLK(16);
     const int nbp = (st->pool_hw + BS - 1) / BS;
     sl.nb = nbp;
