@@ -2653,6 +2653,11 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
 #pragma unroll
     for (int u = 0; u < U; ++u)
         if (keyed[u] && slot[u] < 0) atomicOr(&st->err_flags, ERR_TABLE);
+    // the list pushes need the slot only - sent before the creation chain below (pool pop -> free-stack read -> header), whose round trips
+    // they then share instead of following them
+    int nx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) nx[u] = (slot[u] >= 0) ? atomicExch(&c.tab[slot[u]].head, idx[u]) : -1;
     {   // the new voxels take their blocks from the pool: every step for all U points at once (the pops, then the reads of the
         // free stack, then the headers) - step by step per point it is a chain of dependent memory round trips per u, and some
         // lane of a wavefront creates a voxel for nearly every u
@@ -2683,9 +2688,6 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
             if (used > (c.tmask + 1u) / 4u * 3u) atomicOr(&st->err_flags, ERR_TABLE);
         }
     }
-    int nx[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) nx[u] = (slot[u] >= 0) ? atomicExch(&c.tab[slot[u]].head, idx[u]) : -1;
 #pragma unroll
     for (int u = 0; u < U; ++u)
         if (act[u]) { c.pslot[idx[u]] = slot[u]; c.nxt[idx[u]] = nx[u]; }
@@ -2703,6 +2705,17 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
         rank[u] = 0; len[u] = 0; j[u] = -1; pb[u] = -1;
         if (slot[u] >= 0) { const TabEnt e = c.tab[slot[u]]; j[u] = e.head; pb[u] = e.blk; }
     }
+    // (what does not depend on the ranks - the voxel's stored count and the point itself - is requested before the walk and arrives during it)
+    int cnt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cnt[u] = (slot[u] >= 0 && pb[u] >= 0) ? blk_hdr(c, pb[u] & BLK_ID_MASK)[0] : 0;
+    double w[U][3];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = (size_t)idx[u];
+        w[u][0] = w[u][1] = w[u][2] = 0.0;
+        if (idx[u] < n && slot[u] >= 0 && pb[u] >= 0) { w[u][0] = c.fdw[3 * i]; w[u][1] = c.fdw[3 * i + 1]; w[u][2] = c.fdw[3 * i + 2]; }
+    }
     for (;;) {  // the U list walks step together: their reads of nxt[] are in flight at the same time
         bool any = false;
 #pragma unroll
@@ -2714,16 +2727,6 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (j[u] >= 0) { ++len[u]; rank[u] += (j[u] < idx[u]) ? 1 : 0; j[u] = nx[u]; }
-    }
-    int cnt[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) cnt[u] = (slot[u] >= 0 && pb[u] >= 0) ? blk_hdr(c, pb[u] & BLK_ID_MASK)[0] : 0;
-    double w[U][3];  // (requested for all U points before the first store: see d_compact_src)
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const size_t i = (size_t)idx[u];
-        const bool ins = idx[u] < n && slot[u] >= 0 && pb[u] >= 0 && cnt[u] + rank[u] < c.P;
-        if (ins) { w[u][0] = c.fdw[3 * i]; w[u][1] = c.fdw[3 * i + 1]; w[u][2] = c.fdw[3 * i + 2]; }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -2748,9 +2751,13 @@ __device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, i
     int idx[U], slot[U], pb[U], pl[U], cnt[U];
     bool first[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { idx[u] = base + u * BS; first[u] = idx[u] < n && c.prank[idx[u]] == 0; }
-#pragma unroll
-    for (int u = 0; u < U; ++u) { slot[u] = first[u] ? c.pslot[idx[u]] : -1; pl[u] = first[u] ? c.plen[idx[u]] : 0; }
+    for (int u = 0; u < U; ++u) {  // (rank, slot and list length of a point travel together: the latter two are used by the voxel's first point only)
+        idx[u] = base + u * BS;
+        const bool in = idx[u] < n;
+        const int pr = in ? c.prank[idx[u]] : -1, ps = in ? c.pslot[idx[u]] : -1, pn = in ? c.plen[idx[u]] : 0;
+        first[u] = in && pr == 0;
+        slot[u] = first[u] ? ps : -1; pl[u] = first[u] ? pn : 0;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) pb[u] = first[u] ? c.tab[slot[u]].blk : -1;
 #pragma unroll
