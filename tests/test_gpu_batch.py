@@ -172,6 +172,13 @@ def test_batch_rejects_missing_imu():
         b.upload_imu(0, np.zeros((4, 7)), [2, 2, 4])  # no IMU between scans 0 and 1
 
 
+def test_batch_that_does_not_fit_the_device_is_refused_with_the_numbers():
+    """ptl_batch_create adds up the batch's device memory before it allocates anything: 256 sequences with 8 M voxel
+    blocks each (4 GB of blocks per sequence) cannot fit 288 GB - a capacity error that says how much is needed and how much is free"""
+    with pytest.raises(RuntimeError, match=r"needs .* GB of device memory .* per sequence"):
+        core.BatchRunner(256, 2, 131072, 2, with_ekf=True, map_block_capacity=8 * 1024 * 1024)
+
+
 def test_batch_rejects_bad_workgroup_count():
     with pytest.raises(ValueError):
         core.BatchRunner(2, 3, 1024, 4, with_ekf=True, max_points_per_scan=1024, scan_cols=64, gn_workgroups=100)
