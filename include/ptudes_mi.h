@@ -326,7 +326,8 @@ int ptl_batch_sched_counters(ptl_batch *b, int32_t seq, uint64_t out[4]);
  * other than "all scans done" - 1 a teammate never reached the head-of-launch barrier, 2 ... the job barrier, 4 a team
  * found no work for its whole idle budget while sequences were pending, 8 a team gave up on a sequence (see that
  * sequence's error flags), 16 a sequence did not reach the last scan of a launch (it gets the time-out flag).
- * ptl_batch_wait returns PTL_ERR_CAPACITY for a flagged sequence and PTL_ERR_STATE for a non-zero status without one:
+ * ptl_batch_wait returns PTL_ERR_CAPACITY for a flagged sequence and PTL_ERR_STATE for a status without one (bit 4 alone -
+ * a team that only idled past its budget while every sequence reached its last scan - is reported here, not as an error):
  * no exit of the persistent kernel is silent. */
 int ptl_batch_status(ptl_batch *b, uint32_t *status);
 /* test hook: workgroup `block` of the free-running grid returns right before the job barrier of its `round`-th job of every
