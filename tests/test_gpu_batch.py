@@ -359,3 +359,54 @@ def test_one_handle_both_drivers_and_several_team_sizes():
         r.upload_imu(sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
         r.run()
         assert np.array_equal(b.results(3)["res_poses"], r.results()["res_poses"]) and b.results(3)["stats"] == r.results()["stats"], team
+
+
+def test_empty_and_nearly_empty_sweeps_inside_a_batch():
+    """ragged inputs through the look-back compactions of the free-running kernel: one sequence of the batch gets a sweep without a
+    single return, then a sweep with a handful of returns, then normal sweeps again (frame_downsample of 0 / a few entries: no block,
+    one block for K3b and K4).  Every sequence equals its run alone (whose stages are separate launches with counting passes) bit for
+    bit, and the disturbed one follows the oracle."""
+    from oracle import cpu as orc
+    S, n = 3, 7
+    seqs = [synth.make_sequence(seed=1750 + s, n_scans=n) for s in range(S)]
+    n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
+    sweeps = [[sq.scan(k).copy() for k in range(n)] for sq in seqs]
+    sweeps[1][2][:] = 0.0                      # no return at all
+    keep = np.zeros(len(sweeps[1][3]), dtype=bool)
+    keep[5000:5040] = True                     # forty returns of one beam
+    sweeps[1][3][~keep] = 0.0
+    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=True, with_ekf=True, team_workgroups=2)
+    singles = []
+    for s, sq in enumerate(seqs):
+        r = core.SeqRunner(n, sq.H * sq.W, n_imu, use_imu_prediction=True, with_ekf=True, gn_workgroups=2, gn_lanes_per_point=8, gn_threads=512)
+        ends = [sq.imu_range_for_scan(k)[1] for k in range(n)]
+        for k in range(n):
+            b.upload_scan(s, k, sweeps[s][k])
+            r.upload_scan(k, sweeps[s][k])
+        b.upload_imu(s, sq.imu[:n_imu], ends)
+        r.upload_imu(sq.imu[:n_imu], ends)
+        r.run()
+        singles.append(r.results())
+    b.run()
+    assert b.status() == 0
+    for s in range(S):
+        out = b.results(s)
+        assert np.array_equal(out["kiss_poses"], singles[s]["kiss_poses"]) and np.array_equal(out["res_poses"], singles[s]["res_poses"]), s
+        assert out["stats"] == singles[s]["stats"], s
+    st = b.results(1)["stats"]
+    assert st[2]["n_valid"] == 0 and st[2]["n_down"] == 0 and st[2]["n_src"] == 0 and st[2]["iterations"] == 0
+    assert 0 < st[3]["n_valid"] <= 40 and 0 < st[3]["n_src"] <= st[3]["n_down"] <= 40
+    assert st[4]["n_src"] > 1000 and st[4]["iterations"] > 0
+    # the disturbed sequence against the oracle (same sweeps, same IMU)
+    orc.set_threads(1)
+    icp, ekf = orc.ICP(max_range=seqs[1].max_range, min_range=seqs[1].min_range), orc.EKF()
+    t01 = seqs[1].column_times()
+    for k in range(n):
+        a, e = seqs[1].imu_range_for_scan(k)
+        for i in range(a, e):
+            ekf.process_imu(seqs[1].imu[i, 1:4], seqs[1].imu[i, 4:7], seqs[1].imu[i, 0])
+        pose = icp.register_frame(sweeps[1][k].astype(np.float64), t01, ekf.pose_mat())
+        ekf.process_pose(pose)
+        assert np.abs(b.results(1)["kiss_poses"][k] - pose).max() < 1e-9, k
+        assert all(st[k][q] == icp.stats[k][q] for q in _INT_STATS), (k, st[k], icp.stats[k])
+
