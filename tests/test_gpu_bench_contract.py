@@ -182,3 +182,17 @@ def test_bench_under_the_launcher_gathers_over_rccl():
     assert g["sequences"] == 240 and g["rows_each"] == [12] and g["backend"].startswith("nccl")
     assert d["repeats"]["n"] == 3 and d["roofline"]["launches"] == 3
     assert "rendering" in res.stderr and "timed region" in res.stderr  # the per-rank start-up times a slow many-rank start is read from
+
+
+@pytest.mark.gpu
+def test_bench_verify_all_compares_every_sequence_with_its_single_run():
+    """`--verify-all`: after the batched run every sequence is registered once more ALONE (single-sequence runner with a team's
+    workgroup count) and compared bit for bit - the whole batch, not a sample"""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--seqs-per-gpu", "20", "--team-wgs", "2", "--steps", "6", "--warmup", "3",
+                          "--repeats", "2", "--verify-all", "--no-cpu-baseline", "--no-single-sequence"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
+    assert d["config"]["sequences_per_gpu"] == 20 and d["config"]["team_workgroups"] == 2
+    assert d["verify_all"] == {"sequences": 20, "differ_from_their_single_runs": []}
+    assert d["repeats"]["n"] == 2 and d["repeats"]["bit_identical_trajectories"] is True
+
