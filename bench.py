@@ -350,6 +350,7 @@ def main():
     ap.add_argument("--voxel-size", type=float, default=0.0, help="override the map voxel size (default max_range/100)")
     ap.add_argument("--map-blocks", type=int, default=0, help="voxel-block pool capacity")
     ap.add_argument("--map-table", type=int, default=0, help="map hash-table slots (power of two)")
+    ap.add_argument("--rebuild-every", type=int, default=0, help="scans between two rebuilds of the map hash table (tombstones dropped; 0 = library default)")
     ap.add_argument("--workload-name", type=str, default="")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default LOCAL_RANK %% visible devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -420,6 +421,7 @@ def main():
     if args.voxel_size: icp_over["voxel_size"] = args.voxel_size
     if args.map_blocks: icp_over["map_block_capacity"] = args.map_blocks
     if args.map_table: icp_over["map_table_capacity"] = args.map_table
+    if args.rebuild_every: icp_over["rebuild_every"] = args.rebuild_every
     # rank r owns the sequences s with s % world == r, sequence s has seed seed_base + s - independent
     # sequences, nothing shared, no data-path collective.  They differ by up to 40 % in GN iterations per scan, so the
     # max-over-ranks clock of such a run is the slowest sequence's; --equal-work gives every rank a private copy of the

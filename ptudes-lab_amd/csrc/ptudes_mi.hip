@@ -91,9 +91,13 @@ extern "C" int ptl_icp_default_cfg(ptl_icp_cfg* cfg, double max_range, double mi
     cfg->scan_cols = 1024;
     cfg->max_points_per_scan = 131072;
     cfg->map_block_capacity = 1 << 19;
-    cfg->map_table_capacity = 1 << 21;
+    // The table is sparse on purpose: a 2 x 2 x 2 brick of voxels is one 128-byte line, and two bricks that hash to the same line push each other's
+    // entries into dependent probe rounds (probe-row rebuilds, map insert).  ~30 k occupied bricks in 2 M lines hardly ever meet; in the 262 k lines of
+    // round 3's 2^21 slots they did: Gauss-Newton 2 357 -> 2 196 us per scan, + 7 % scans/s (profiles/r04_y_map_table_and_rebuild.txt).  256 MB per
+    // sequence - what 288 GB per GPU are for.  The rebuild (tombstones dropped, table cleared by the team) is correspondingly rarer.
+    cfg->map_table_capacity = 1 << 24;
     cfg->gn_workgroups = 256;
-    cfg->rebuild_every = 16;
+    cfg->rebuild_every = 128;
     cfg->gn_threads = 1024;
     cfg->gn_lanes_per_point = 32;
     return PTL_OK;
@@ -220,8 +224,11 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     // per-scan voxel tables: 8 slots per point.  A table line holds a 2x2x2 brick of voxels (brick_slot), so what counts is how many
     // LINES are taken: at 2 slots per point a third of them were, and every voxel of a brick that landed on a taken line walked on
     // through dependent reads; the lines a scan touches do not depend on the table's size.
+#ifndef VDS_SLOTS_PER_POINT
+#define VDS_SLOTS_PER_POINT 8
+#endif
     size_t vcap = 1024;
-    while (vcap < (size_t)(8 * n)) vcap <<= 1;
+    while (vcap < (size_t)(VDS_SLOTS_PER_POINT * n)) vcap <<= 1;
     c.vmask = (unsigned)(vcap - 1);
     c.tmask = (unsigned)(cfg->map_table_capacity - 1);
     c.bstride = (int)(((size_t)c.P * 24 + 16 + 127) / 128 * 128);
@@ -278,7 +285,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
 static size_t icp_footprint_bytes(const ptl_icp_cfg* cfg) {
     const size_t n = (size_t)cfg->max_points_per_scan;
     size_t vcap = 1024;
-    while (vcap < 8 * n) vcap <<= 1;
+    while (vcap < VDS_SLOTS_PER_POINT * n) vcap <<= 1;
     const size_t bstride = ((size_t)cfg->max_points_per_voxel * 24 + 16 + 127) / 128 * 128;
     const size_t per_point = 24 + 4 + 4 + 24 * 2 + 24 + 24 + 24 + 4 * 4 + 8 + 128 + GN8_ANS_ROW * 8 + 24 + 8;
     return n * per_point + 2 * vcap * sizeof(VdsEnt) + (size_t)cfg->map_table_capacity * sizeof(TabEnt) +
