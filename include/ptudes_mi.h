@@ -336,10 +336,11 @@ int ptl_batch_debug_stall_block(ptl_batch *b, int32_t block, int32_t round);
 /* Environment: PTL_TEAM_SYNC=agent when the batch is created keeps the agent-scope release (L2 write-back) at every team
  * barrier of the free-running kernel instead of the XCD-local shortcut (same results; a diagnostic switch).
  *
- * Memory: one sequence of a batch holds ~736 B per point of points_per_scan of work buffers (two 8-slots-per-point voxel
- * tables, probe and answer rows, ...: 96 MB at 128x1024), map_table_capacity x 16 B (256 MB at the default 2^24 slots:
- * sparse on purpose, see ptl_icp_default_cfg), map_block_capacity x (block size + 4) B (512-B blocks at 20 points per
- * voxel: 256 MB at the default 512 k blocks) and its resident sweeps (n_scans x points_per_scan x 12 B): ~620 MB +
+ * Memory: one sequence of a batch holds 480 B per point of points_per_scan of work buffers (probe and answer rows, ...:
+ * 63 MB at 128x1024), its two per-scan voxel tables (64 and 16 slots of 16 B per point: 134 + 34 MB - sparse on purpose,
+ * a taken line costs a claim a dependent read), map_table_capacity x 16 B (256 MB at the default 2^24 slots: sparse for
+ * the same reason, see ptl_icp_default_cfg), map_block_capacity x (block size + 4) B (512-B blocks at 20 points per
+ * voxel: 256 MB at the default 512 k blocks) and its resident sweeps (n_scans x points_per_scan x 12 B): ~770 MB +
  * sweeps at the defaults.  ptl_batch_create checks the sum against
  * hipMemGetInfo and fails with PTL_ERR_CAPACITY and the numbers when it does not fit. */
 

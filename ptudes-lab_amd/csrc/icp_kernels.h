@@ -120,7 +120,7 @@ struct Ctx {
     double* pts;
     int *slot1, *slot2;
     VdsEnt *vtab1, *vtab2;
-    unsigned vmask;
+    unsigned vmask, vmask2;      // slots - 1 of the pass-1 / pass-2 per-scan voxel tables
     int *bcnt1, *bcnt2;
     double *fd, *src0, *src_cur, *fdw;
     double* coltab;  // [12][W] per-column deskew transforms (R row-major 9, t 3), entry-major
@@ -767,7 +767,7 @@ __device__ __forceinline__ void d_vds2_fd(const Ctx& c, const Slice sl) {
         const bool prev_act = __shfl_up(act[u] ? 1 : 0, 1) != 0;
         head[u] = act[u] && (lane == 0 || !prev_act || prev != key[u]);
     }
-    vds_claim_u<U>(c.vtab2, c.vmask, key, head, slot);
+    vds_claim_u<U>(c.vtab2, c.vmask2, key, head, slot);
     {
         int nh = 0;
 #pragma unroll

@@ -140,11 +140,23 @@ __global__ void k_state_init(DevState* st, int pool_cap) {
     st->dbg_dead_wg = -1;
 }
 
+// slots of a per-scan voxel table (power of two): make EXTRA="-DVDS1_SLOTS_PER_POINT=n -DVDS2_SLOTS_PER_POINT=m" for A/B runs
+#ifndef VDS1_SLOTS_PER_POINT
+#define VDS1_SLOTS_PER_POINT 64
+#endif
+#ifndef VDS2_SLOTS_PER_POINT
+#define VDS2_SLOTS_PER_POINT 16
+#endif
+static size_t vds_table_slots(size_t per_point, size_t n) {
+    size_t vcap = 1024;
+    while (vcap < per_point * n) vcap <<= 1;
+    return vcap;
+}
 static int icp_reset_device(ptl_icp* h) {
     Ctx& c = h->c;
-    const size_t vcap = (size_t)c.vmask + 1;
+    const size_t vcap = (size_t)c.vmask + 1, vcap2 = (size_t)c.vmask2 + 1;
     HIPCHK(hipMemsetAsync(c.vtab1, 0xFF, vcap * sizeof(VdsEnt), h->stream));  // (key = EMPTY, index = none)
-    HIPCHK(hipMemsetAsync(c.vtab2, 0xFF, vcap * sizeof(VdsEnt), h->stream));
+    HIPCHK(hipMemsetAsync(c.vtab2, 0xFF, vcap2 * sizeof(VdsEnt), h->stream));
     HIPCHK(hipMemsetAsync(c.tab, 0xFF, ((size_t)c.tmask + 1) * sizeof(TabEnt), h->stream));
     HIPCHK(hipMemsetAsync(c.blocks, 0, (size_t)c.pool_cap * c.bstride, h->stream));
     HIPCHK(hipMemsetAsync(c.bcnt1, 0, (size_t)h->nblk_scan * sizeof(int), h->stream));  // look-back words of the compactions: tag 0 = never published
@@ -221,15 +233,14 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     c.P = cfg->max_points_per_voxel; c.deskew = cfg->deskew; c.max_iter = cfg->max_iterations;
     c.W = cfg->scan_cols > 0 ? cfg->scan_cols : 1;
     c.n_max = (int)n;
-    // per-scan voxel tables: 8 slots per point.  A table line holds a 2x2x2 brick of voxels (brick_slot), so what counts is how many
-    // LINES are taken: at 2 slots per point a third of them were, and every voxel of a brick that landed on a taken line walked on
-    // through dependent reads; the lines a scan touches do not depend on the table's size.
-#ifndef VDS_SLOTS_PER_POINT
-#define VDS_SLOTS_PER_POINT 8
-#endif
-    size_t vcap = 1024;
-    while (vcap < (size_t)(VDS_SLOTS_PER_POINT * n)) vcap <<= 1;
+    // per-scan voxel tables.  A table line holds a 2x2x2 brick of voxels (brick_slot), so what counts is how many LINES are taken:
+    // a voxel of a brick that lands on a taken line walks on through dependent reads, and one such voxel among the 512 claims of a
+    // wavefront's round costs the wavefront another round trip.  The lines a scan touches do not depend on the table's size, the
+    // slots are released by the compaction that follows (no clear per scan): size costs footprint only.  Pass 1 (~46 k voxels of
+    // ~120 k points): 64 slots per point (K0-K4 516 -> 485 us per scan against 8; 32: 493); pass 2 (~14 k voxels): 16.
+    const size_t vcap = vds_table_slots(VDS1_SLOTS_PER_POINT, n), vcap2 = vds_table_slots(VDS2_SLOTS_PER_POINT, n);
     c.vmask = (unsigned)(vcap - 1);
+    c.vmask2 = (unsigned)(vcap2 - 1);
     c.tmask = (unsigned)(cfg->map_table_capacity - 1);
     c.bstride = (int)(((size_t)c.P * 24 + 16 + 127) / 128 * 128);
     c.pool_cap = (int)cfg->map_block_capacity;
@@ -240,7 +251,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     bool ok = true;
     ok &= dalloc(&c.pts, 3 * n) == hipSuccess;
     ok &= dalloc(&c.slot1, n) == hipSuccess && dalloc(&c.slot2, n) == hipSuccess;
-    ok &= dalloc(&c.vtab1, vcap) == hipSuccess && dalloc(&c.vtab2, vcap) == hipSuccess;
+    ok &= dalloc(&c.vtab1, vcap) == hipSuccess && dalloc(&c.vtab2, vcap2) == hipSuccess;
     ok &= dalloc(&c.bcnt1, h->nblk_scan) == hipSuccess && dalloc(&c.bcnt2, h->nblk_scan) == hipSuccess;
     ok &= dalloc(&c.fd, 3 * n) == hipSuccess && dalloc(&c.src0, 3 * n) == hipSuccess;
     h->fd_buf[0] = c.fd;
@@ -280,15 +291,13 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     return PTL_OK;
 }
 // device bytes one registration handle allocates (icp_create_impl above, term by term): per point of max_points_per_scan the work
-// buffers (deskewed points, slots, two 8-slots-per-point voxel tables, frame_down x 2, source x 2, world frame_down, list links,
+// buffers (deskewed points, slots, the two per-scan voxel tables, frame_down x 2, source x 2, world frame_down, list links,
 // probe rows, answer rows, the per-call input), plus the map table, the block pool and its free stack
 static size_t icp_footprint_bytes(const ptl_icp_cfg* cfg) {
     const size_t n = (size_t)cfg->max_points_per_scan;
-    size_t vcap = 1024;
-    while (vcap < VDS_SLOTS_PER_POINT * n) vcap <<= 1;
     const size_t bstride = ((size_t)cfg->max_points_per_voxel * 24 + 16 + 127) / 128 * 128;
     const size_t per_point = 24 + 4 + 4 + 24 * 2 + 24 + 24 + 24 + 4 * 4 + 8 + 128 + GN8_ANS_ROW * 8 + 24 + 8;
-    return n * per_point + 2 * vcap * sizeof(VdsEnt) + (size_t)cfg->map_table_capacity * sizeof(TabEnt) +
+    return n * per_point + (vds_table_slots(VDS1_SLOTS_PER_POINT, n) + vds_table_slots(VDS2_SLOTS_PER_POINT, n)) * sizeof(VdsEnt) + (size_t)cfg->map_table_capacity * sizeof(TabEnt) +
            (size_t)cfg->map_block_capacity * (bstride + 4) + (size_t)4096 * (128 + sizeof(ScanStats)) + (1u << 20);
 }
 extern "C" int ptl_icp_create(const ptl_icp_cfg* cfg, ptl_icp** out) { return icp_create_impl(cfg, nullptr, out); }
