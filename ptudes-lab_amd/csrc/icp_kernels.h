@@ -2705,10 +2705,11 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
         rank[u] = 0; len[u] = 0; j[u] = -1; pb[u] = -1;
         if (slot[u] >= 0) { const TabEnt e = c.tab[slot[u]]; j[u] = e.head; pb[u] = e.blk; }
     }
-    // (what does not depend on the ranks - the voxel's stored count and the point itself - is requested before the walk and arrives during it)
+    // (the voxel's stored count comes with the table entry - insert c / rebuild mirror it there, a new voxel's entry says 0 - and the point itself is
+    // requested before the walk and arrives during it)
     int cnt[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) cnt[u] = (slot[u] >= 0 && pb[u] >= 0) ? blk_hdr(c, pb[u] & BLK_ID_MASK)[0] : 0;
+    for (int u = 0; u < U; ++u) cnt[u] = (slot[u] >= 0 && pb[u] >= 0) ? (pb[u] >> 24) : 0;
     double w[U][3];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -2761,7 +2762,7 @@ __device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, i
 #pragma unroll
     for (int u = 0; u < U; ++u) pb[u] = first[u] ? c.tab[slot[u]].blk : -1;
 #pragma unroll
-    for (int u = 0; u < U; ++u) cnt[u] = (pb[u] >= 0) ? blk_hdr(c, pb[u] & BLK_ID_MASK)[0] : 0;
+    for (int u = 0; u < U; ++u) cnt[u] = (pb[u] >= 0) ? (pb[u] >> 24) : 0;  // the entry's mirror of the block's count: no dependent read of the header
     int added = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {

@@ -287,7 +287,9 @@ __device__ __forceinline__ int sched_pick(SeqSched* sc, int nslots, int k1, int*
         }
         if (!pending) return SCHED_DONE;
         if (best >= 0 && atomicCAS(&sc->busy[best], 0, 1) == 0) {
+#ifndef SCHED_NO_FENCE_EXPERIMENT  /* timing experiment only (results of migrated sequences are then undefined) */
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the team that ran the previous scan wrote
+#endif
             const int k = __hip_atomic_load(&sc->next_scan[best], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (k < k1) { *scan_out = k; return best; }
             __hip_atomic_store(&sc->busy[best], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (finished meanwhile)
@@ -298,9 +300,15 @@ __device__ __forceinline__ int sched_pick(SeqSched* sc, int nslots, int k1, int*
     return SCHED_RETRY;
 }
 __device__ __forceinline__ void sched_release(SeqSched* sc, int q, int next_scan) {
+#ifndef SCHED_NO_FENCE_EXPERIMENT
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (always the full release: the next scan may run on any team - any XCD as far as this protocol knows)
+#endif
     __hip_atomic_store(&sc->next_scan[q], next_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef SCHED_NO_FENCE_EXPERIMENT
     __hip_atomic_store(&sc->busy[q], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    __hip_atomic_store(&sc->busy[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 // a team that gives up on its sequence (abort word, poll budget) takes it off the schedule: nobody waits for its remaining scans
 __device__ __forceinline__ void sched_abandon(SeqSched* sc, int q, int k1) {
