@@ -75,13 +75,14 @@ EXEC_COST = {
     "vds_claim": 24,
     # per frame_down point: K3 reads the point (24), writes fd (24), releases the pass-1 slot (12); K3b reads fd (24), writes its pass-2 slot (4); K4 reads slot (4) + index (4);
     # map insert a: fd read (24), world point written (24), table key read (8), list push (4), slot + link written (8);
-    # b: slot (4) + table entry (16) + list walk (~8) + block header (4) + world point (24) read, block written (24), rank + length written (8);
-    # c: rank read (4)
-    "down_point": (24 + 24 + 12) + (24 + 4) + (4 + 4) + (24 + 24 + 8 + 4 + 8) + (4 + 16 + 8 + 4 + 24 + 24 + 8) + 4,
+    # b: slot (4) + table entry (16: the stored count comes with it) + list walk (~8) + world point (24) read, block written (24);
+    # c: none in the free-running kernel - the prune pass counts the batch in (round 4; before: rank + length written and read back, block header read)
+    "down_point": (24 + 24 + 12) + (24 + 4) + (4 + 4) + (24 + 24 + 8 + 4 + 8) + (4 + 16 + 8 + 24 + 24),
     # per source point: K4 reads + writes it (48) and releases its pass-2 slot (12)
     "source_point": 48 + 12,
-    # prune: header (8) + first point (24) of every block below the pool's high-water mark (~ live voxels)
-    "map_voxel": 32,
+    # prune: header (12) + first point (24) of every block below the pool's high-water mark (~ live voxels); the publish of a voxel the
+    # batch touched (header 8 + table entry 8) is not counted
+    "map_voxel": 36,
     # the per-column deskew table (12 doubles per column), written once per scan and read through the caches: counted once
     "scan_column": 96,
 }

@@ -2678,6 +2678,7 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
                 int* h = blk_hdr(c, blk[u]);
                 h[0] = 0;
                 h[1] = slot[u];
+                h[2] = 0;  // (points of a batch waiting to be counted in: FUSE form of insert b / prune)
                 atomicAdd(&st->n_live, 1);
                 atomicMax(&st->pool_hw, blk[u] + 1);
             } else {
@@ -2693,7 +2694,10 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
         if (act[u]) { c.pslot[idx[u]] = slot[u]; c.nxt[idx[u]] = nx[u]; }
 }
 // phase b: rank among this batch's points of the same voxel (by scan order) -> slot in the block
-template <int U>
+// FUSE (the free-running kernel, where the prune pass always follows): the voxel's first point of the batch leaves the batch's
+// length in the block header, and the prune pass - which reads every live header anyway - counts it in, mirrors the count in
+// the table entry and resets the list: phase c, its pass over the points with two dependent reads and its barrier are gone.
+template <int U, bool FUSE = false>
 __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, int n_fixed, const Slice sl) {
     const int n = n_ptr ? *n_ptr : n_fixed;
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
@@ -2704,6 +2708,10 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
     for (int u = 0; u < U; ++u) {
         rank[u] = 0; len[u] = 0; j[u] = -1; pb[u] = -1;
         if (slot[u] >= 0) { const TabEnt e = c.tab[slot[u]]; j[u] = e.head; pb[u] = e.blk; }
+        // FUSE: a voxel without a block (the pool ran out: ERR_POOL) never shows up in the prune pass - its points need no rank, so each of
+        // them resets the batch list itself (the others either saw the list and drop it here too, or see it empty).  A list left
+        // standing would be pushed onto by the next scan and walked in circles.
+        if (FUSE && slot[u] >= 0 && pb[u] < 0) { c.tab[slot[u]].head = -1; j[u] = -1; }
     }
     // (the voxel's stored count comes with the table entry - insert c / rebuild mirror it there, a new voxel's entry says 0 - and the point itself is
     // requested before the walk and arrives during it)
@@ -2717,7 +2725,8 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
         w[u][0] = w[u][1] = w[u][2] = 0.0;
         if (idx[u] < n && slot[u] >= 0 && pb[u] >= 0) { w[u][0] = c.fdw[3 * i]; w[u][1] = c.fdw[3 * i + 1]; w[u][2] = c.fdw[3 * i + 2]; }
     }
-    for (;;) {  // the U list walks step together: their reads of nxt[] are in flight at the same time
+    for (int steps = 0;; ++steps) {  // the U list walks step together: their reads of nxt[] are in flight at the same time
+        if (steps > n) { atomicOr(&c.st->err_flags, ERR_TABLE); break; }  // (a list longer than the batch: corrupted links must not hang the launch)
         bool any = false;
 #pragma unroll
         for (int u = 0; u < U; ++u) any = any || j[u] >= 0;
@@ -2733,10 +2742,13 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
     for (int u = 0; u < U; ++u) {
         if (idx[u] >= n) continue;
         const size_t i = (size_t)idx[u];
-        if (slot[u] < 0) { c.prank[i] = -1; continue; }
-        c.prank[i] = rank[u];
-        c.plen[i] = len[u];
-        if (pb[u] < 0) continue;
+        if (!FUSE) {
+            if (slot[u] < 0) { c.prank[i] = -1; continue; }
+            c.prank[i] = rank[u];
+            c.plen[i] = len[u];
+        }
+        if (slot[u] < 0 || pb[u] < 0) continue;
+        if (FUSE && rank[u] == 0) blk_hdr(c, pb[u] & BLK_ID_MASK)[2] = len[u];
         const int pos = cnt[u] + rank[u];
         if (pos < c.P) {
             double* X = blk_x(c, pb[u] & BLK_ID_MASK);
@@ -2785,7 +2797,8 @@ __device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, i
 
 // ------------------------------------------------------------------------------------------------ K10
 // RemovePointsFarFromLocation: a voxel goes when its FIRST point is farther than max_range from the origin
-template <int U>
+// FUSE: ... and counts in what insert b left in the headers (see there)
+template <int U, bool FUSE = false>
 __device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_xyz, int use_new_pose, const Slice sl) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     DevState* st = c.st;
@@ -2793,33 +2806,49 @@ __device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_x
     double ox, oy, oz;
     if (use_new_pose) { ox = st->new_pose[3]; oy = st->new_pose[7]; oz = st->new_pose[11]; }
     else { ox = origin_xyz[0]; oy = origin_xyz[1]; oz = origin_xyz[2]; }
-    int cnt[U], hs[U];
+    int cnt[U], hs[U], add[U];
     double x0[U], y0[U], z0[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int b = base + u * BS;
-        cnt[u] = 0; hs[u] = -1; x0[u] = y0[u] = z0[u] = 0.0;
+        cnt[u] = 0; hs[u] = -1; add[u] = 0; x0[u] = y0[u] = z0[u] = 0.0;
         if (b < hw) {
             const int* h = blk_hdr(c, b);
             cnt[u] = h[0]; hs[u] = h[1];
+            if (FUSE) add[u] = h[2];
             const double* X = blk_x(c, b);
             x0[u] = X[0]; y0[u] = X[1]; z0[u] = X[2];  // (read whether or not the block is live: no dependent round trip)
         }
     }
+    long long added = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        if (cnt[u] <= 0) continue;
+        int nc = cnt[u];
+        if (FUSE && add[u] > 0) { nc += add[u]; if (nc > c.P) nc = c.P; }
+        if (nc <= 0) continue;
         const int b = base + u * BS;
         const double dx = x0[u] - ox, dy = y0[u] - oy, dz = z0[u] - oz;
         if (dx * dx + dy * dy + dz * dz > c.max_range * c.max_range) {
             c.tab[hs[u]].key = TOMB_KEY;
             c.tab[hs[u]].blk = -1;
             blk_hdr(c, b)[0] = 0;
+            if (FUSE && add[u] > 0) { blk_hdr(c, b)[2] = 0; c.tab[hs[u]].head = -1; }
             const int top = atomicAdd(&st->free_top, 1);
             if (top >= 0 && top < c.pool_cap) c.free_stack[top] = b;
             atomicSub(&st->n_live, 1);
-            atomicAdd((unsigned long long*)&st->map_points, (unsigned long long)(-(long long)cnt[u]));
+            if (FUSE) added -= cnt[u];  // (what this batch brought was never counted)
+            else atomicAdd((unsigned long long*)&st->map_points, (unsigned long long)(-(long long)cnt[u]));
+        } else if (FUSE && add[u] > 0) {  // what insert c does in the other drivers: publish the new count, reset the batch list
+            int* h = blk_hdr(c, b);
+            h[0] = nc; h[2] = 0;
+            c.tab[hs[u]].head = -1;
+            c.tab[hs[u]].blk = b | (nc << 24);  // the table entry mirrors the count so a probe returns both
+            added += nc - cnt[u];
         }
+    }
+    if (FUSE) {  // one atomic per wavefront (see insert c)
+        for (int o = 32; o > 0; o >>= 1) added += __shfl_xor(added, o);
+        if ((threadIdx.x & 63) == 0 && added != 0) atomicAdd((unsigned long long*)&c.st->map_points, (unsigned long long)added);
     }
 }
 

@@ -186,17 +186,15 @@ __device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, in
     SQ_CLK(10);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(11);
-    for (sl.b = sq_grab(ctr + 1); sl.b < nbd; sl.b = sq_grab(ctr + 1)) d_map_insert_b<SEQ_UM>(c, &st->n_down_ins, 0, sl);
+    for (sl.b = sq_grab(ctr + 1); sl.b < nbd; sl.b = sq_grab(ctr + 1)) d_map_insert_b<SEQ_UM, true>(c, &st->n_down_ins, 0, sl);
     SQ_CLK(12);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(13);
-    for (sl.b = sq_grab(ctr + 2); sl.b < nbd; sl.b = sq_grab(ctr + 2)) d_map_insert_c<SEQ_UM>(c, &st->n_down_ins, 0, sl);
-    SQ_CLK(14);
-    if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
+    SQ_CLK(14);  // (phase c is part of the prune pass here: d_map_insert_b / d_map_prune, FUSE)
     SQ_CLK(15);
     const int nbpu = (st->pool_hw + BU - 1) / BU;
     sl.nb = nbpu;
-    for (sl.b = sq_grab(ctr + 3); sl.b < nbpu; sl.b = sq_grab(ctr + 3)) d_map_prune<SEQ_UM>(c, nullptr, 1, sl);
+    for (sl.b = sq_grab(ctr + 3); sl.b < nbpu; sl.b = sq_grab(ctr + 3)) d_map_prune<SEQ_UM, true>(c, nullptr, 1, sl);
     SQ_CLK(16);
     const int nbp = (st->pool_hw + BS - 1) / BS;
     sl.nb = nbp;
@@ -275,40 +273,42 @@ __global__ void k_sched_check(const SeqCtx* a, const SeqSched* sc, int S, int k1
 #define SCHED_DONE (-1)
 #define SCHED_RETRY (-2)
 #define SCHED_POLLS 256
+// (the FIRST WAVEFRONT of the leader workgroup asks: lane q reads slot q - one memory round trip for the whole table instead of up
+// to two per slot one after the other by a single lane, at agent scope each; the choice is the serial loop's: fewest scans done,
+// lowest slot on a tie.  Lane 0 takes the slot; every lane returns the same answer.)
 __device__ __forceinline__ int sched_pick(SeqSched* sc, int nslots, int k1, int* scan_out, unsigned max_polls = SCHED_POLLS) {
+    const int lane = (int)(threadIdx.x & 63u);
     for (unsigned polls = 0; polls < max_polls; ++polls) {
-        int best = -1, bestk = 0x7FFFFFFF;
-        bool pending = false;
-        for (int q = 0; q < nslots; ++q) {
-            const int k = __hip_atomic_load(&sc->next_scan[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k >= k1) continue;
-            pending = true;
-            if (k < bestk && __hip_atomic_load(&sc->busy[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { best = q; bestk = k; }
+        int k = k1, busy = 1;
+        if (lane < nslots) {
+            k = __hip_atomic_load(&sc->next_scan[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            busy = __hip_atomic_load(&sc->busy[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (!pending) return SCHED_DONE;
-        if (best >= 0 && atomicCAS(&sc->busy[best], 0, 1) == 0) {
-#ifndef SCHED_NO_FENCE_EXPERIMENT  /* timing experiment only (results of migrated sequences are then undefined) */
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the team that ran the previous scan wrote
-#endif
-            const int k = __hip_atomic_load(&sc->next_scan[best], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k < k1) { *scan_out = k; return best; }
-            __hip_atomic_store(&sc->busy[best], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (finished meanwhile)
-            continue;
+        const bool pend = k < k1;
+        if (__ballot(pend) == 0ull) return SCHED_DONE;
+        unsigned key = (pend && busy == 0) ? (((unsigned)k << 6) | (unsigned)lane) : 0xFFFFFFFFu;
+        for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+        if (key != 0xFFFFFFFFu) {
+            const int best = (int)(key & 63u);
+            int res = -3, kk = 0;  // -3: the slot went to somebody else / finished meanwhile - look again
+            if (lane == 0 && atomicCAS(&sc->busy[best], 0, 1) == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the team that ran the previous scan wrote
+                kk = __hip_atomic_load(&sc->next_scan[best], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (kk < k1) res = best;
+                else __hip_atomic_store(&sc->busy[best], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (finished meanwhile)
+            }
+            res = __shfl(res, 0); kk = __shfl(kk, 0);
+            if (res >= 0) { *scan_out = kk; return res; }
+            continue;  // (lost the swap, or the slot was done: the table has changed - look again straight away)
         }
         __builtin_amdgcn_s_sleep(16);
     }
     return SCHED_RETRY;
 }
 __device__ __forceinline__ void sched_release(SeqSched* sc, int q, int next_scan) {
-#ifndef SCHED_NO_FENCE_EXPERIMENT
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (always the full release: the next scan may run on any team - any XCD as far as this protocol knows)
-#endif
     __hip_atomic_store(&sc->next_scan[q], next_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifndef SCHED_NO_FENCE_EXPERIMENT
     __hip_atomic_store(&sc->busy[q], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    __hip_atomic_store(&sc->busy[q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 // a team that gives up on its sequence (abort word, poll budget) takes it off the schedule: nobody waits for its remaining scans
 __device__ __forceinline__ void sched_abandon(SeqSched* sc, int q, int k1) {
@@ -364,8 +364,8 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_seq_run(const SeqC
     int round = 0;
     const unsigned my_xcc = xcc_id();
     for (;;) {
-        if (lead) {  // hand the finished scan back, take the next job
-            if (q_mine >= 0) sched_release(sched + x_mine, q_mine, k_mine + 1);
+        if (wg == 0 && threadIdx.x < 64u) {  // the leader workgroup's first wavefront: hand the finished scan back (lane 0), take the next job
+            if (lead && q_mine >= 0) sched_release(sched + x_mine, q_mine, k_mine + 1);
             int k = 0, xs = x;
             int q = sched_pick(sc, nslots, r.k1, &k, 16u);  // (a short wait at home, then a look at the neighbours, then round the team barrier and again)
             if (q < 0) {
@@ -383,9 +383,11 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_seq_run(const SeqC
                 if (q < 0) q = all_done ? SCHED_DONE : SCHED_RETRY;
             }
             q_mine = q; k_mine = k; x_mine = xs;
-            __hip_atomic_store(&tb[40], q == SCHED_DONE ? JOB_DONE : q == SCHED_RETRY ? JOB_RETRY : (unsigned)(xs + 8 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&tb[41], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int i = 0; i < 5; ++i) __hip_atomic_store(&tb[44 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the map update's block counters
+            if (lead) {
+                __hip_atomic_store(&tb[40], q == SCHED_DONE ? JOB_DONE : q == SCHED_RETRY ? JOB_RETRY : (unsigned)(xs + 8 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&tb[41], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < 5; ++i) __hip_atomic_store(&tb[44 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the map update's block counters
+            }
         }
         if ((int)blockIdx.x == r.dbg_dead_block && round == r.dbg_dead_round) return;  // test hook: a workgroup that dies between two scans
         ++round;
