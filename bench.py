@@ -32,6 +32,7 @@ DEFAULT_REPEATS = 3       # timed repeats of the K steps (>= 3, 
 GATHER_TIMEOUT_S = 120
 CPU_MIN_SWEEPS = 300  # sweeps offered to the CPU baseline (it stops at its time budget)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_COPY_RATE = 6.29e12  # B/s a streaming copy reaches on MI355X (same guide)
 
 
 def icp_bytes(stats):
@@ -380,35 +381,25 @@ def main():
         args.team_wgs = default_team_wgs(args.seqs_per_gpu)
     multi = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # a rank of a multi-process run
     dist = None
-    torch = None
     ctl = None
-    if multi:
-        # torch FIRST: it bundles its own HIP runtime, and libptudes_mi.so (linked against the system's) has to find that
-        # one already loaded - the other order puts two runtimes into the process and torch then sees no GPU
-        import datetime
-        import torch
-        import torch.distributed as dist
-        n_dev = torch.cuda.device_count()  # (does not initialise a device)
+    # the product library FIRST, on the system's HIP runtime - the runtime every single-rank run uses.  torch comes in afterwards and for
+    # the CONTROL PLANE only (a gloo group: barriers, the max-over-ranks clock, the 128 bytes of the RCCL id); it never touches a GPU
+    # here, so whichever HIP runtime it finds mapped is of no consequence.  The one collective of the path - the trajectory gather - is
+    # the library's own (ptl_comm_* / ptl_batch_gather_trajectories: ncclAllGather from librccl).
     import ptudes_lab_amd  # noqa: F401
     from ptudes_lab_amd import _lib, core, synth
-    if not multi:
-        n_dev = _lib.lib().ptl_device_count()  # (hipGetDeviceCount: does not initialise a device)
+    n_dev = _lib.lib().ptl_device_count()  # (hipGetDeviceCount: does not initialise a device)
     if n_dev < 1:
         sys.exit("bench.py: no HIP device - the HIP path is the only path")
     local_rank = (int(os.environ.get("LOCAL_RANK", "0")) % n_dev) if args.device < 0 else args.device
-    shared_device = world > n_dev  # several ranks on one GPU (1-GPU box): RCCL refuses duplicate devices, the gather goes over gloo
+    shared_device = world > n_dev  # several ranks on one GPU (1-GPU box): RCCL refuses duplicate devices, the gather goes through host rows over gloo
     if multi:
-        # RCCL carries the one collective of the path, the trajectory gather after the run.  Its communicator is brought
-        # up there and not before: a live RCCL communicator in the process stretches the cross-stream hand-overs of the
-        # scan pipeline from 63 to 110 us per scan (2700 -> 2400 scans/s, measured with one rank).  Barriers and the
-        # max-over-ranks clock go through a host-side gloo group.
-        if shared_device:
-            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
-            ctl = dist.group.WORLD
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", timeout=datetime.timedelta(seconds=600))
-            ctl = dist.new_group(backend="gloo")
+        import datetime
+        import torch.distributed as dist
+        # The RCCL communicator is brought up AFTER the timed region (a live communicator in the process stretched the cross-stream
+        # hand-overs of the single-sequence pipeline from 63 to 110 us per scan, measured with one rank in round 1).
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+        ctl = dist.group.WORLD
 
     K, W, S = args.steps, args.warmup, args.seqs_per_gpu
     n_total = W + K
@@ -478,9 +469,7 @@ def main():
             dist.barrier(group=ctl)
 
     def sync():
-        if torch is not None and not shared_device:
-            torch.cuda.synchronize()
-        core.device_sync(local_rank)
+        core.device_sync(local_rank)  # hipDeviceSynchronize on this rank's device: every stream of the runner
 
     # HIP events around every 8th launch of the dominant kernel: two event records per scan cost ~18 us (4 %) of
     # command-processor time on the critical path
@@ -560,9 +549,9 @@ def main():
     n_timed = sum(len(o["stats"]) - W for o in outs)
     assert n_timed == K * S, (n_timed, K, S)
 
-    # final trajectory gather: the only collective (T x 8 NC-GT rows per sequence, RCCL all-gather; gloo when several
-    # ranks share one GPU, which RCCL refuses).  It runs after the timed region and brings the RCCL communicator up; a
-    # failure or a stall there is reported in the line AND in the exit code.
+    # final trajectory gather: the only collective (T x 8 NC-GT rows per sequence: the library's ncclAllGather, device rows in, host
+    # rows out; host rows over gloo when several ranks share one GPU, which RCCL refuses).  It runs after the timed region and brings
+    # the RCCL communicator up; a failure or a stall there is reported in the line AND in the exit code.
     gathered, gather_err = None, None
     if dist is not None and with_ekf:
         import threading
@@ -572,6 +561,7 @@ def main():
         def _gather():
             try:
                 if shared_device:
+                    import torch
                     rows = torch.zeros((S, n_total, 8), dtype=torch.float64)
                     counts = []
                     for j in range(S):
@@ -580,10 +570,13 @@ def main():
                         rows[j, : counts[-1]] = torch.from_numpy(parallel.poses_to_rows(o["res_t"], o["res_poses"]))
                     box["out"] = parallel.gather_trajectories(rows, counts, dist)
                 else:
-                    torch.cuda.set_device(local_rank)
-                    rows = torch.zeros((S, n_total, 8), dtype=torch.float64, device="cuda")
-                    counts = [runner.copy_traj(j, rows[j].data_ptr(), n_total) for j in range(S)]
-                    box["out"] = parallel.gather_trajectories(rows, counts, dist)
+                    comm = parallel.Comm.over(dist, ctl, device_id=local_rank)  # rank 0 makes the id, gloo carries it, everybody joins
+                    if S == 1:
+                        ptr, n_rows = runner.r.traj_device()
+                        box["out"] = comm.gather_rows(ptr, 1, n_total, [min(n_rows, n_total)])
+                    else:
+                        box["out"] = comm.gather_batch(runner)
+                    comm.close()
             except Exception as e:  # noqa: BLE001
                 box["err"] = repr(e)
 
@@ -623,12 +616,21 @@ def main():
             # what the kernel itself requested from memory (EXEC_COST x its own counters): the roofline figure of the line
             avg_exec = R * exec_bytes / launches
             achieved = avg_exec / avg_gn_s if avg_gn_s > 0 else 0.0
+        exec_achieved = achieved  # executed-byte model (free-running) / algorithmic bytes (the per-launch kernels)
+        fresh_pmc = bool(pmc) and not pmc[2] and avg_gn_s > 0
+        if fresh_pmc:  # a counter pass of THIS workload on THIS build's kernel sources: what the memory system moved is the roofline figure
+            achieved = pmc[0] / avg_gn_s
         roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
-                "frac_kind": ("executed bytes: every load / store the kernel issued, at the width requested (bench.py EXEC_COST x the "
-                              "kernel's own counters, DESIGN.md 3) / launch time / peak" if free else
+                "frac_of_copy_rate": achieved / HBM_COPY_RATE,
+                "frac_kind": ("HBM traffic of the dominant kernel (rocprofv3 PMC pass of this workload on this build's kernel sources, profiles/" + pmc[1] +
+                              ": 2 x FETCH_SIZE + WRITE_SIZE, corrected as the guide prescribes) / launch time (HIP events, this run) / peak; "
+                              "frac_of_copy_rate: / the 6.29 TB/s a streaming copy reaches on this part" if fresh_pmc else
+                              "executed bytes: every load / store the kernel issued, at the width requested (bench.py EXEC_COST x the "
+                              "kernel's own counters, DESIGN.md 3) / launch time / peak - no counter pass of this build and workload is committed" if free else
                               "algorithmic bytes of SURVEY 8(d) (27 probes x 16 B + every candidate x 12 B + the source, per iteration) / "
                               "launch time / peak; the kernel prunes the search exactly and skips ~3/4 of the candidate bytes"),
+                "executed_frac": (exec_achieved / HBM_PEAK) if free else None,
                 "algorithmic_frac": alg_frac, "algorithmic_bytes_per_launch": avg_gn_bytes,
                 "executed_bytes_per_launch": (R * exec_bytes / launches) if free else None,
                 "executed_model_build": ({"info": core.build_info(), "differs_from_default_build": exec_notes} if free else None),
@@ -644,8 +646,8 @@ def main():
                 "scans_per_launch": scans_per_launch_mean,
                 "timed_launches": (f"all {gn_n} persistent launches of the {R} x {K} timed steps (HIP events)" if free else
                                    f"every {ev_every}th of {R} x {K} (HIP events)"),
-                "note": ("the free-running kernel carries the WHOLE per-scan pipeline of every sequence.  frac = executed bytes / launch time "
-                         "/ peak; algorithmic_frac = B_scan of SURVEY 8(d) (brute-force 27-voxel search) the same way - above 1 because the "
+                "note": ("the free-running kernel carries the WHOLE per-scan pipeline of every sequence.  frac = measured HBM traffic / launch time "
+                         "/ peak when a counter pass of this build exists (else = executed_frac); executed_frac = executed bytes / launch time / peak; algorithmic_frac = B_scan of SURVEY 8(d) (brute-force 27-voxel search) the same way - above 1 because the "
                          "answer cache settles most point-iterations without the probes and candidate reads that formula charges; "
                          "traffic = HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE) of a committed pass of this workload, per scan x this run's "
                          "scans per launch; measured_frac = traffic / launch time / peak.  FETCH_SIZE counts what the L2s request from the "
@@ -763,7 +765,8 @@ def main():
             one.close()
         if gathered is not None:
             line["gathered_trajectories"] = {"sequences": len(gathered), "rows_each": sorted({len(v) for v in gathered.values()}),
-                                             "backend": "gloo (ranks share a GPU; RCCL refuses duplicate devices)" if shared_device else "nccl (RCCL)"}
+                                             "backend": "gloo, host rows (ranks share a GPU; RCCL refuses duplicate devices)" if shared_device
+                                                        else "RCCL ncclAllGather through libptudes_mi.so (ptl_batch_gather_trajectories), id over gloo"}
             if args.dump_traj:
                 np.savez(args.dump_traj, **{f"rank{r}_seq{j}": v for (r, j), v in gathered.items()},
                          seeds=np.array([[r, j, args.seed_base + (j if args.equal_work else r + world * j)] for (r, j) in gathered]))

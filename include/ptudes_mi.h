@@ -333,6 +333,9 @@ int ptl_batch_status(ptl_batch *b, uint32_t *status);
 /* test hook: workgroup `block` of the free-running grid returns right before the job barrier of its `round`-th job of every
  * launch from now on (0 = the first); block < 0 switches it off */
 int ptl_batch_debug_stall_block(ptl_batch *b, int32_t block, int32_t round);
+/* test hook: points per thread and pass of the free-running kernel's map update (reference kiss.py:129) - 0 = only ask, else the
+ * build's default (8) or its second instance (4); *points_out = the value in effect.  Results must not depend on it. */
+int ptl_batch_debug_set_map_points_per_thread(ptl_batch *b, int32_t points, int32_t *points_out);
 /* Environment: PTL_TEAM_SYNC=agent when the batch is created keeps the agent-scope release (L2 write-back) at every team
  * barrier of the free-running kernel instead of the XCD-local shortcut (same results; a diagnostic switch).
  *
@@ -351,6 +354,26 @@ int ptl_batch_debug_stall_block(ptl_batch *b, int32_t block, int32_t round);
  * [9] chunks phase A requests ahead, [10] 1000 x the pruning margin, [11] / [12] bytes per map-table / voxel-table
  * entry, [13] 1 when diagnostic clocks are compiled in. */
 int ptl_build_info(int32_t out[16]);
+
+/* ---- multi-GPU: the final trajectory gather.  The reference has no distributed layer; the path shards
+ * across independent sequences only (one rank per GPU, no data-path collective) and its ONE collective is the all-gather of every
+ * rank's NC-GT rows [t, x, y, z, qx, qy, qz, qw] (reference utils.py:191-252 writes such rows) after the run: ncclAllGather straight
+ * from librccl (opened on first use; PTL_RCCL_PATH overrides the search), RCCL over xGMI on the node.
+ * The library does no bootstrap: ONE rank calls ptl_comm_unique_id, the caller carries the PTL_COMM_ID_BYTES bytes to the other ranks
+ * (environment, file, gloo / MPI / TCP - its business), EVERY rank then calls ptl_comm_create (collective: returns when all have). */
+#define PTL_COMM_ID_BYTES 128
+typedef struct ptl_comm ptl_comm;
+int ptl_comm_unique_id(uint8_t id[PTL_COMM_ID_BYTES]);
+int ptl_comm_create(const uint8_t id[PTL_COMM_ID_BYTES], int32_t world, int32_t rank, int32_t device_id, ptl_comm **out);
+int ptl_comm_destroy(ptl_comm *c);
+/* Every rank: d_rows = S x T x 8 doubles in DEVICE memory (sequence-major, rows beyond a sequence's count are padding),
+ * counts = S valid row counts (host); S and T equal on every rank.  On return, on every rank, rows_out [world][S][T][8] and
+ * counts_out [world][S] (host) hold everybody's. */
+int ptl_gather_trajectories(ptl_comm *c, const double *d_rows, int64_t S, int64_t T, const int64_t *counts,
+                            double *rows_out, int64_t *counts_out);
+/* ... the rows a batch's filter kernel wrote on device (what ptl_batch_copy_traj copies), T = the batch's n_scans:
+ * rows_out [world][n_sequences][n_scans][8], counts_out [world][n_sequences] */
+int ptl_batch_gather_trajectories(ptl_batch *b, ptl_comm *c, double *rows_out, int64_t *counts_out);
 
 #ifdef __cplusplus
 }

@@ -136,7 +136,13 @@ PROTOTYPES = {
     "ptl_batch_sched_counters": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
     "ptl_batch_status": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "ptl_batch_debug_stall_block": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "ptl_batch_debug_set_map_points_per_thread": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int32)]),
     "ptl_build_info": (C.c_int, [C.POINTER(C.c_int32)]),
+    "ptl_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "ptl_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _vpp]),
+    "ptl_comm_destroy": (C.c_int, [_vp]),
+    "ptl_gather_trajectories": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, c_i64_p, c_d_p, c_i64_p]),
+    "ptl_batch_gather_trajectories": (C.c_int, [_vp, _vp, c_d_p, c_i64_p]),
 }
 
 _lib = None

@@ -425,6 +425,12 @@ class BatchRunner:
     def debug_stall_block(self, block, round=0):
         L.check(L.lib().ptl_batch_debug_stall_block(self._h, int(block), int(round)))
 
+    def debug_map_points_per_thread(self, points=0):
+        """test hook: the free-running map update's points per thread (0 = ask); returns the value in effect"""
+        v = C.c_int32()
+        L.check(L.lib().ptl_batch_debug_set_map_points_per_thread(self._h, int(points), C.byref(v)))
+        return v.value
+
     def close(self):
         if getattr(self, "_h", None):
             L.lib().ptl_batch_destroy(self._h)

@@ -36,6 +36,13 @@
 #define ERR_TABLE 4
 #define ERR_VDS_TABLE 8
 #define ERR_GN_TIMEOUT 16
+// make EXTRA=-DMAP_DIAG: every site that raises ERR_TABLE counts itself in st->dbg_sums[24 + site] and leaves two values of its first
+// occurrence in dbg_sums[28..31] (tools/um_diag.py reads them)
+#ifdef MAP_DIAG
+#define MAP_DIAG_AT(st_, site, a_, b_) do { if (atomicAdd(&(st_)->dbg_sums[24 + (site)], 1.0) == 0.0) { (st_)->dbg_sums[28] = (double)(site); (st_)->dbg_sums[29] = (double)(a_); (st_)->dbg_sums[30] = (double)(b_); } } while (0)
+#else
+#define MAP_DIAG_AT(st_, site, a_, b_) do { } while (0)
+#endif
 
 struct TabEnt {
     unsigned long long key;
@@ -2616,13 +2623,19 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
     }
     bool created[U], pend[U];
     unsigned sp[U];
+    // (The three outcomes are formed as predicates and selects, not as an if / else-if / else chain over slot[u]: with U = 4 the
+    // compiler keeps slot[] in one 128-bit register tuple and - ROCm 7.2 hipcc, -O3 - generated for the chain a region in which the
+    // lanes that LOST the swap to their own key (cur == EMPTY, old == key: every further point of a new voxel inside one wavefront)
+    // had their slot reset to -1 together with the pending lanes and never set again: ERR_TABLE on the first scan, 60 % of the
+    // points dropped.  U = 8 compiled correctly.  profiles/r05_a_seq_um4_root_cause.txt has the ISA; the test matrix over U guards it.)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        created[u] = false; pend[u] = false; sp[u] = s0[u];
-        if (!keyed[u]) continue;
-        if (cur[u] == key[u] || (cur[u] == EMPTY_KEY && old[u] == key[u])) slot[u] = (int)s0[u];
-        else if (cur[u] == EMPTY_KEY && old[u] == EMPTY_KEY) { slot[u] = (int)s0[u]; created[u] = true; }
-        else pend[u] = true;  // occupied by another voxel or a tombstone (or the swap lost to another key): linear probing goes on
+        sp[u] = s0[u];
+        const bool was_empty = cur[u] == EMPTY_KEY;
+        const bool found = keyed[u] && (cur[u] == key[u] || (was_empty && old[u] == key[u]));
+        created[u] = keyed[u] && was_empty && old[u] == EMPTY_KEY;
+        slot[u] = (found || created[u]) ? (int)s0[u] : -1;
+        pend[u] = keyed[u] && !found && !created[u];  // occupied by another voxel or a tombstone (or the swap lost to another key): linear probing goes on
     }
     // ... in rounds: the next slot of every unsettled point is read, then the swaps on the empty ones are sent, then all are
     // looked at (point by point it was two to three dependent round trips per collision and u)
@@ -2643,16 +2656,18 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
             if (pend[u] && ck[u] == EMPTY_KEY) o[u] = atomicCAS(&c.tab[sp[u]].key, EMPTY_KEY, key[u]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!pend[u]) continue;
-            if (ck[u] == key[u]) { slot[u] = (int)sp[u]; pend[u] = false; }
-            else if (ck[u] == EMPTY_KEY && o[u] == EMPTY_KEY) { slot[u] = (int)sp[u]; created[u] = true; pend[u] = false; }
-            else if (ck[u] == EMPTY_KEY && o[u] == key[u]) { slot[u] = (int)sp[u]; pend[u] = false; }
+        for (int u = 0; u < U; ++u) {  // (predicates and selects, as above)
+            const bool was_empty = ck[u] == EMPTY_KEY;
+            const bool found = pend[u] && (ck[u] == key[u] || (was_empty && o[u] == key[u]));
+            const bool made = pend[u] && was_empty && o[u] == EMPTY_KEY;
+            slot[u] = (found || made) ? (int)sp[u] : slot[u];
+            created[u] = created[u] || made;
+            pend[u] = pend[u] && !found && !made;
         }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        if (keyed[u] && slot[u] < 0) atomicOr(&st->err_flags, ERR_TABLE);
+        if (keyed[u] && slot[u] < 0) { atomicOr(&st->err_flags, ERR_TABLE); MAP_DIAG_AT(st, 0, idx[u], s0[u]); }
     // the list pushes need the slot only - sent before the creation chain below (pool pop -> free-stack read -> header), whose round trips
     // they then share instead of following them
     int nx[U];
@@ -2686,7 +2701,7 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
             }
             c.tab[slot[u]].blk = blk[u];
             const unsigned used = atomicAdd(&st->tab_used, 1u) + 1u;
-            if (used > (c.tmask + 1u) / 4u * 3u) atomicOr(&st->err_flags, ERR_TABLE);
+            if (used > (c.tmask + 1u) / 4u * 3u) { atomicOr(&st->err_flags, ERR_TABLE); MAP_DIAG_AT(st, 1, used, c.tmask); }
         }
     }
 #pragma unroll
@@ -2726,7 +2741,7 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
         if (idx[u] < n && slot[u] >= 0 && pb[u] >= 0) { w[u][0] = c.fdw[3 * i]; w[u][1] = c.fdw[3 * i + 1]; w[u][2] = c.fdw[3 * i + 2]; }
     }
     for (int steps = 0;; ++steps) {  // the U list walks step together: their reads of nxt[] are in flight at the same time
-        if (steps > n) { atomicOr(&c.st->err_flags, ERR_TABLE); break; }  // (a list longer than the batch: corrupted links must not hang the launch)
+        if (steps > n) { atomicOr(&c.st->err_flags, ERR_TABLE); MAP_DIAG_AT(c.st, 2, idx[0], n); break; }  // (a list longer than the batch: corrupted links must not hang the launch)
         bool any = false;
 #pragma unroll
         for (int u = 0; u < U; ++u) any = any || j[u] >= 0;
@@ -2869,6 +2884,7 @@ __device__ __forceinline__ void d_map_rebuild(const Ctx& c, const Slice sl) {
         s = (s + 1) & c.tmask;
     }
     atomicOr(&c.st->err_flags, ERR_TABLE);
+    MAP_DIAG_AT(c.st, 3, b, s);
 }
 
 // export of the map points (KissICPWrapper.local_map_points)

@@ -414,6 +414,14 @@ static void icp_collect_profile(ptl_icp* h) {
     h->ev_used = 0;
 }
 
+// Every entry point that touches the map, the device state or the handle's staging buffers (d_in, d_ext, fdw) on h->stream goes through
+// this first: with lazy_map_stats a registration returns while its scan's map update (K7-K10, the rebuild) still runs on map_stream, and
+// the sequence runner leaves one in flight too - work enqueued on h->stream must be ordered behind it (map_add / align /
+// linear_system used to start beside it: two inserts on one table and pool, or a search over a half-inserted batch).
+static int icp_join_map(ptl_icp* h) {
+    if (h->ev_map_valid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_map, 0));
+    return PTL_OK;
+}
 static int icp_check_flags(ptl_icp* h) {
     int flags = 0;
     HIPCHK(hipStreamSynchronize(h->map_stream));  // the last scan's map update
@@ -513,6 +521,7 @@ __global__ void k_prediction(const DevState* st, double* out) {
 extern "C" int ptl_icp_get_prediction(ptl_icp* h, double out[16]) {
     if (!h || !out) return set_err(PTL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    { int rcj = icp_join_map(h); if (rcj) return rcj; }
     k_prediction<<<1, 64, 0, h->stream>>>(h->c.st, h->d_ext);
     HIPCHK(hipMemcpyAsync(out, h->d_ext, 16 * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -569,6 +578,7 @@ extern "C" int ptl_icp_deskew(ptl_icp* h, const double* xyz, const double* t01, 
     if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "too many points");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     if (n == 0) return PTL_OK;
+    { int rcj = icp_join_map(h); if (rcj) return rcj; }  // (the result is staged in fdw, which insert b of a running map update still reads)
     k_finish_scan<<<1, 64, 0, h->stream>>>(h->c);
     HIPCHK(hipMemcpyAsync(h->d_in, xyz, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_t01, t01, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
@@ -582,6 +592,7 @@ extern "C" int ptl_icp_map_add(ptl_icp* h, const double* xyz_world, int64_t n, c
     HIPCHK(hipSetDevice(h->cfg.device_id));
     Ctx& c = h->c;
     hipStream_t s = h->stream;
+    { int rcj = icp_join_map(h); if (rcj) return rcj; }
     for (int64_t off = 0; off < n; off += h->n_max) {  // batches keep scan order: earlier batch = earlier points
         const int m = (int)((n - off) < h->n_max ? (n - off) : h->n_max);
         HIPCHK(hipMemcpyAsync(h->d_in, xyz_world + 3 * off, (size_t)m * 24, hipMemcpyHostToDevice, s));
@@ -615,6 +626,7 @@ extern "C" int ptl_icp_linear_system(ptl_icp* h, const double* src_world, int64_
     if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "too many points");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     Ctx& c = h->c;
+    { int rcj = icp_join_map(h); if (rcj) return rcj; }
     HIPCHK(hipMemcpyAsync(c.src_cur, src_world, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     k_set_gn<<<1, 64, 0, h->stream>>>(c, (int)n, max_dist, kernel, nullptr);
     if (c.P == 20) k_gn_loop<20, false><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1); else k_gn_loop<0, false><<<c.G, h->cfg.gn_threads, 0, h->stream>>>(c, 1);
@@ -633,6 +645,7 @@ extern "C" int ptl_icp_align(ptl_icp* h, const double* frame, int64_t n, const d
     if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "too many points");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     Ctx& c = h->c;
+    { int rcj = icp_join_map(h); if (rcj) return rcj; }
     HIPCHK(hipMemcpyAsync(c.src0, frame, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_ext, guess, 128, hipMemcpyHostToDevice, h->stream));
     k_set_gn<<<1, 64, 0, h->stream>>>(c, (int)n, max_dist, kernel, h->d_ext);
@@ -1359,9 +1372,11 @@ struct ptl_batch {
     int* d_imu_end[GN_MAX_SEQ];
     unsigned* d_bar;            // [SEQ_MAX_TEAMS][64] barrier counters and job words of the free-running kernel's teams
     SeqSched* d_sched;          // [8] its per-XCD scan schedulers
+    int *d_flags, *h_flags;     // [GN_MAX_SEQ + 1] error flags of every sequence + the status word, gathered by k_finish_all (h_flags: pinned)
     unsigned* d_status;         // one sticky word: why teams of the free-running kernel left a launch early (SEQ_EXIT_*), cleared by a reset
     int force_agent;            // PTL_TEAM_SYNC=agent in the environment when the batch was created: no XCD-local barrier shortcut
     int dbg_dead_block, dbg_dead_round;  // test hook: ptl_batch_debug_stall_block
+    int um_alt;                 // test hook: ptl_batch_debug_set_map_points_per_thread
     bool free_running;
     int team_wgs;               // workgroups per team of the free-running kernel (0 = by the number of sequences, batch_gseq)
     bool seq_run_checked;
@@ -1436,6 +1451,8 @@ extern "C" int ptl_batch_destroy(ptl_batch* b) {
     if (b->d_bar) (void)hipFree(b->d_bar);
     if (b->d_sched) (void)hipFree(b->d_sched);
     if (b->d_status) (void)hipFree(b->d_status);
+    if (b->d_flags) (void)hipFree(b->d_flags);
+    if (b->h_flags) (void)hipHostFree(b->h_flags);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->ev_gn) (void)hipEventDestroy(b->ev_gn);
     if (b->ev_side) (void)hipEventDestroy(b->ev_side);
@@ -1466,8 +1483,8 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     ptl_batch* b = new ptl_batch();
     b->cfg = *cfg;
     b->S = n_sequences;
-    b->stream = nullptr; b->d_ctx = nullptr; b->lut = nullptr; b->is_range = 0; b->d_bar = nullptr; b->d_sched = nullptr; b->d_status = nullptr;
-    b->dbg_dead_block = -1; b->dbg_dead_round = -1;
+    b->stream = nullptr; b->d_ctx = nullptr; b->lut = nullptr; b->is_range = 0; b->d_bar = nullptr; b->d_sched = nullptr; b->d_status = nullptr; b->d_flags = nullptr; b->h_flags = nullptr;
+    b->dbg_dead_block = -1; b->dbg_dead_round = -1; b->um_alt = 0;
     {   // PTL_TEAM_SYNC=agent: the teams of the free-running kernel keep the agent-scope release at every barrier (seq_kernel.h team_sync)
         const char* e = getenv("PTL_TEAM_SYNC");
         b->force_agent = (e && strcmp(e, "agent") == 0) ? 1 : 0;
@@ -1505,7 +1522,8 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
         b->imu_end[s].assign((size_t)cfg->n_scans, 0);
     }
     if (rc == PTL_OK && (dalloc(&b->d_ctx, (size_t)GN_MAX_SEQ) != hipSuccess || dalloc(&b->d_bar, (size_t)SEQ_MAX_TEAMS * 64) != hipSuccess || dalloc(&b->d_sched, (size_t)8) != hipSuccess ||
-                         dalloc(&b->d_status, (size_t)16) != hipSuccess || hipMemset(b->d_status, 0, 16 * sizeof(unsigned)) != hipSuccess))
+                         dalloc(&b->d_status, (size_t)16) != hipSuccess || hipMemset(b->d_status, 0, 16 * sizeof(unsigned)) != hipSuccess ||
+                         dalloc(&b->d_flags, (size_t)GN_MAX_SEQ + 1) != hipSuccess || hipHostMalloc((void**)&b->h_flags, (size_t)(GN_MAX_SEQ + 1) * sizeof(int)) != hipSuccess))
         rc = set_err(PTL_ERR_HIP, "batch allocation failed");
     // (the free-running driver's own limits - co-residency of the persistent grid, team size - are checked when that driver is
     // chosen or first used: a batch that is switched to lockstep right after creation must not be refused on them)
@@ -1634,6 +1652,7 @@ static int batch_enqueue_free(ptl_batch* b, int64_t n) {
         r.S = S; r.k0 = (int)k0; r.k1 = (int)k1; r.with_ekf = with_ekf ? 1 : 0; r.rebuild_every = ic.rebuild_every;
         const int gseq = batch_gseq(b);
         r.G = gseq;
+        r.um_alt = b->um_alt;
         r.force_agent = b->force_agent; r.dbg_dead_block = b->dbg_dead_block; r.dbg_dead_round = b->dbg_dead_round;
         const bool p20 = ic.max_points_per_voxel == 20;
 #define KXR(GC) do { if (p20) kx_seq_run<20, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r, b->d_sched, b->d_bar, b->d_status); \
@@ -1789,18 +1808,28 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
     HIPCHK(hipGetLastError());
     return PTL_OK;
 }
+// closes the last scan of EVERY sequence (what k_finish_scan does for one) and collects the error flags and the batch's status word in one
+// array: one launch and one copy per wait instead of S launches and S + 1 copies (240 + 241 of them sat inside the bench's timed region:
+// 3 % of a 20-step run)
+__global__ void k_finish_all(const SeqCtx* a, int S, const unsigned* status, int* out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) out[GN_MAX_SEQ] = (int)*status;
+    if (s >= S) return;
+    const Ctx& c = a[s].c;
+    finish_pending(c, c.st);
+    flush_map_stats(c, c.st);
+    out[s] = c.st->err_flags;
+}
 extern "C" int ptl_batch_wait(ptl_batch* b) {
     if (!b) return set_err(PTL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
-    int flags[GN_MAX_SEQ] = {0};
-    unsigned status = 0u;
+    if (b->ctx_dirty) { int rc = batch_push_ctx(b); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(b->side));
-    for (int s = 0; s < b->S; ++s) {
-        k_finish_scan<<<1, 64, 0, b->stream>>>(b->icp[s]->c);
-        HIPCHK(hipMemcpyAsync(&flags[s], &b->icp[s]->c.st->err_flags, sizeof(int), hipMemcpyDeviceToHost, b->stream));
-    }
-    HIPCHK(hipMemcpyAsync(&status, b->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream));
+    k_finish_all<<<(b->S + 63) / 64, 64, 0, b->stream>>>(b->d_ctx, b->S, b->d_status, b->d_flags);
+    HIPCHK(hipMemcpyAsync(b->h_flags, b->d_flags, (size_t)(GN_MAX_SEQ + 1) * sizeof(int), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    const int* flags = b->h_flags;
+    const unsigned status = (unsigned)b->h_flags[GN_MAX_SEQ];
     for (size_t i = 0; i + 1 < b->ev_used; i += 2) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]) == hipSuccess) { b->gn_ms += ms; b->gn_launches++; }
@@ -1827,6 +1856,15 @@ extern "C" int ptl_batch_status(ptl_batch* b, uint32_t* status) {
 extern "C" int ptl_batch_debug_stall_block(ptl_batch* b, int32_t block, int32_t round) {
     if (!b) return set_err(PTL_ERR_ARG, "null argument");
     b->dbg_dead_block = block; b->dbg_dead_round = block < 0 ? -1 : round;
+    return PTL_OK;
+}
+// test hook: points per thread and pass of the free-running kernel's map update - the build's default (SEQ_UM, 8) or its second instance
+// (SEQ_UM_ALT, 4); anything else is refused.  The result must not depend on it (tests/test_gpu_batch.py).  points_out: the value in effect.
+extern "C" int ptl_batch_debug_set_map_points_per_thread(ptl_batch* b, int32_t points, int32_t* points_out) {
+    if (!b) return set_err(PTL_ERR_ARG, "null argument");
+    if (points != 0 && points != SEQ_UM && points != SEQ_UM_ALT) return set_err(PTL_ERR_ARG, "this build carries the map update at %d and %d points per thread", SEQ_UM, SEQ_UM_ALT);
+    if (points != 0) b->um_alt = (points == SEQ_UM_ALT && SEQ_UM_ALT != SEQ_UM) ? 1 : 0;
+    if (points_out) *points_out = b->um_alt ? SEQ_UM_ALT : SEQ_UM;
     return PTL_OK;
 }
 // where the scans of sequence s ran (free-running kernel), cumulative since the cold start: out[0] scans run by a team of another XCD than
@@ -1929,4 +1967,163 @@ extern "C" int ptl_batch_profile(ptl_batch* b, int enable, double* gn_ms_total, 
     if (reset) { b->gn_ms = 0; b->gn_launches = 0; }
     b->prof = enable != 0;
     return PTL_OK;
+}
+
+// ================================================================================================ multi-GPU: the trajectory gather (RCCL)
+// The path shards across sequences only; its one collective is the all-gather of every rank's (S, T, 8) NC-GT rows
+// [t, x, y, z, qx, qy, qz, qw] after the run (ptl_gather_trajectories) - ncclAllGather straight from librccl, over
+// xGMI on the node.  The library does NO bootstrap: rank 0 makes the 128-byte ncclUniqueId (ptl_comm_unique_id), the caller carries the
+// bytes to the other ranks however it likes (environment, a file, a gloo / MPI / TCP broadcast), every rank calls ptl_comm_create.
+// librccl is opened on first use (dlopen): a process that never gathers needs no RCCL, and a process that has torch loaded gets the
+// librccl that is already mapped.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+extern char g_rccl_why[320];
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    char why[256] = "";
+};
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.lib ? &api : nullptr;
+    tried = true;
+    const char* override_path = getenv("PTL_RCCL_PATH");
+    const char* names[] = {override_path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (api.lib) break;
+        snprintf(api.why, sizeof api.why, "%s", dlerror());
+    }
+    if (!api.lib) { snprintf(g_rccl_why, sizeof g_rccl_why, "librccl could not be opened (%s); PTL_RCCL_PATH overrides the search", api.why); return nullptr; }
+#define RSYM(f) api.f = (decltype(api.f))dlsym(api.lib, "nccl" #f)
+    RSYM(GetUniqueId); RSYM(CommInitRank); RSYM(AllGather); RSYM(CommDestroy); RSYM(CommAbort); RSYM(GetErrorString);
+#undef RSYM
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) {
+        snprintf(g_rccl_why, sizeof g_rccl_why, "the librccl that was opened lacks a needed symbol");
+        dlclose(api.lib);
+        api.lib = nullptr;
+        return nullptr;
+    }
+    return &api;
+}
+char g_rccl_why[320] = "";
+const char* rccl_why() { return g_rccl_why; }
+}  // namespace
+#define RCCLCHK(api, x)                                                                                          \
+    do {                                                                                                         \
+        ncclResult_t r_ = (x);                                                                                   \
+        if (r_ != ncclSuccess) return set_err(PTL_ERR_HIP, "%s: %s (%s:%d)", #x, (api)->GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+struct ptl_comm {
+    ncclComm_t comm;
+    int world, rank, device_id;
+    hipStream_t stream;
+};
+extern "C" int ptl_comm_unique_id(uint8_t id[PTL_COMM_ID_BYTES]) {
+    if (!id) return set_err(PTL_ERR_ARG, "null argument");
+    static_assert(PTL_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the ABI's id size is RCCL's");
+    RcclApi* api = rccl_api();
+    if (!api) return set_err(PTL_ERR_STATE, "%s", rccl_why());
+    ncclUniqueId u;
+    RCCLCHK(api, api->GetUniqueId(&u));
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return PTL_OK;
+}
+extern "C" int ptl_comm_create(const uint8_t id[PTL_COMM_ID_BYTES], int32_t world, int32_t rank, int32_t device_id, ptl_comm** out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return set_err(PTL_ERR_ARG, "bad argument");
+    if (ptl_device_count() <= device_id || device_id < 0) return set_err(PTL_ERR_HIP, "no HIP device %d", device_id);
+    RcclApi* api = rccl_api();
+    if (!api) return set_err(PTL_ERR_STATE, "%s", rccl_why());
+    HIPCHK(hipSetDevice(device_id));
+    ptl_comm* c = new ptl_comm();
+    c->comm = nullptr; c->world = world; c->rank = rank; c->device_id = device_id; c->stream = nullptr;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_err(PTL_ERR_HIP, "stream creation failed"); }
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclResult_t r = api->CommInitRank(&c->comm, world, u, rank);  // (collective: returns when every rank has called it)
+    if (r != ncclSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return set_err(PTL_ERR_HIP, "ncclCommInitRank(world %d, rank %d, device %d): %s", world, rank, device_id, api->GetErrorString(r));
+    }
+    *out = c;
+    return PTL_OK;
+}
+extern "C" int ptl_comm_destroy(ptl_comm* c) {
+    if (!c) return PTL_OK;
+    RcclApi* api = rccl_api();
+    (void)hipSetDevice(c->device_id);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (api && c->comm) (void)api->CommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PTL_OK;
+}
+// every rank: S sequences x T rows x 8 doubles on the DEVICE (padded with anything) and S row counts on the host; same S and T on every rank.
+// rows_out [world][S][T][8] and counts_out [world][S] on the host, filled on every rank.  One ncclAllGather: the counts ride behind the rows
+// in the same send buffer (as doubles - exact for any count below 2^53).
+extern "C" int ptl_gather_trajectories(ptl_comm* c, const double* d_rows, int64_t S, int64_t T, const int64_t* counts,
+                                       double* rows_out, int64_t* counts_out) {
+    if (!c || !d_rows || !counts || !rows_out || !counts_out || S < 1 || T < 1) return set_err(PTL_ERR_ARG, "bad argument");
+    RcclApi* api = rccl_api();
+    if (!api) return set_err(PTL_ERR_STATE, "%s", rccl_why());
+    HIPCHK(hipSetDevice(c->device_id));
+    const size_t per_rank = (size_t)S * (size_t)T * 8 + (size_t)S;
+    double *d_send = nullptr, *d_recv = nullptr;
+    HIPCHK(dalloc(&d_send, per_rank));
+    if (dalloc(&d_recv, per_rank * (size_t)c->world) != hipSuccess) { (void)hipFree(d_send); return set_err(PTL_ERR_HIP, "gather buffer allocation failed"); }
+    std::vector<double> cnt((size_t)S);
+    for (int64_t s = 0; s < S; ++s) {
+        if (counts[s] < 0 || counts[s] > T) { (void)hipFree(d_send); (void)hipFree(d_recv); return set_err(PTL_ERR_ARG, "count of sequence %lld outside [0, T]", (long long)s); }
+        cnt[(size_t)s] = (double)counts[s];
+    }
+    int rc = PTL_OK;
+    std::vector<double> host(per_rank * (size_t)c->world);
+    do {
+        if (hipMemcpyAsync(d_send, d_rows, (size_t)S * T * 64, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_send + (size_t)S * T * 8, cnt.data(), (size_t)S * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = set_err(PTL_ERR_HIP, "gather staging failed"); break; }
+        ncclResult_t r = api->AllGather(d_send, d_recv, per_rank, ncclDouble, c->comm, c->stream);
+        if (r != ncclSuccess) { rc = set_err(PTL_ERR_HIP, "ncclAllGather: %s", api->GetErrorString(r)); break; }
+        if (hipMemcpyAsync(host.data(), d_recv, host.size() * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { rc = set_err(PTL_ERR_HIP, "gather read-back failed: %s", hipGetErrorString(hipGetLastError())); break; }
+    } while (0);
+    (void)hipFree(d_send); (void)hipFree(d_recv);
+    if (rc) return rc;
+    for (int r = 0; r < c->world; ++r) {
+        const double* p = host.data() + per_rank * (size_t)r;
+        memcpy(rows_out + (size_t)r * S * T * 8, p, (size_t)S * T * 64);
+        for (int64_t s = 0; s < S; ++s) counts_out[(size_t)r * S + s] = (int64_t)p[(size_t)S * T * 8 + s];
+    }
+    return PTL_OK;
+}
+// ... of a batch: the rows its filter kernel wrote for every sequence (ptl_batch_copy_traj's source), T = the batch's n_scans
+extern "C" int ptl_batch_gather_trajectories(ptl_batch* b, ptl_comm* c, double* rows_out, int64_t* counts_out) {
+    if (!b || !c || !rows_out || !counts_out) return set_err(PTL_ERR_ARG, "null argument");
+    if (!b->cfg.with_ekf) return set_err(PTL_ERR_STATE, "trajectory rows need with_ekf");
+    if (c->device_id != b->cfg.icp.device_id) return set_err(PTL_ERR_ARG, "communicator on device %d, batch on device %d", c->device_id, b->cfg.icp.device_id);
+    HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    HIPCHK(hipStreamSynchronize(b->side));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    const int64_t S = b->S, T = b->cfg.n_scans;
+    double* d_rows = nullptr;
+    HIPCHK(dalloc(&d_rows, (size_t)S * T * 8));
+    std::vector<int64_t> counts((size_t)S, b->n_out < T ? b->n_out : T);
+    hipError_t e = hipMemsetAsync(d_rows, 0, (size_t)S * T * 64, b->stream);
+    for (int64_t s = 0; s < S && e == hipSuccess; ++s)
+        if (counts[(size_t)s] > 0) e = hipMemcpyAsync(d_rows + (size_t)s * T * 8, b->d_rows[s], (size_t)counts[(size_t)s] * 64, hipMemcpyDeviceToDevice, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) { (void)hipFree(d_rows); return set_err(PTL_ERR_HIP, "row staging failed: %s", hipGetErrorString(e)); }
+    const int rc = ptl_gather_trajectories(c, d_rows, S, T, counts.data(), rows_out, counts_out);
+    (void)hipFree(d_rows);
+    return rc;
 }

@@ -90,6 +90,9 @@ __device__ __forceinline__ unsigned xcc_id() {
 #ifndef SEQ_UM
 #define SEQ_UM SEQ_U  /* ... in the map update */
 #endif
+#ifndef SEQ_UM_ALT
+#define SEQ_UM_ALT 4  /* the map update's second instance (test hook: the result must not depend on the points per thread) */
+#endif
 #ifndef SEQ_U2
 #define SEQ_U2 16  /* ... in K3 / K3b / K4 (a few registers per point: an index, a slot, two flags); they share their block size through bcnt1 / bcnt2 */
 #endif
@@ -174,19 +177,24 @@ __device__ __forceinline__ int sq_grab(unsigned* ctr) {
     __syncthreads();
     return s_blk;
 }
+// UM: points (blocks of the pool) per thread and pass.  Nothing in the result depends on it - block partitioning only - and the kernel carries
+// two instances (SEQ_UM, the default, and SEQ_UM_ALT; SeqRun::um_alt picks, ptl_batch_debug_set_map_points_per_thread) so that a GPU test can
+// hold that true: round 3-4's "map update fails at 4 points per thread" was a miscompiled branch chain in insert a (see there), found
+// only because somebody built another U.
+template <int UM>
 __device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, int wg, int nw, unsigned target, int rebuild, unsigned* word, unsigned* ctr, bool local) {
     const Ctx c = load_seq_ctx(a, s, k);
     DevState* st = c.st;
-    const int BS = (int)blockDim.x, BU = BS * SEQ_UM, nbd = (st->n_down_ins + BU - 1) / BU;
+    const int BS = (int)blockDim.x, BU = BS * UM, nbd = (st->n_down_ins + BU - 1) / BU;
     Slice sl;
     sl.nb = nbd; sl.clk = 0;
     const TeamEnv te = {word, &st->gn_abort, st, local};
     SQ_CLK_DECL;
-    for (sl.b = sq_grab(ctr); sl.b < nbd; sl.b = sq_grab(ctr)) d_map_insert_a<SEQ_UM>(c, c.fd, &st->n_down_ins, 0, 1, sl);
+    for (sl.b = sq_grab(ctr); sl.b < nbd; sl.b = sq_grab(ctr)) d_map_insert_a<UM>(c, c.fd, &st->n_down_ins, 0, 1, sl);
     SQ_CLK(10);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(11);
-    for (sl.b = sq_grab(ctr + 1); sl.b < nbd; sl.b = sq_grab(ctr + 1)) d_map_insert_b<SEQ_UM, true>(c, &st->n_down_ins, 0, sl);
+    for (sl.b = sq_grab(ctr + 1); sl.b < nbd; sl.b = sq_grab(ctr + 1)) d_map_insert_b<UM, true>(c, &st->n_down_ins, 0, sl);
     SQ_CLK(12);
     if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
     SQ_CLK(13);
@@ -194,7 +202,7 @@ __device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, in
     SQ_CLK(15);
     const int nbpu = (st->pool_hw + BU - 1) / BU;
     sl.nb = nbpu;
-    for (sl.b = sq_grab(ctr + 3); sl.b < nbpu; sl.b = sq_grab(ctr + 3)) d_map_prune<SEQ_UM, true>(c, nullptr, 1, sl);
+    for (sl.b = sq_grab(ctr + 3); sl.b < nbpu; sl.b = sq_grab(ctr + 3)) d_map_prune<UM, true>(c, nullptr, 1, sl);
     SQ_CLK(16);
     const int nbp = (st->pool_hw + BS - 1) / BS;
     sl.nb = nbp;
@@ -233,6 +241,7 @@ __device__ __noinline__ void sq_filter(const SeqCtx* a, int s, int k) {
 
 struct SeqRun {
     int S, k0, k1, with_ekf, rebuild_every, G;  // G: workgroups per team (run-time value; the GC instances fix it at compile time)
+    int um_alt;          // test hook: the map update runs its SEQ_UM_ALT instance (ptl_batch_debug_set_map_points_per_thread)
     int force_agent;     // PTL_TEAM_SYNC=agent: every team barrier keeps the agent-scope release (no XCD-local shortcut)
     int dbg_dead_block;  // test hook (ptl_batch_debug_stall_block): this workgroup of the grid leaves right before the job barrier of its
     int dbg_dead_round;  // dbg_dead_round-th job (0 = the first); -1 = none
@@ -313,6 +322,9 @@ __device__ __forceinline__ void sched_release(SeqSched* sc, int q, int next_scan
 // a team that gives up on its sequence (abort word, poll budget) takes it off the schedule: nobody waits for its remaining scans
 __device__ __forceinline__ void sched_abandon(SeqSched* sc, int q, int k1) {
     __hip_atomic_store(&sc->next_scan[q], k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ... and lets go of it: k_sched_check then finds it at k1 and free, and leaves the diagnosis to the flag the team raised (a slot that is
+    // still busy after the launch belongs to a team that died holding it - only that gets the time-out flag)
+    __hip_atomic_store(&sc->busy[q], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // bar: per team 64 words - [0] barrier of the whole team, [32] of the map update, [40], [41] the leader's job (sequence,
@@ -440,7 +452,9 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_seq_run(const SeqC
         const long long c4 = (long long)wall_clock64();
         long long c5f = c4, c5g = c4;
         if (fwg) { sq_filter(a, s, k); c5g = (long long)wall_clock64(); }  // ... and then it joins the map update
-        t_work = sq_map_update(a, s, k, wg, G, t_work, (r.rebuild_every > 0 && ((k + 1) % r.rebuild_every) == 0) ? 1 : 0, tb + 32, tb + 44, local);
+        const int rebuild = (r.rebuild_every > 0 && ((k + 1) % r.rebuild_every) == 0) ? 1 : 0;
+        t_work = r.um_alt ? sq_map_update<SEQ_UM_ALT>(a, s, k, wg, G, t_work, rebuild, tb + 32, tb + 44, local)
+                          : sq_map_update<SEQ_UM>(a, s, k, wg, G, t_work, rebuild, tb + 32, tb + 44, local);
         if (t_work == SEQ_FAIL) SEQ_LEAVE;
         if (solo && r.with_ekf) { c5f = (long long)wall_clock64(); sq_filter(a, s, k); c5g = (long long)wall_clock64(); }
         const long long c5 = (long long)wall_clock64();

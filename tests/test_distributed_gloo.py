@@ -74,3 +74,48 @@ def test_sharding_and_rows():
     t, T = parallel.rows_to_poses(rows)
     assert np.array_equal(t, rows[:, 0]) and np.allclose(T[:, :3, 3], rows[:, 1:4])
     assert np.allclose(np.einsum("nij,nkj->nik", T[:, :3, :3], T[:, :3, :3]), np.eye(3))
+
+
+def _id_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    made = []
+
+    def make():  # stands in for ptl_comm_unique_id (which needs a GPU): only rank 0 may be asked
+        made.append(rank)
+        return bytes((7 * i + 3) % 256 for i in range(parallel.Comm.ID_BYTES))
+
+    got = parallel.broadcast_id(dist, dist.group.WORLD, make)
+    # the communicator itself needs a HIP device: on this box the constructor must fail loudly, not fall back to anything
+    err = None
+    try:
+        parallel.Comm(got, world, rank, 0)
+    except Exception as e:  # noqa: BLE001
+        err = str(e)
+    q.put((rank, got.hex(), made, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_communicator_id_travels_over_the_control_plane():
+    """the library does no bootstrap: rank 0 makes the 128-byte id, the control plane (gloo here) carries it, every rank
+    constructs ptl_comm with the same bytes; without a HIP device the constructor raises (no CPU stand-in for the gather)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = bytes((7 * i + 3) % 256 for i in range(128)).hex()
+    assert [r[1] for r in res] == [want, want]
+    assert res[0][2] == [0] and res[1][2] == []  # made on rank 0 only
+    if not torch.cuda.is_available():
+        assert all(r[3] and "HIP device" in r[3] for r in res), res
+    import pytest
+    with pytest.raises(ValueError):
+        parallel.Comm(b"short", 1, 0)

@@ -411,3 +411,80 @@ def test_empty_and_nearly_empty_sweeps_inside_a_batch():
         assert np.abs(b.results(1)["kiss_poses"][k] - pose).max() < 1e-9, k
         assert all(st[k][q] == icp.stats[k][q] for q in _INT_STATS), (k, st[k], icp.stats[k])
 
+
+
+def _map_rows(b, s):
+    """sorted points of sequence s's local map (KissICPWrapper.local_map_points of that member)"""
+    import ctypes as C
+    from ptudes_lab_amd import _lib as L
+    h = C.c_void_p()
+    L.check(L.lib().ptl_batch_icp(b._h, s, C.byref(h)))
+    nv, npnt = C.c_int64(), C.c_int64()
+    L.check(L.lib().ptl_icp_map_size(h, C.byref(nv), C.byref(npnt)))
+    pts = np.empty((npnt.value + 8, 3))
+    w = C.c_int64()
+    L.check(L.lib().ptl_icp_map_points(h, L.dptr(pts), len(pts), C.byref(w)))
+    p = pts[:w.value]
+    return (nv.value, npnt.value), p[np.lexsort(p.T[::-1])]
+
+
+def test_free_running_map_update_does_not_depend_on_its_points_per_thread():
+    """VoxelHashMap::AddPoints + RemovePointsFarFromLocation of the free-running kernel (reference kiss.py:129) at BOTH instances the build
+    carries - 8 points per thread (default) and 4 - and in the lockstep driver (one point per thread): the local map of every sequence
+    after every launch, every pose and every per-scan counter bit-equal between the three; the map after the first sweep (identity pose:
+    no Gauss-Newton sum in it) bit-equal to the CPU oracle's, after the last sweep the oracle's voxel and point counts and its points
+    within 1e-9 m.  Rounds 3-4 failed this at 4 points per thread (a miscompiled branch chain in insert a): with the table
+    rebuild inside the kernel every 3 scans and launches of 1 / 3 / 4 scans."""
+    from oracle import cpu as orc
+    S, n = 5, 8
+    seqs = [synth.make_sequence(seed=1300 + s, n_scans=n) for s in range(S)]
+    b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, 0, with_ekf=False, rebuild_every=3)
+    for s, sq in enumerate(seqs):
+        for k in range(n):
+            b.upload_scan(s, k, sq.scan(k))
+        b.upload_imu(s, np.zeros((0, 7)), [0] * n)
+    assert b.debug_map_points_per_thread() == 8
+    runs = {}
+    for name in ("u8", "u4", "lockstep"):
+        b.set_driver(name != "lockstep")
+        if name != "lockstep":
+            assert b.debug_map_points_per_thread(8 if name == "u8" else 4) == (8 if name == "u8" else 4)
+        maps = []
+        b.run(1)
+        maps.append([_map_rows(b, s) for s in range(S)])
+        for m in (3, 4):
+            b.enqueue(m)
+            b.wait()
+            maps.append([_map_rows(b, s) for s in range(S)])
+        runs[name] = (maps, [b.results(s) for s in range(S)])
+    b.debug_map_points_per_thread(8)
+    for name in ("u4", "lockstep"):
+        for launch in range(3):
+            for s in range(S):
+                assert runs[name][0][launch][s][0] == runs["u8"][0][launch][s][0], (name, launch, s)
+                assert np.array_equal(runs[name][0][launch][s][1], runs["u8"][0][launch][s][1]), (name, launch, s)
+        for s in range(S):
+            assert np.array_equal(runs[name][1][s]["kiss_poses"], runs["u8"][1][s]["kiss_poses"]), (name, s)
+            assert runs[name][1][s]["stats"] == runs["u8"][1][s]["stats"], (name, s)
+    # ... and against the oracle (sequences 0 and 3)
+    orc.set_threads(1)
+    for s in (0, 3):
+        ref = orc.ICP(70.0, 1.0)
+        t01 = seqs[s].column_times()
+        for k in range(n):
+            ref.register_frame(seqs[s].scan(k).astype(np.float64), t01)
+            if k == 0:
+                p = ref.map.points()
+                assert np.array_equal(p[np.lexsort(p.T[::-1])], runs["u4"][0][0][s][1])  # bit for bit
+                assert (ref.map.num_voxels, ref.map.num_points) == runs["u4"][0][0][s][0]
+        p = ref.map.points()
+        p = p[np.lexsort(p.T[::-1])]
+        (nv, npnt), q = runs["u4"][0][2][s]
+        assert (ref.map.num_voxels, ref.map.num_points) == (nv, npnt)
+        # (sorted by coordinates that differ in the 14th digit: compare as sets through a rounded key)
+        kp, kq = np.round(p, 6), np.round(q, 6)
+        p, q = p[np.lexsort(kp.T[::-1])], q[np.lexsort(kq.T[::-1])]
+        assert np.abs(p - q).max() <= 1e-9
+        for k in range(n):
+            for key in ("n_down", "n_src", "iterations", "map_voxels", "map_points"):
+                assert ref.stats[k][key] == runs["u4"][1][s]["stats"][k][key], (s, k, key)

@@ -17,7 +17,7 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # the hot device functions of the default build: the free-running kernel's stages (teams of 2 = the bench default, and the
 # generic instance) and the single-sequence Gauss-Newton kernels
 HOT = ["_Z15sq_gauss_newtonILi20ELi2EEvPK6SeqCtxiiii", "_Z15sq_gauss_newtonILi20ELi0EEvPK6SeqCtxiiii", "_Z15sq_gauss_newtonILi20ELi4EEvPK6SeqCtxiiii",
-       "_Z10sq_preparePK6SeqCtxiiiijPjb", "_Z13sq_map_updatePK6SeqCtxiiiijiPjS2_b", "_Z10k_gn_loop8ILi20ELi0EEv3Ctxi", "_Z9k_gn_loopILi20ELb0EEv3Ctxi"]
+       "_Z10sq_preparePK6SeqCtxiiiijPjb", "_Z13sq_map_updateILi8EEjPK6SeqCtxiiiijiPjS3_b", "_Z13sq_map_updateILi4EEjPK6SeqCtxiiiijiPjS3_b", "_Z10k_gn_loop8ILi20ELi0EEv3Ctxi", "_Z9k_gn_loopILi20ELb0EEv3Ctxi"]
 
 
 def device_code_object(tmp_path):
