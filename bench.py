@@ -59,7 +59,7 @@ EXEC_COST = {
     # workgroup's LDS (GN8_LDS_PTS = 3072 per workgroup), only the points beyond that are written (24) and read back (24) through
     # src_cur every iteration; after the first iteration phase A also reads the voxel key (8) and the 144-byte answer row
     # (position of the last search, its four nearest candidates, the bound on everybody else, ids: GN8_KCAND = 4)
-    "source_read": 24, "point_iteration_in_memory": 48, "point_iteration_later": 152, "lds_points_per_workgroup": 3072,
+    "source_read": 24, "point_iteration_in_memory": 48, "point_iteration_later": 144, "lds_points_per_workgroup": 3072,
     # a full search reads the probe row (128) + key (8), writes the answer row (144) + the winner's voxel (4); the searches of a scan's
     # first iteration (every source point once) read neither: their rows are rebuilt whatever they hold
     "search": 284, "search_first_iteration_not_read": 136,
@@ -98,7 +98,7 @@ def exec_cost_for_build(info):
     row = 8 * info["ans_row_doubles"]
     if row != 144:
         notes.append(f"answer row {row} B (KCAND {info['kcand']})")
-    c["point_iteration_later"] = 8 + row
+    c["point_iteration_later"] = row  # (the voxel key travels in the row since round 5: no separate 8-byte read)
     c["search"] = 128 + 8 + row + 4
     c["lds_points_per_workgroup"] = info["lds_points"]
     if info["lds_points"] != 3072:
@@ -299,6 +299,7 @@ def workload_key(args, S):
             f"seed{args.seed_base}_S{S}_" + ("" if free else f"W{args.warmup}_K{args.steps}_") +
             f"{'cv' if args.const_velocity else 'imu'}"
             f"{'' if not args.icp_only else '_icponly'}{'' if not args.gn_lanes else '_L%d' % args.gn_lanes}"
+            f"{'' if not getattr(args, 'map_small_blocks', 0) else '_sb%d' % args.map_small_blocks}"
             + (f"_free_g{getattr(args, 'gn_wgs', 0) or 256}x{getattr(args, 'gn_threads', 0) or 512}_t{getattr(args, 'team_wgs', 0)}" if free else ""))
 
 
@@ -352,6 +353,7 @@ def main():
     ap.add_argument("--voxel-size", type=float, default=0.0, help="override the map voxel size (default max_range/100)")
     ap.add_argument("--map-blocks", type=int, default=0, help="voxel-block pool capacity")
     ap.add_argument("--map-table", type=int, default=0, help="map hash-table slots (power of two)")
+    ap.add_argument("--map-small-blocks", type=int, default=0, help="small (128-byte, 5-point) voxel blocks beside the --map-blocks full ones: sparse maps (config 5)")
     ap.add_argument("--rebuild-every", type=int, default=0, help="scans between two rebuilds of the map hash table (tombstones dropped; 0 = library default)")
     ap.add_argument("--workload-name", type=str, default="")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default LOCAL_RANK %% visible devices)")
@@ -375,6 +377,7 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    seqs_explicit = any(a == "--seqs-per-gpu" or a.startswith("--seqs-per-gpu=") for a in sys.argv[1:])
     if args.seqs_per_gpu < 1 or args.seqs_per_gpu > 256:
         sys.exit("bench.py: --seqs-per-gpu must be in [1, 256]")
     if args.team_wgs < 0:
@@ -413,6 +416,7 @@ def main():
     if args.voxel_size: icp_over["voxel_size"] = args.voxel_size
     if args.map_blocks: icp_over["map_block_capacity"] = args.map_blocks
     if args.map_table: icp_over["map_table_capacity"] = args.map_table
+    if args.map_small_blocks: icp_over["map_small_blocks"] = args.map_small_blocks
     if args.rebuild_every: icp_over["rebuild_every"] = args.rebuild_every
     # rank r owns the sequences s with s % world == r, sequence s has seed seed_base + s - independent
     # sequences, nothing shared, no data-path collective.  They differ by up to 40 % in GN iterations per scan, so the
@@ -420,13 +424,15 @@ def main():
     # same sequence(s) instead (the pure scaling measurement).
     if world > 1:  # the ranks of one host share its cores: no oversubscription while every rank renders its sweeps
         synth.set_threads(max(2, min(16, synth.usable_cores() // world)))
-    seq_ids = [j if args.equal_work else rank + world * j for j in range(S)]
     # the CPU baseline wants a sample of its own size (>= CPU_MIN_SWEEPS sweeps within its time budget) however short the
     # timed GPU run is: sequence 0 of rank 0 is generated that long, the GPU registers its first n_total sweeps
     n_cpu = max(n_total, CPU_MIN_SWEEPS) if (world == 1 and not args.no_cpu_baseline) else n_total
-    seqs = [synth.make_sequence(seed=args.seed_base + s, n_scans=(n_cpu if j == 0 else n_total), H=args.rows, W=args.cols,
-                                min_range=args.min_range, max_range=args.max_range) for j, s in enumerate(seq_ids)]
-    n_imu = seqs[0].imu_range_for_scan(n_total - 1)[1] if with_ekf else 0
+
+    def make_seq(j, s):
+        return synth.make_sequence(seed=args.seed_base + s, n_scans=(n_cpu if j == 0 else n_total), H=args.rows, W=args.cols,
+                                   min_range=args.min_range, max_range=args.max_range)
+    seq0 = make_seq(0, 0 if args.equal_work else rank)
+    n_imu = seq0.imu_range_for_scan(n_total - 1)[1] if with_ekf else 0
     # S == 1: the single-sequence runner (its Gauss-Newton kernel caches hash probes across iterations);
     # S > 1: all sequences of this rank advance in lockstep in one batched runner (one launch per stage for all)
     class _One:
@@ -441,13 +447,29 @@ def main():
         def results(self, j): return self.r.results()
         def profile(self, **kw): return self.r.profile(**kw)
         def copy_traj(self, j, ptr, n): return self.r.copy_traj(ptr, n)
-    free = free_running(args, S)
     t_setup = time.perf_counter()
-    runner = _One() if S == 1 else core.BatchRunner(S, n_total, pps, n_imu, max_range=args.max_range,
-                                                    min_range=args.min_range, use_imu_prediction=use_imu,
-                                                    with_ekf=with_ekf, device_id=local_rank, free_running=free,
-                                                    scans_per_launch=args.scans_per_launch,
-                                                    team_workgroups=args.team_wgs if free else 0, **icp_over)
+    s_asked = S
+    while True:
+        free = free_running(args, S)
+        try:
+            runner = _One() if S == 1 else core.BatchRunner(S, n_total, pps, n_imu, max_range=args.max_range,
+                                                            min_range=args.min_range, use_imu_prediction=use_imu,
+                                                            with_ekf=with_ekf, device_id=local_rank, free_running=free,
+                                                            scans_per_launch=args.scans_per_launch,
+                                                            team_workgroups=args.team_wgs if free else 0, **icp_over)
+            break
+        except RuntimeError as e:
+            # the DEFAULT sequence count is sized for the 288 GB of an MI355X (about 0.8 GB per sequence): on a part with less memory -
+            # ptl_batch_create says what it needs and what is free - the default shrinks until it fits; an explicit
+            # --seqs-per-gpu that does not fit stays an error.  Every rank of a run takes the same decision from the same numbers.
+            if args.seqs_per_gpu == DEFAULT_SEQS and "of device memory" in str(e) and S > 16 and not seqs_explicit:
+                S -= 16
+                continue
+            raise
+    if S != s_asked:
+        print(f"bench.py rank {rank}: {s_asked} sequences do not fit this device, running {S}", file=sys.stderr, flush=True)
+    seq_ids = [j if args.equal_work else rank + world * j for j in range(S)]
+    seqs = [seq0] + [make_seq(j, s) for j, s in enumerate(seq_ids) if j > 0]
     team_g, teams = runner.team_geometry() if free else (0, 0)
     t_render, t_upload = 0.0, 0.0
     for j, sq in enumerate(seqs):
@@ -585,6 +607,8 @@ def main():
         th.join(timeout=GATHER_TIMEOUT_S)
         gathered = box.get("out")
         gather_err = "no answer after %d s" % GATHER_TIMEOUT_S if th.is_alive() else box.get("err")
+        if gather_err is not None:
+            print(f"bench.py rank {rank}: trajectory gather failed: {gather_err}", file=sys.stderr, flush=True)
         if parallel.max_over_ranks(0.0 if gather_err is None else 1.0, dist, device="cpu", group=ctl) > 0 and gather_err is None:
             gather_err = "failed on another rank"  # every rank takes the same exit below
 
@@ -725,7 +749,8 @@ def main():
             for j in range(S):
                 one = core.SeqRunner(n_total, pps, n_imu, max_range=args.max_range, min_range=args.min_range, use_imu_prediction=use_imu,
                                      with_ekf=with_ekf, device_id=local_rank,
-                                     **dict(icp_over, gn_workgroups=team_g, gn_lanes_per_point=8, gn_threads=args.gn_threads or 512))
+                                     **dict({k: v for k, v in icp_over.items() if k != "map_small_blocks"}, gn_workgroups=team_g, gn_lanes_per_point=8, gn_threads=args.gn_threads or 512,
+                                            map_block_capacity=icp_over.get("map_block_capacity", 1 << 19) + icp_over.get("map_small_blocks", 0)))
                 for k in range(n_total):
                     one.upload_scan(k, seqs[j].scan(k))
                 one.upload_imu(seqs[j].imu[:n_imu] if with_ekf else np.zeros((0, 7)),
@@ -742,7 +767,7 @@ def main():
             runner.close()  # (its 2 x 16 handles' streams would share hardware queues with the pipeline measured next)
             one = core.SeqRunner(n_total, pps, n_imu, max_range=args.max_range, min_range=args.min_range,
                                  use_imu_prediction=use_imu, with_ekf=with_ekf, device_id=local_rank,
-                                 **{k: v for k, v in icp_over.items() if k not in ("gn_lanes_per_point", "gn_threads", "gn_workgroups")})
+                                 **{k: v for k, v in icp_over.items() if k not in ("gn_lanes_per_point", "gn_threads", "gn_workgroups", "map_small_blocks")})
             for k in range(n_total):
                 one.upload_scan(k, sq.scan(k))
             one.upload_imu(sq.imu[:n_imu] if with_ekf else np.zeros((0, 7)),

@@ -71,6 +71,10 @@ typedef struct {
                                    * 8: throughput form (lane-per-point answer cache, 8 lanes per searched point, moment
                                    * accumulation; gn_threads <= 512) - what the batched runner uses per sequence, and the
                                    * faster form for dense scans (tens of thousands of source points) */
+    int64_t map_small_blocks;     /* 0 (default): every voxel owns a full block of max_points_per_voxel points.  > 0: that many SMALL blocks
+                                   * (one 128-byte line, 5 points) beside the map_block_capacity full ones - a voxel starts small and moves to a
+                                   * full block when a batch takes it past 5 points.  For sparse maps (BASELINE config 5, 0.1 m voxels: 3.6
+                                   * points per voxel): the pool shrinks to a third and a sparse voxel is one line.  Free-running batches only. */
 } ptl_icp_cfg;
 
 /* per-scan counters; identical meaning to oracle/oracle.h orc_icp_stats (SURVEY.md 8(d) byte model) */

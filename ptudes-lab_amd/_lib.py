@@ -24,7 +24,7 @@ class IcpCfg(C.Structure):
                 ("convergence", C.c_double), ("device_id", C.c_int32), ("scan_cols", C.c_int32),
                 ("max_points_per_scan", C.c_int64), ("map_block_capacity", C.c_int64),
                 ("map_table_capacity", C.c_int64), ("gn_workgroups", C.c_int32), ("rebuild_every", C.c_int32),
-                ("gn_threads", C.c_int32), ("gn_lanes_per_point", C.c_int32)]
+                ("gn_threads", C.c_int32), ("gn_lanes_per_point", C.c_int32), ("map_small_blocks", C.c_int64)]
 
 
 class IcpStats(C.Structure):

@@ -93,8 +93,9 @@ struct DevState {
     int n_down_ins;     // frame_down points of the scan whose map update is in flight (n_down belongs to the next scan's K3 already)
     int stats_pending;  // scan whose map_voxels / map_points are still to be recorded once its map update is complete, or -1
     // map
-    int pool_hw, pad2;
+    int pool_hw, pool_hw_s;   // high-water marks: full blocks (an id bound, >= n_small) | small blocks
     int free_top, n_live;
+    int free_top_s, mig_n;    // free small blocks | small blocks waiting for their move to a full block (this scan)
     long long map_points;
     unsigned tab_used;
     int err_flags;
@@ -136,6 +137,12 @@ struct Ctx {
     TabEnt* tab;
     unsigned tmask;
     unsigned char* blocks;
+    unsigned char* big_base;  // blocks + n_small * (SMALL_BYTES - bstride): full block b (>= n_small) at big_base + b * bstride
+    int n_small;              // small blocks (ids below it); 0 = every block is a full one
+    int* free_stack_s;        // free small ids
+    int* mig_list;            // [n_small] small blocks a batch has outgrown (prune -> d_map_migrate)
+    int* bhdr;        // [pool_cap][4]  block directory: count | table slot | batch points pending | pad
+    double* bfirst;   // [pool_cap][3]  ... and the voxel's first point
     int bstride, pool_cap;
     int* free_stack;
     // GN
@@ -155,16 +162,32 @@ struct Ctx {
     int traj_cap;
 };
 
-// One block per voxel: a 16-byte header {i32 count, i32 table slot, pad} and then the stored points as (x, y, z) triples,
-// point j at blk_x()[3 j .. 3 j + 2].  HBM serves whole 128-byte lines (tools/hip/gather_probe.hip: a scattered 8-byte read
-// costs as much bandwidth as a full line), and a voxel holds 7-8 points on average: header + points of a typical voxel
-// sit in its first two lines, a voxel of <= 4 points and the first point every prune pass looks at in the first one.
-// (Round 1-2 kept x[P] | y[P] | z[P] | header: three to four lines per visit, four per pruned block.)
-#define BLK_HDR_BYTES 16
+// One block per voxel: the stored points as (x, y, z) triples, point j at blk_x()[3 j .. 3 j + 2], and nothing else.  HBM serves whole
+// 128-byte lines (tools/hip/gather_probe.hip: a scattered 8-byte read costs as much bandwidth as a full line), so a block's first line
+// carries its first five points.  What the map update needs per voxel beside the points lives in a DIRECTORY indexed by block id
+// (round 5): bhdr[b] = {i32 count, i32 table slot, i32 points of the current batch not yet counted in (free-running kernel:
+// insert b -> prune), pad} and bfirst[b] = the voxel's first point (a copy of blk_x()[0..2]).  The prune pass, which looks at the first
+// point of EVERY live voxel every scan (VoxelHashMap::RemovePointsFarFromLocation), streams 40 coalesced bytes per voxel from the
+// directory instead of pulling one scattered 128-byte line per voxel out of the pool: BASELINE config 5 holds 1.6 M voxels -
+// 200 MB of lines per scan (a sixth of its HBM traffic) against 63 MB.  The search never looks at a header (the stored count comes with
+// the table entry), so its lines hold points only.
+// (Rounds 3-4: header + triples in the block; rounds 1-2: x[P] | y[P] | z[P] | header, three to four lines per visit.)
+// Two block classes by id range (round 5; n_small = 0: one class, as before): ids [0, n_small) are SMALL blocks - one 128-byte line,
+// SMALL_CAP = 5 points - ids [n_small, pool_cap) are full blocks of bstride bytes (P points).  A voxel starts in a small block and
+// moves to a full one when a batch takes it past five points (d_map_migrate, free-running kernel only).  BASELINE config 5 (0.1 m
+// voxels) holds 3.6 points per voxel, 77 % of the voxels <= 4: the pool shrinks to about a third and a sparse voxel is ONE line.
+#define SMALL_CAP 5
+#define SMALL_BYTES 128
 template <class CT>
-__device__ __forceinline__ double* blk_x(const CT& c, int b) { return (double*)(c.blocks + (size_t)b * c.bstride + BLK_HDR_BYTES); }
+__device__ __forceinline__ double* blk_x(const CT& c, int b) {
+    return (double*)(b < c.n_small ? c.blocks + (size_t)b * SMALL_BYTES : c.big_base + (size_t)b * c.bstride);
+}
 template <class CT>
-__device__ __forceinline__ int* blk_hdr(const CT& c, int b) { return (int*)(c.blocks + (size_t)b * c.bstride); }
+__device__ __forceinline__ int blk_cap(const CT& c, int b) { return b < c.n_small ? SMALL_CAP : c.P; }
+template <class CT>
+__device__ __forceinline__ int* blk_hdr(const CT& c, int b) { return c.bhdr + 4 * (size_t)b; }
+template <class CT>
+__device__ __forceinline__ double* blk_first(const CT& c, int b) { return c.bfirst + 3 * (size_t)b; }
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long h) {
     h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;
@@ -1630,7 +1653,8 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
 #define GN8_KCAND 4           /* candidates an answer row keeps (2..5); a CPU simulation of the policy on the bench's sweeps: repeated searches per scan
                                  32 k (1) | 11.5 k (2) | 6.5 k (3) | 4.4 k (4) | 2.4 k (6) for ~6800 source points x 36 iterations */
 #endif
-#define GN8_ANS_ROW ((3 + 3 * GN8_KCAND + 2 + 1) & ~1)  /* doubles per answer row: s0 (3) | the K nearest candidates (3 each) | bound | ids, counts (packed) [| pad] */
+#define GN8_ANS_ROW ((3 + 3 * GN8_KCAND + 3 + 1) & ~1)  /* doubles per answer row: s0 (3) | the K nearest candidates (3 each) | bound | ids, counts (packed) | voxel key of s0 [| pad]
+                                                          (K = 4: 18 doubles = 144 B as before - the key sits where the padding was, and phase A no longer reads pc_key[]) */
 #define GN8_ANS_D (3 + 3 * GN8_KCAND)
 #ifndef GN8_SPEC
 #define GN8_SPEC 2            /* how many of the nearest other boxes the first search round takes along, their loads in flight with the own voxel's (0 .. 3; make SPEC=n) */
@@ -1962,6 +1986,7 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
         arow[GN8_ANS_D] = sl2;
         meta |= (unsigned long long)(unsigned)ctot << 50 | (unsigned long long)(unsigned)nvalid << 60;
         arow[GN8_ANS_D + 1] = __longlong_as_double((long long)meta);
+        arow[GN8_ANS_D + 2] = __longlong_as_double((long long)key);  // (= pc_key[i]: the voxel this search looked around)
     }
     SRCH_CLK(4);  // reductions + answer row
 #ifdef GN_PHASE_CLOCKS
@@ -2052,11 +2077,12 @@ __device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, b
     if (valid) {
         const double* sp0 = first ? c.src0 : c.src_cur;
         if (want_pos) { p.px = sp0[3 * (size_t)i]; p.py = sp0[3 * (size_t)i + 1]; p.pz = sp0[3 * (size_t)i + 2]; }
-        if (!first) {
-            p.key = c.pc_key[i];
+        if (!first) {  // (the voxel key of the row's s0 travels in the row: no separate read of pc_key[])
             const double2* row = (const double2*)(c.pc_ans + GN8_ANS_ROW * (size_t)i);
 #pragma unroll
             for (int k = 0; k < GN8_ANS_ROW / 2; ++k) p.r[k] = row[k];
+            const double kd = ((GN8_ANS_D + 2) & 1) ? p.r[(GN8_ANS_D + 2) / 2].y : p.r[(GN8_ANS_D + 2) / 2].x;
+            p.key = (unsigned long long)__double_as_longlong(kd);
         }
     }
     return p;
@@ -2677,14 +2703,23 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
         // free stack, then the headers) - step by step per point it is a chain of dependent memory round trips per u, and some
         // lane of a wavefront creates a voxel for nearly every u
         int top[U], blk[U];
+        bool small[U];
+        if (c.n_small > 0) {  // (uniform) two classes: a new voxel starts in a small block; the full pool only when the small one has run out
 #pragma unroll
-        for (int u = 0; u < U; ++u) top[u] = created[u] ? atomicSub(&st->free_top, 1) - 1 : -1;
+            for (int u = 0; u < U; ++u) { top[u] = created[u] ? atomicSub(&st->free_top_s, 1) - 1 : -1; small[u] = created[u]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (created[u] && top[u] < 0) { atomicAdd(&st->free_top_s, 1); small[u] = false; top[u] = atomicSub(&st->free_top, 1) - 1; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { top[u] = created[u] ? atomicSub(&st->free_top, 1) - 1 : -1; small[u] = false; }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             blk[u] = -1;
             if (!created[u]) continue;
             if (top[u] < 0) atomicAdd(&st->free_top, 1);  // pool exhausted: put the count back (the prune pass pushes at free_top: it must not find it negative)
-            else blk[u] = c.free_stack[top[u]];
+            else blk[u] = small[u] ? c.free_stack_s[top[u]] : c.free_stack[top[u]];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -2695,7 +2730,7 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
                 h[1] = slot[u];
                 h[2] = 0;  // (points of a batch waiting to be counted in: FUSE form of insert b / prune)
                 atomicAdd(&st->n_live, 1);
-                atomicMax(&st->pool_hw, blk[u] + 1);
+                if (small[u]) atomicMax(&st->pool_hw_s, blk[u] + 1); else atomicMax(&st->pool_hw, blk[u] + 1);
             } else {
                 atomicOr(&st->err_flags, ERR_POOL);
             }
@@ -2764,10 +2799,12 @@ __device__ __forceinline__ void d_map_insert_b(const Ctx& c, const int* n_ptr, i
         }
         if (slot[u] < 0 || pb[u] < 0) continue;
         if (FUSE && rank[u] == 0) blk_hdr(c, pb[u] & BLK_ID_MASK)[2] = len[u];
+        if (FUSE && c.n_small > 0) c.prank[i] = rank[u];  // (d_map_migrate places the points a small block has no room for)
         const int pos = cnt[u] + rank[u];
-        if (pos < c.P) {
+        if (pos < blk_cap(c, pb[u] & BLK_ID_MASK)) {
             double* X = blk_x(c, pb[u] & BLK_ID_MASK);
             X[3 * pos] = w[u][0]; X[3 * pos + 1] = w[u][1]; X[3 * pos + 2] = w[u][2];
+            if (pos == 0) { double* F = blk_first(c, pb[u] & BLK_ID_MASK); F[0] = w[u][0]; F[1] = w[u][1]; F[2] = w[u][2]; }  // the directory's copy (prune, rebuild)
         }
     }
 }
@@ -2811,27 +2848,45 @@ __device__ __forceinline__ void d_map_insert_c(const Ctx& c, const int* n_ptr, i
 }
 
 // ------------------------------------------------------------------------------------------------ K10
+// The passes over "every block" walk a VIRTUAL index v: the small blocks below their high-water mark, then the full blocks below
+// theirs (block ids are handed out low-first in both classes: nothing lives above the marks).  One class: v = block id.
+__device__ __forceinline__ int blk_virtual_count(const Ctx& c, const DevState* st) { return st->pool_hw_s + (st->pool_hw - c.n_small); }
+__device__ __forceinline__ int blk_from_virtual(const Ctx& c, int hw_s, int v) { return v < hw_s ? v : c.n_small + (v - hw_s); }
+// a block goes back to the free stack of its class
+__device__ __forceinline__ void blk_free(const Ctx& c, DevState* st, int b) {
+    if (b < c.n_small) {
+        const int top = atomicAdd(&st->free_top_s, 1);
+        if (top >= 0 && top < c.n_small) c.free_stack_s[top] = b;
+    } else {
+        const int top = atomicAdd(&st->free_top, 1);
+        if (top >= 0 && top < c.pool_cap - c.n_small) c.free_stack[top] = b;
+    }
+}
 // RemovePointsFarFromLocation: a voxel goes when its FIRST point is farther than max_range from the origin
-// FUSE: ... and counts in what insert b left in the headers (see there)
+// FUSE: ... and counts in what insert b left in the headers (see there).  With two block classes a small block whose batch takes it
+// past its capacity is only NOTED here (mig_list): its move to a full block pops the full pool, which this pass pushes to - the
+// migration pass runs behind a team barrier (d_map_migrate).
 template <int U, bool FUSE = false>
 __device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_xyz, int use_new_pose, const Slice sl) {
     const int BS = (int)blockDim.x, base = sl.b * BS * U + (int)threadIdx.x;
     DevState* st = c.st;
-    const int hw = st->pool_hw;  // block ids are handed out low-first: nothing lives above the high-water mark
+    const int hw_s = st->pool_hw_s, nv = hw_s + (st->pool_hw - c.n_small);
     double ox, oy, oz;
     if (use_new_pose) { ox = st->new_pose[3]; oy = st->new_pose[7]; oz = st->new_pose[11]; }
     else { ox = origin_xyz[0]; oy = origin_xyz[1]; oz = origin_xyz[2]; }
-    int cnt[U], hs[U], add[U];
+    int cnt[U], hs[U], add[U], bid[U];
     double x0[U], y0[U], z0[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int b = base + u * BS;
-        cnt[u] = 0; hs[u] = -1; add[u] = 0; x0[u] = y0[u] = z0[u] = 0.0;
-        if (b < hw) {
+        const int v = base + u * BS;
+        cnt[u] = 0; hs[u] = -1; add[u] = 0; x0[u] = y0[u] = z0[u] = 0.0; bid[u] = -1;
+        if (v < nv) {
+            const int b = blk_from_virtual(c, hw_s, v);
+            bid[u] = b;
             const int* h = blk_hdr(c, b);
             cnt[u] = h[0]; hs[u] = h[1];
             if (FUSE) add[u] = h[2];
-            const double* X = blk_x(c, b);
+            const double* X = blk_first(c, b);
             x0[u] = X[0]; y0[u] = X[1]; z0[u] = X[2];  // (read whether or not the block is live: no dependent round trip)
         }
     }
@@ -2841,19 +2896,24 @@ __device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_x
         int nc = cnt[u];
         if (FUSE && add[u] > 0) { nc += add[u]; if (nc > c.P) nc = c.P; }
         if (nc <= 0) continue;
-        const int b = base + u * BS;
+        const int b = bid[u];
         const double dx = x0[u] - ox, dy = y0[u] - oy, dz = z0[u] - oz;
         if (dx * dx + dy * dy + dz * dz > c.max_range * c.max_range) {
             c.tab[hs[u]].key = TOMB_KEY;
             c.tab[hs[u]].blk = -1;
             blk_hdr(c, b)[0] = 0;
             if (FUSE && add[u] > 0) { blk_hdr(c, b)[2] = 0; c.tab[hs[u]].head = -1; }
-            const int top = atomicAdd(&st->free_top, 1);
-            if (top >= 0 && top < c.pool_cap) c.free_stack[top] = b;
+            blk_free(c, st, b);
             atomicSub(&st->n_live, 1);
             if (FUSE) added -= cnt[u];  // (what this batch brought was never counted)
             else atomicAdd((unsigned long long*)&st->map_points, (unsigned long long)(-(long long)cnt[u]));
-        } else if (FUSE && add[u] > 0) {  // what insert c does in the other drivers: publish the new count, reset the batch list
+        } else if (FUSE && add[u] > 0) {
+            if (nc > blk_cap(c, b)) {  // a small block the batch has outgrown: its points move to a full block behind the next barrier
+                const int w = atomicAdd(&st->mig_n, 1);
+                if (w < c.n_small) c.mig_list[w] = b;
+                continue;
+            }
+            // what insert c does in the other drivers: publish the new count, reset the batch list
             int* h = blk_hdr(c, b);
             h[0] = nc; h[2] = 0;
             c.tab[hs[u]].head = -1;
@@ -2866,15 +2926,65 @@ __device__ __forceinline__ void d_map_prune(const Ctx& c, const double* origin_x
         if ((threadIdx.x & 63) == 0 && added != 0) atomicAdd((unsigned long long*)&c.st->map_points, (unsigned long long)added);
     }
 }
+// A small block the batch has outgrown (noted by the prune pass) moves to a full block: its stored points are copied, the batch's points
+// that found no room (position >= SMALL_CAP; insert b left their ranks in prank[]) are placed from the world-frame copy of the batch
+// along the voxel's batch list, the directory entry and the table entry follow, the small block goes back to its stack.  One thread per
+// voxel; a scan of BASELINE config 5 moves a few thousand.  Runs behind a team barrier after the prune pass: it POPS the full pool,
+// which the prune pass pushes to (and pushes the small pool, which nobody pops here).
+__device__ __forceinline__ void d_map_migrate(const Ctx& c, const Slice sl) {
+    DevState* st = c.st;
+    const int t = sl.b * (int)blockDim.x + (int)threadIdx.x;
+    const int nm = st->mig_n < c.n_small ? st->mig_n : c.n_small;
+    if (t >= nm) return;
+    const int b = c.mig_list[t];
+    int* h = blk_hdr(c, b);
+    const int cnt = h[0], slot = h[1], add = h[2];
+    int nc = cnt + add;
+    if (nc > c.P) nc = c.P;
+    const int top = atomicSub(&st->free_top, 1) - 1;
+    if (top < 0) {  // no full block left: the voxel keeps what its small block holds, the loss is flagged
+        atomicAdd(&st->free_top, 1);
+        atomicOr(&st->err_flags, ERR_POOL);
+        h[0] = SMALL_CAP; h[2] = 0;
+        c.tab[slot].head = -1;
+        c.tab[slot].blk = b | (SMALL_CAP << 24);
+        atomicAdd((unsigned long long*)&st->map_points, (unsigned long long)(long long)(SMALL_CAP - cnt));
+        return;
+    }
+    const int nb = c.free_stack[top];
+    const double* Xo = blk_x(c, b);
+    double* Xn = blk_x(c, nb);
+    const int held = (cnt + add < SMALL_CAP) ? cnt + add : SMALL_CAP;  // the stored points + the batch's that found room
+    for (int j = 0; j < 3 * held; ++j) Xn[j] = Xo[j];
+    int j = c.tab[slot].head;
+    for (int steps = 0; j >= 0 && steps <= add; ++steps) {
+        const int pos = cnt + c.prank[j];
+        if (pos >= SMALL_CAP && pos < c.P) { Xn[3 * pos] = c.fdw[3 * (size_t)j]; Xn[3 * pos + 1] = c.fdw[3 * (size_t)j + 1]; Xn[3 * pos + 2] = c.fdw[3 * (size_t)j + 2]; }
+        j = c.nxt[j];
+    }
+    int* hn = blk_hdr(c, nb);
+    hn[0] = nc; hn[1] = slot; hn[2] = 0;
+    const double* Fo = blk_first(c, b);
+    double* Fn = blk_first(c, nb);
+    Fn[0] = Fo[0]; Fn[1] = Fo[1]; Fn[2] = Fo[2];
+    c.tab[slot].head = -1;
+    c.tab[slot].blk = nb | (nc << 24);
+    h[0] = 0; h[2] = 0;
+    blk_free(c, st, b);
+    atomicMax(&st->pool_hw, nb + 1);
+    atomicAdd((unsigned long long*)&st->map_points, (unsigned long long)(long long)(nc - cnt));
+}
 
 // ------------------------------------------------------------------------------------------------ K11
 // after the table has been reset to EMPTY: re-enter every live voxel
 __device__ __forceinline__ void d_map_rebuild(const Ctx& c, const Slice sl) {
-    const int b = sl.b * (int)blockDim.x + (int)threadIdx.x;
-    if (b >= c.st->pool_hw) return;
+    const int v = sl.b * (int)blockDim.x + (int)threadIdx.x;
+    const int hw_s = c.st->pool_hw_s;
+    if (v >= hw_s + (c.st->pool_hw - c.n_small)) return;
+    const int b = blk_from_virtual(c, hw_s, v);
     int* h = blk_hdr(c, b);
     if (h[0] <= 0) return;
-    const double* X = blk_x(c, b);
+    const double* X = blk_first(c, b);
     unsigned long long key; int kx, ky, kz;
     vox_key(v3(X[0], X[1], X[2]), c.vs, key, kx, ky, kz);
     unsigned s = brick_slot(key, c.tmask);
@@ -2890,7 +3000,7 @@ __device__ __forceinline__ void d_map_rebuild(const Ctx& c, const Slice sl) {
 // export of the map points (KissICPWrapper.local_map_points)
 __global__ __launch_bounds__(256) void k_map_export(Ctx c, double* out, int* counter, int max_points) {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= c.st->pool_hw) return;
+    if (b >= c.pool_cap) return;
     const int cnt = blk_hdr(c, b)[0];
     if (cnt <= 0) return;
     const int o = atomicAdd(counter, cnt);
@@ -2993,6 +3103,8 @@ __device__ __forceinline__ Ctx load_seq_ctx(const SeqCtx* a, int s, int scan_k) 
     c.fd = uniform_ptr(c.fd); c.fdw = uniform_ptr(c.fdw); c.src0 = uniform_ptr(c.src0); c.coltab = uniform_ptr(c.coltab);
     c.pslot = uniform_ptr(c.pslot); c.nxt = uniform_ptr(c.nxt); c.prank = uniform_ptr(c.prank); c.plen = uniform_ptr(c.plen);
     c.tab = uniform_ptr(c.tab); c.blocks = uniform_ptr(c.blocks); c.free_stack = uniform_ptr(c.free_stack); c.st = uniform_ptr(c.st);
+    c.bhdr = uniform_ptr(c.bhdr); c.bfirst = uniform_ptr(c.bfirst); c.big_base = uniform_ptr(c.big_base);
+    c.free_stack_s = uniform_ptr(c.free_stack_s); c.mig_list = uniform_ptr(c.mig_list);
     return c;
 }
 __global__ __launch_bounds__(1024) void k_scan_prologue(Ctx c) { d_scan_prologue(c); }

@@ -100,6 +100,7 @@ extern "C" int ptl_icp_default_cfg(ptl_icp_cfg* cfg, double max_range, double mi
     cfg->rebuild_every = 128;
     cfg->gn_threads = 1024;
     cfg->gn_lanes_per_point = 32;
+    cfg->map_small_blocks = 0;
     return PTL_OK;
 }
 
@@ -111,7 +112,7 @@ static int icp_free(ptl_icp* h) {
     (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
     void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vtab1, c.vtab2, c.bcnt1, c.bcnt2, h->fd_buf[0], h->fd_buf[1], c.src0,
-                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.free_stack, c.wg_clk, c.pc_key, c.pc_pb, c.pc_ans, c.gn_rows_ll, c.gn_xsum_ll,
+                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.bhdr, c.bfirst, c.free_stack, c.free_stack_s, c.mig_list, c.wg_clk, c.pc_key, c.pc_pb, c.pc_ans, c.gn_rows_ll, c.gn_xsum_ll,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter, h->d_row_mask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -125,17 +126,19 @@ static int icp_free(ptl_icp* h) {
     return PTL_OK;
 }
 
-__global__ void k_fill_free_stack(int* fs, int n) {
+__global__ void k_fill_free_stack(int* fs, int n, int base) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) fs[i] = n - 1 - i;  // pops hand out low block ids first
+    if (i < n) fs[i] = base + n - 1 - i;  // pops hand out low block ids first
 }
-__global__ void k_state_init(DevState* st, int pool_cap) {
+__global__ void k_state_init(DevState* st, int n_full, int n_small) {
     if (threadIdx.x || blockIdx.x) return;
     memset(st, 0, sizeof(DevState));
     Rt I = rt_identity();
     rt_to16(I, st->pose_first); rt_to16(I, st->pose_prev); rt_to16(I, st->pose_last);
     rt_to16(I, st->model_dev); rt_to16(I, st->guess); rt_to16(I, st->new_pose); rt_to16(I, st->T_icp);
-    st->free_top = pool_cap;
+    st->free_top = n_full;
+    st->free_top_s = n_small;
+    st->pool_hw = n_small;  // (an id bound: the full blocks' ids start behind the small ones)
     st->stats_pending = -1;
     st->dbg_dead_wg = -1;
 }
@@ -158,13 +161,16 @@ static int icp_reset_device(ptl_icp* h) {
     HIPCHK(hipMemsetAsync(c.vtab1, 0xFF, vcap * sizeof(VdsEnt), h->stream));  // (key = EMPTY, index = none)
     HIPCHK(hipMemsetAsync(c.vtab2, 0xFF, vcap2 * sizeof(VdsEnt), h->stream));
     HIPCHK(hipMemsetAsync(c.tab, 0xFF, ((size_t)c.tmask + 1) * sizeof(TabEnt), h->stream));
-    HIPCHK(hipMemsetAsync(c.blocks, 0, (size_t)c.pool_cap * c.bstride, h->stream));
+    HIPCHK(hipMemsetAsync(c.blocks, 0, (size_t)c.n_small * SMALL_BYTES + (size_t)(c.pool_cap - c.n_small) * c.bstride, h->stream));
+    HIPCHK(hipMemsetAsync(c.bhdr, 0, (size_t)c.pool_cap * 16, h->stream));
+    HIPCHK(hipMemsetAsync(c.bfirst, 0, (size_t)c.pool_cap * 24, h->stream));
     HIPCHK(hipMemsetAsync(c.bcnt1, 0, (size_t)h->nblk_scan * sizeof(int), h->stream));  // look-back words of the compactions: tag 0 = never published
     HIPCHK(hipMemsetAsync(c.bcnt2, 0, (size_t)h->nblk_scan * sizeof(int), h->stream));
     HIPCHK(hipMemsetAsync(c.gn_rows_ll, 0, (size_t)2 * c.G * 64 * 8, h->stream));  // the launch epoch restarts with the state
     HIPCHK(hipMemsetAsync(c.gn_xsum_ll, 0, (size_t)2 * 8 * 8 * 64 * 8, h->stream));
-    k_fill_free_stack<<<(c.pool_cap + 255) / 256, 256, 0, h->stream>>>(c.free_stack, c.pool_cap);
-    k_state_init<<<1, 64, 0, h->stream>>>(c.st, c.pool_cap);
+    k_fill_free_stack<<<(c.pool_cap - c.n_small + 255) / 256, 256, 0, h->stream>>>(c.free_stack, c.pool_cap - c.n_small, c.n_small);
+    if (c.n_small > 0) k_fill_free_stack<<<(c.n_small + 255) / 256, 256, 0, h->stream>>>(c.free_stack_s, c.n_small, 0);
+    k_state_init<<<1, 64, 0, h->stream>>>(c.st, c.pool_cap - c.n_small, c.n_small);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->map_stream));
     HIPCHK(hipStreamSynchronize(h->stream));  // the other streams must not start on half-reset tables
@@ -178,7 +184,11 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
     // the search maps one lane of a 32-lane group to one stored point of a voxel: more than 32 per voxel would be stored and never examined
     if (cfg->max_points_per_voxel < 1 || cfg->max_points_per_voxel > 32) return set_err(PTL_ERR_ARG, "max_points_per_voxel must be in [1, 32]");
-    if (cfg->map_block_capacity < 1 || cfg->map_block_capacity >= (1 << 24) - 1) return set_err(PTL_ERR_ARG, "map_block_capacity must be below 2^24 - 1");
+    if (cfg->map_block_capacity < 1 || cfg->map_small_blocks < 0 || cfg->map_block_capacity + cfg->map_small_blocks >= (1 << 24) - 1)
+        return set_err(PTL_ERR_ARG, "map_block_capacity + map_small_blocks must be below 2^24 - 1");
+    if (cfg->map_small_blocks > 0 && !batch_member)
+        return set_err(PTL_ERR_ARG, "map_small_blocks (two block classes) is served by the free-running batch driver only: a voxel's move to a full block is part of its map update");
+    if (cfg->map_small_blocks > 0 && cfg->max_points_per_voxel < SMALL_CAP) return set_err(PTL_ERR_ARG, "map_small_blocks needs max_points_per_voxel >= %d", SMALL_CAP);
     if (cfg->map_table_capacity & (cfg->map_table_capacity - 1)) return set_err(PTL_ERR_ARG, "map_table_capacity must be a power of two");
     if (cfg->max_points_per_scan < 1 || cfg->gn_workgroups < 1 || cfg->gn_workgroups > 512) return set_err(PTL_ERR_ARG, "bad capacity (gn_workgroups must be in [1, 512])");
     if (cfg->max_iterations < 1 || cfg->max_iterations > 1000) return set_err(PTL_ERR_ARG, "max_iterations must be in [1, 1000]");
@@ -242,8 +252,9 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     c.vmask = (unsigned)(vcap - 1);
     c.vmask2 = (unsigned)(vcap2 - 1);
     c.tmask = (unsigned)(cfg->map_table_capacity - 1);
-    c.bstride = (int)(((size_t)c.P * 24 + 16 + 127) / 128 * 128);
-    c.pool_cap = (int)cfg->map_block_capacity;
+    c.bstride = (int)(((size_t)c.P * 24 + 127) / 128 * 128);  // points only: the per-voxel header lives in the block directory (bhdr / bfirst)
+    c.n_small = (int)cfg->map_small_blocks;
+    c.pool_cap = (int)(cfg->map_block_capacity + cfg->map_small_blocks);  // block ids: the small blocks first, then map_block_capacity full ones
     c.G = cfg->gn_workgroups;
     h->nblk_scan = (int)((n + 255) / 256);
     h->traj_cap = 4096;
@@ -265,8 +276,11 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= dalloc(&c.pslot, n) == hipSuccess && dalloc(&c.nxt, n) == hipSuccess;
     ok &= dalloc(&c.prank, n) == hipSuccess && dalloc(&c.plen, n) == hipSuccess;
     ok &= dalloc(&c.tab, (size_t)cfg->map_table_capacity) == hipSuccess;
-    ok &= hipMalloc((void**)&c.blocks, (size_t)c.pool_cap * c.bstride) == hipSuccess;
-    ok &= dalloc(&c.free_stack, c.pool_cap) == hipSuccess;
+    ok &= hipMalloc((void**)&c.blocks, (size_t)c.n_small * SMALL_BYTES + (size_t)(c.pool_cap - c.n_small) * c.bstride) == hipSuccess;
+    c.big_base = (unsigned char*)((uintptr_t)c.blocks + (uintptr_t)c.n_small * SMALL_BYTES - (uintptr_t)c.n_small * (uintptr_t)c.bstride);
+    ok &= dalloc(&c.bhdr, (size_t)c.pool_cap * 4) == hipSuccess && dalloc(&c.bfirst, (size_t)c.pool_cap * 3) == hipSuccess;
+    ok &= dalloc(&c.free_stack, c.pool_cap - c.n_small) == hipSuccess;
+    ok &= dalloc(&c.free_stack_s, (size_t)(c.n_small > 0 ? c.n_small : 1)) == hipSuccess && dalloc(&c.mig_list, (size_t)(c.n_small > 0 ? c.n_small : 1)) == hipSuccess;
     ok &= dalloc(&c.pc_key, n) == hipSuccess && dalloc(&c.pc_pb, 32 * n) == hipSuccess && dalloc(&c.pc_ans, GN8_ANS_ROW * n) == hipSuccess;
     ok &= hipHostMalloc((void**)&h->n_src_hint, sizeof(int)) == hipSuccess;
     if (h->n_src_hint) *h->n_src_hint = 0;
@@ -295,10 +309,10 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
 // probe rows, answer rows, the per-call input), plus the map table, the block pool and its free stack
 static size_t icp_footprint_bytes(const ptl_icp_cfg* cfg) {
     const size_t n = (size_t)cfg->max_points_per_scan;
-    const size_t bstride = ((size_t)cfg->max_points_per_voxel * 24 + 16 + 127) / 128 * 128;
+    const size_t bstride = ((size_t)cfg->max_points_per_voxel * 24 + 127) / 128 * 128;
     const size_t per_point = 24 + 4 + 4 + 24 * 2 + 24 + 24 + 24 + 4 * 4 + 8 + 128 + GN8_ANS_ROW * 8 + 24 + 8;
     return n * per_point + (vds_table_slots(VDS1_SLOTS_PER_POINT, n) + vds_table_slots(VDS2_SLOTS_PER_POINT, n)) * sizeof(VdsEnt) + (size_t)cfg->map_table_capacity * sizeof(TabEnt) +
-           (size_t)cfg->map_block_capacity * (bstride + 4) + (size_t)4096 * (128 + sizeof(ScanStats)) + (1u << 20);
+           (size_t)cfg->map_block_capacity * (bstride + 4 + 16 + 24) + (size_t)cfg->map_small_blocks * (SMALL_BYTES + 8 + 16 + 24) + (size_t)4096 * (128 + sizeof(ScanStats)) + (1u << 20);
 }
 extern "C" int ptl_icp_create(const ptl_icp_cfg* cfg, ptl_icp** out) { return icp_create_impl(cfg, nullptr, out); }
 extern "C" int ptl_icp_destroy(ptl_icp* h) { return icp_free(h); }
@@ -1423,6 +1437,9 @@ static int batch_check_seq_run(ptl_batch* b) {
     const int gseq = batch_gseq(b), J = ic.gn_workgroups / 8;
     if (gseq < 1 || gseq > J || gseq > 64) return set_err(PTL_ERR_ARG, "a team needs 1 .. min(64, gn_workgroups / 8 = %d) workgroups, not %d", J, gseq);
     if (b->S > 8 * SEQ_SLOTS) return set_err(PTL_ERR_ARG, "at most %d sequences", 8 * SEQ_SLOTS);
+    // the look-back words of the one-pass compactions tell a stale count from this scan's by a 16-bit tag (scan % 65535 + 1, lookback_tag):
+    // a run must not come back to a tag it has used
+    if (b->cfg.n_scans >= 65535) return set_err(PTL_ERR_ARG, "free-running batches run at most 65534 scans per sequence (look-back tags of the compaction passes)");
     if (b->cfg.with_ekf && ic.gn_threads < 384) return set_err(PTL_ERR_ARG, "free-running batches with a filter need gn_threads >= 384 (the filter step maps one thread to each of the 324 covariance cells)");
     int per_cu = 0, cus = 0;
     const bool p20 = ic.max_points_per_voxel == 20;
@@ -1490,6 +1507,7 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
         b->force_agent = (e && strcmp(e, "agent") == 0) ? 1 : 0;
     }
     b->free_running = cfg->icp.gn_lanes_per_point == 8;
+    if (!b->free_running && cfg->icp.map_small_blocks > 0) { ptl_batch_destroy(b); return set_err(PTL_ERR_ARG, "map_small_blocks (two block classes) needs the free-running driver (gn_lanes_per_point = 8)"); }
     b->team_wgs = 0; b->seq_run_checked = false;
     b->scans_per_launch = 256;
     b->next_scan = 0; b->n_out = 0; b->ctx_dirty = true; b->prof = false; b->ev_used = 0; b->gn_ms = 0; b->gn_launches = 0;
@@ -1686,6 +1704,7 @@ extern "C" int ptl_batch_set_driver(ptl_batch* b, int32_t free_running, int64_t 
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
     if (scans_per_launch > 4096) return set_err(PTL_ERR_ARG, "scans_per_launch: at most 4096 (every wait inside the persistent kernel has a poll budget worth seconds, and a launch must stay well below it)");
     if (scans_per_launch > 0) b->scans_per_launch = scans_per_launch;
+    if (!free_running && b->cfg.icp.map_small_blocks > 0) return set_err(PTL_ERR_ARG, "map_small_blocks (two block classes) needs the free-running driver");
     const bool was = b->free_running;
     b->free_running = free_running != 0;
     b->seq_run_checked = false;
@@ -1720,6 +1739,7 @@ extern "C" int ptl_batch_enqueue(ptl_batch* b, int64_t n) {
     if (b->ctx_dirty) { int rc = batch_push_ctx(b); if (rc) return rc; }
     if (b->free_running) return batch_enqueue_free(b, n);
     if (b->S > 32) return set_err(PTL_ERR_ARG, "the lockstep driver serves up to 32 sequences (four per XCD); %d need the free-running one", b->S);
+    if (b->cfg.icp.map_small_blocks > 0) return set_err(PTL_ERR_ARG, "map_small_blocks (two block classes) needs the free-running driver");
     const bool with_ekf = b->cfg.with_ekf != 0;
     const int S = b->S;
     const int64_t pps = b->cfg.points_per_scan;
@@ -1995,8 +2015,23 @@ RcclApi* rccl_api() {
     static bool tried = false;
     if (tried) return api.lib ? &api : nullptr;
     tried = true;
+    // RCCL has to sit on the SAME HIP runtime as this library: a process may hold two ROCm stacks (torch bundles its own libamdhip64 /
+    // librccl with the same sonames; whichever HIP runtime was mapped first serves everybody).  So the first choice is the librccl that
+    // lives beside the HIP runtime this library is actually bound to; a bare soname comes last (it would return whatever is already mapped).
     const char* override_path = getenv("PTL_RCCL_PATH");
-    const char* names[] = {override_path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    char beside[2][600] = {"", ""};
+    {
+        Dl_info info;
+        if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+            const char* slash = strrchr(info.dli_fname, '/');
+            if (slash) {
+                const int dir = (int)(slash - info.dli_fname);
+                snprintf(beside[0], sizeof beside[0], "%.*s/librccl.so.1", dir, info.dli_fname);
+                snprintf(beside[1], sizeof beside[1], "%.*s/librccl.so", dir, info.dli_fname);
+            }
+        }
+    }
+    const char* names[] = {override_path, beside[0], beside[1], "librccl.so.1", "librccl.so"};
     for (const char* n : names) {
         if (!n || !*n) continue;
         api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);

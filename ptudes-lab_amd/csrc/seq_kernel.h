@@ -200,11 +200,20 @@ __device__ __noinline__ unsigned sq_map_update(const SeqCtx* a, int s, int k, in
     SQ_CLK(13);
     SQ_CLK(14);  // (phase c is part of the prune pass here: d_map_insert_b / d_map_prune, FUSE)
     SQ_CLK(15);
-    const int nbpu = (st->pool_hw + BU - 1) / BU;
+    const int nvb = blk_virtual_count(c, st);  // small blocks below their high-water mark, then the full ones below theirs
+    const int nbpu = (nvb + BU - 1) / BU;
     sl.nb = nbpu;
     for (sl.b = sq_grab(ctr + 3); sl.b < nbpu; sl.b = sq_grab(ctr + 3)) d_map_prune<UM, true>(c, nullptr, 1, sl);
     SQ_CLK(16);
-    const int nbp = (st->pool_hw + BS - 1) / BS;
+    if (c.n_small > 0) {  // (uniform) two block classes: the voxels the batch took past a small block's capacity move to full blocks
+        if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;
+        const int nm = st->mig_n < c.n_small ? st->mig_n : c.n_small, nbm = (nm + BS - 1) / BS;
+        sl.nb = nbm;
+        for (sl.b = sq_grab(ctr + 2); sl.b < nbm; sl.b = sq_grab(ctr + 2)) d_map_migrate(c, sl);
+        if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;  // (the rebuild below and the next scan's list see the moved voxels; mig_n is reset behind it)
+        if (wg == 0 && threadIdx.x == 0) st->mig_n = 0;
+    }
+    const int nbp = (blk_virtual_count(c, st) + BS - 1) / BS;
     sl.nb = nbp;
     if (rebuild) {  // drop the tombstones: empty table, re-enter the live voxels
         if (!team_sync(te, (unsigned)nw, target)) return SEQ_FAIL;

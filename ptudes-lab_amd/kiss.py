@@ -59,6 +59,9 @@ class KissICPWrapper:
         self._max_range, self._min_range = _max_range, _min_range
         # lazy_map_stats: register_frame returns with the pose (what the reference's returns), the map update of the scan still under
         # way on the device; the per-scan `stats` rows then carry no map size (core.Icp)
+        # (the per-call handle keeps a 2^22-slot map table - 64 MB, cleared at every construction - instead of the batch default's 2^24: one
+        # sequence over the whole chip holds its probe results in registers and gains little from a sparser table)
+        icp_over.setdefault("map_table_capacity", 1 << 22)
         self._icp = core.Icp(_max_range, _min_range, device_id=device_id, scan_cols=w,
                              max_points_per_scan=max(h * w, 1024), lazy_map_stats=lazy_map_stats, **icp_over)
         c = self._icp.cfg

@@ -65,12 +65,12 @@ def test_executed_byte_model_follows_the_loaded_build():
     from ptudes_lab_amd import core
     b = _bench()
     info = core.build_info()
-    assert info["kcand"] >= 2 and info["ans_row_doubles"] >= 3 + 3 * info["kcand"] + 2 and info["tab_entry_bytes"] == 16
+    assert info["kcand"] >= 2 and info["ans_row_doubles"] >= 3 + 3 * info["kcand"] + 3 and info["tab_entry_bytes"] == 16  # (s0, K candidates, bound, ids, voxel key)
     cost, notes = b.exec_cost_for_build(info)
-    assert cost["point_iteration_later"] == 8 + 8 * info["ans_row_doubles"] and cost["lds_points_per_workgroup"] == info["lds_points"]
+    assert cost["point_iteration_later"] == 8 * info["ans_row_doubles"] and cost["lds_points_per_workgroup"] == info["lds_points"]  # (the key travels in the row)
     other = dict(info, ans_row_doubles=14, kcand=3, lds_points=1536, diagnostics=1)
     cost2, notes2 = b.exec_cost_for_build(other)
-    assert cost2["point_iteration_later"] == 8 + 112 and cost2["search"] == 128 + 8 + 112 + 4 and len(notes2) == 3
+    assert cost2["point_iteration_later"] == 112 and cost2["search"] == 128 + 8 + 112 + 4 and len(notes2) == 3
 
 
 def test_committed_pmc_summaries_name_their_workload():
@@ -98,11 +98,11 @@ def test_executed_byte_model():
     cnt = dict(searches=5000, rows_rebuilt=10, map_points_read=5000, gn_iterations=7, vds1_claims=300, vds2_claims=40, point_iterations=7000, scans=1)
     st = [dict(iterations=7, n_src=1000, n_valid=100000, n_down=30000, map_voxels=20000)]
     tot, gn, stages = b.executed_bytes(cnt, st, 131072, 8, 1024)
-    assert gn == 24 * 1000 + 152 * 6000 + c["search"] * 5000 - 136 * 1000 + c["row_rebuilt"] * 10 + 24 * 5000 + 7 * 8 * 9 * 36 * 8  # (the 1000 searches of the first iteration read no row)
+    assert gn == 24 * 1000 + c["point_iteration_later"] * 6000 + c["search"] * 5000 - 136 * 1000 + c["row_rebuilt"] * 10 + 24 * 5000 + 7 * 8 * 9 * 36 * 8  # (the 1000 searches of the first iteration read no row)
     # a scan with more source points than the team's LDS holds (1 workgroup: 3072): the rest goes through src_cur every iteration
     big = [dict(st[0], n_src=4072)]
     _, gn_big, _ = b.executed_bytes(dict(cnt, point_iterations=7 * 4072), big, 131072, 1, 1024)
-    assert gn_big == 24 * 4072 + 48 * 1000 * 7 + 152 * 6 * 4072 + c["search"] * 5000 - 136 * 4072 + c["row_rebuilt"] * 10 + 24 * 5000 + 7 * 1 * 2 * 36 * 8
+    assert c["point_iteration_later"] == 144 and gn_big == 24 * 4072 + 48 * 1000 * 7 + 144 * 6 * 4072 + c["search"] * 5000 - 136 * 4072 + c["row_rebuilt"] * 10 + 24 * 5000 + 7 * 1 * 2 * 36 * 8
     assert stages == c["raw_point"] * 131072 + c["valid_point"] * 100000 + c["down_point"] * 30000 + c["source_point"] * 1000 \
         + c["map_voxel"] * 20000 + 96 * 1024 + 24 * 340
     assert c["map_voxel"] == 36 and c["down_point"] == 240  # (round 4: insert c is part of the prune pass, the stored count comes with the table entry)

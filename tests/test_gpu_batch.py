@@ -488,3 +488,71 @@ def test_free_running_map_update_does_not_depend_on_its_points_per_thread():
         for k in range(n):
             for key in ("n_down", "n_src", "iterations", "map_voxels", "map_points"):
                 assert ref.stats[k][key] == runs["u4"][1][s]["stats"][k][key], (s, k, key)
+
+
+@pytest.mark.parametrize("case", ["sparse_map", "small_pool_runs_out"])
+def test_two_block_classes_give_the_one_class_map(case):
+    """map_small_blocks: voxels start in 128-byte blocks of 5 points and move to full blocks when a batch takes them past that (prune
+    pass notes them, d_map_migrate moves them behind a barrier).  Same sweeps through a batch with ONE block class: every pose, every
+    per-scan counter and the local map of every sequence after every launch bit-equal; counters against the CPU oracle.
+    sparse_map: 64 x 2048 sweeps into 0.1 m voxels (BASELINE config 5's kind of map: most voxels never leave their small block);
+    small_pool_runs_out: the default 0.7 m voxels (nearly every voxel outgrows five points) with so few small blocks that new
+    voxels fall back to full blocks from the first scan on."""
+    from oracle import cpu as orc
+    if case == "sparse_map":
+        S, n, H, W, mr, over = 3, 6, 64, 2048, 100.0, dict(voxel_size=0.1, scan_cols=2048, map_table_capacity=1 << 22)
+        small, full = 600_000, 150_000
+    else:
+        S, n, H, W, mr, over = 5, 9, 128, 1024, 70.0, dict(rebuild_every=4, map_table_capacity=1 << 20)
+        small, full = 3_000, 60_000
+    seqs = [synth.make_sequence(seed=1400 + s, n_scans=n, H=H, W=W, max_range=mr) for s in range(S)]
+    n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
+    runs = {}
+    for name, kw in (("one", dict(map_block_capacity=small + full)), ("two", dict(map_block_capacity=full, map_small_blocks=small))):
+        b = core.BatchRunner(S, n, H * W, n_imu, max_range=mr, min_range=1.0, use_imu_prediction=True, with_ekf=True, **over, **kw)
+        _load(b, seqs, n, n_imu)
+        maps = []
+        b.run(2)
+        maps.append([_map_rows(b, s) for s in range(S)])
+        b.enqueue(n - 2)
+        b.wait()
+        maps.append([_map_rows(b, s) for s in range(S)])
+        runs[name] = (maps, [b.results(s) for s in range(S)])
+        b.close()
+    for s in range(S):
+        assert np.array_equal(runs["two"][1][s]["kiss_poses"], runs["one"][1][s]["kiss_poses"]), s
+        assert np.array_equal(runs["two"][1][s]["res_poses"], runs["one"][1][s]["res_poses"]), s
+        assert runs["two"][1][s]["stats"] == runs["one"][1][s]["stats"], s
+        for launch in range(2):
+            assert runs["two"][0][launch][s][0] == runs["one"][0][launch][s][0], (launch, s)
+            assert np.array_equal(runs["two"][0][launch][s][1], runs["one"][0][launch][s][1]), (launch, s)
+    assert runs["two"][1][0]["stats"][-1]["map_points"] > runs["two"][1][0]["stats"][-1]["map_voxels"] > 0  # (voxels hold more than one point each)
+    orc.set_threads(4)
+    kiss, res, stats = _oracle_run_cfg(seqs[1], n, mr, over.get("voxel_size"))
+    out = runs["two"][1][1]
+    assert np.abs(out["kiss_poses"] - kiss).max() < 1e-9
+    for k in range(n):
+        assert all(out["stats"][k][q] == stats[k][q] for q in _INT_STATS), (k, out["stats"][k], stats[k])
+    orc.set_threads(1)
+    # the one-class drivers refuse the option instead of mis-addressing blocks
+    with pytest.raises((ValueError, RuntimeError)):
+        core.SeqRunner(n, H * W, n_imu, max_range=mr, min_range=1.0, map_small_blocks=1000)
+    with pytest.raises((ValueError, RuntimeError)):
+        core.BatchRunner(2, n, H * W, n_imu, max_range=mr, min_range=1.0, free_running=False, map_small_blocks=1000)
+
+
+def _oracle_run_cfg(sq, n, max_range, voxel_size):
+    from oracle import cpu as orc
+    over = {"voxel_size": voxel_size} if voxel_size else {}
+    icp, ekf = orc.ICP(max_range=max_range, min_range=1.0, **over), orc.EKF()
+    t01 = sq.column_times()
+    kiss, res = [], []
+    for k in range(n):
+        a, e = sq.imu_range_for_scan(k)
+        for i in range(a, e):
+            ekf.process_imu(sq.imu[i, 1:4], sq.imu[i, 4:7], sq.imu[i, 0])
+        pose = icp.register_frame(sq.scan(k).astype(np.float64), t01, ekf.pose_mat())
+        ekf.process_pose(pose)
+        kiss.append(pose)
+        res.append(ekf.pose_mat())
+    return np.array(kiss), np.array(res), icp.stats

@@ -111,6 +111,42 @@ def test_lazy_map_stats_gives_the_same_poses_without_waiting_for_the_map_update(
     assert a._icp.map_size() == b._icp.map_size() == (b.stats[-1]["map_voxels"], b.stats[-1]["map_points"])
 
 
+def test_calls_right_after_a_lazy_registration_are_ordered_behind_its_map_update(seq):
+    """lazy_map_stats lets register_frame return while the scan's map update (K7-K10) still runs on the map stream: whatever touches the
+    map, the device state or the staging buffers next - map_add, align, linear_system, deskew, the prediction - has to wait for it
+    (they used to start beside it).  A lazy handle and a default one go through the same calls: identical results."""
+    from ptudes_lab_amd import core
+    rng = np.random.default_rng(11)
+    gt = seq.gt_poses(0.5)
+    g0i = np.linalg.inv(gt[0])
+    a, b = core.Icp(70.0, 1.0, lazy_map_stats=True), core.Icp(70.0, 1.0)
+    extra = rng.uniform(-20, 20, (3000, 3))
+    for k in range(5):
+        x = seq.scan(k)
+        guess = g0i @ gt[k]
+        Ta, Tb = a.register_frame(x, None, guess), b.register_frame(x, None, guess)
+        assert np.array_equal(Ta, Tb), k
+        if k == 1:  # straight into the map while the lazy handle's update of scan 1 is still in flight
+            a.map_add(extra + 0.01 * k, origin=Ta[:3, 3])
+            b.map_add(extra + 0.01 * k, origin=Tb[:3, 3])
+            assert a.map_size() == b.map_size()
+        if k == 2:  # a registration against the map as that scan left it: needs the complete update
+            src = x[np.linalg.norm(x, axis=1) > 1.0][::37].astype(np.float64)
+            Pa, ia = a.align(src, Ta, 6.0, 2.0 / 3.0)
+            Pb, ib = b.align(src, Tb, 6.0, 2.0 / 3.0)
+            assert np.array_equal(Pa, Pb) and ia == ib
+        if k == 3:
+            w = (Ta @ np.c_[x[::53].astype(np.float64), np.ones(len(x[::53]))].T).T[:, :3].copy()
+            sa, sb = a.linear_system(w, 6.0, 2.0 / 3.0), b.linear_system(w, 6.0, 2.0 / 3.0)
+            assert sa[1:] == sb[1:] and np.array_equal(sa[0], sb[0])
+            assert np.array_equal(a.prediction(), b.prediction())
+            t01 = seq.column_times()[::53]
+            assert np.array_equal(a.deskew(x[::53].astype(np.float64), t01), b.deskew(x[::53].astype(np.float64), t01))
+    assert a.map_size() == b.map_size()
+    pa, pb = a.map_points(), b.map_points()
+    assert np.array_equal(pa[np.lexsort(pa.T[::-1])], pb[np.lexsort(pb.T[::-1])])
+
+
 def test_ouster_command_on_synthetic_writes_pose_files(tmp_path):
     fk, fn = tmp_path / "k.txt", tmp_path / "n.csv"
     res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "ouster", "--synthetic", "1002", "--end-scan", "5",
