@@ -267,6 +267,16 @@ int ptl_seq_copy_traj(ptl_seq *s, void *dst_device, int64_t max_rows, int64_t *r
 int ptl_seq_icp(ptl_seq *s, ptl_icp **icp);
 int ptl_seq_profile(ptl_seq *s, int enable, double *gn_ms_total, int64_t *gn_launches, int reset);
 
+/* One scan of the reference's loop body (cli/ekf_bench.py:493-563) for the per-call handles in ONE host round trip: the n_imu IMU samples
+ * that precede the scan (rows [ts, lacc(3), avel(3)]: ESEKF.processImu each, es_ekf.py:191-237), the registration (kiss.py:83-131) with
+ * the filter's pose as its guess (use_imu_prediction, ekf_bench.py:533-535), else `guess` (nullable: the constant-velocity model),
+ * ESEKF.processPose with the new pose (es_ekf.py:259-329).  kiss_pose = the registration's pose, ekf_pose / ekf_ts = the filter's pose
+ * after the update and its timestamp (what the loop appends, ekf_bench.py:561-563); any output may be NULL.  Same kernels and order as
+ * the separate calls - same bits - with the hand-overs done on the device (the host waits once instead of three times). */
+int ptl_icp_ekf_step(ptl_icp *icp, ptl_ekf *ekf, const double *imu_rows, int64_t n_imu, const void *xyz, int dtype, int64_t n,
+                     const double *t01, const double *guess, int32_t use_imu_prediction, double kiss_pose[16],
+                     double ekf_pose[16], double *ekf_ts, ptl_icp_stats *stats);
+
 /* ------------------------------------------------------------------------------------------------
  * Batched runner: up to 256 independent sequences on ONE GPU.  The sequences s = x (mod 8) live on XCD x (their maps,
  * probe rows and exchange stay in its L2); the workgroups with blockIdx & 7 == x form 1 / 2 / 4 teams of gn_workgroups /

@@ -97,6 +97,8 @@ PROTOTYPES = {
     "ptl_ekf_get_state": (C.c_int, [_vp, c_d_p, c_d_p]),
     "ptl_ekf_pose_mat": (C.c_int, [_vp, c_d_p]),
     "ptl_ekf_ts": (C.c_int, [_vp, c_d_p]),
+    "ptl_icp_ekf_step": (C.c_int, [_vp, _vp, c_d_p, C.c_int64, _vp, C.c_int, C.c_int64, c_d_p, c_d_p, C.c_int32, c_d_p, c_d_p,
+                                  c_d_p, C.POINTER(IcpStats)]),
     "ptl_seq_create": (C.c_int, [C.POINTER(SeqCfg), _vpp]),
     "ptl_seq_destroy": (C.c_int, [_vp]),
     "ptl_seq_upload_scan": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_float)]),

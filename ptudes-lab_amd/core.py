@@ -267,6 +267,31 @@ class Ekf:
         return t.value
 
 
+def icp_ekf_step(icp: "Icp", ekf: "Ekf", imu_rows, xyz, t01=None, guess=None, use_imu_prediction=False):
+    """One scan of the reference's loop body (cli/ekf_bench.py:493-563) in one host round trip (include/ptudes_mi.h ptl_icp_ekf_step):
+    the IMU rows [ts, lacc, avel] that precede the scan, the registration (guess: the filter's pose when use_imu_prediction, else
+    `guess` / constant velocity), the filter's update with the new pose.  Returns (kiss_pose, ekf_pose, ekf_ts); the stats row is
+    appended to icp.stats like register_frame does."""
+    rows = L.as_f64(imu_rows).reshape(-1, 7) if len(imu_rows) else np.zeros((0, 7))
+    xyz = np.asarray(xyz)
+    if xyz.dtype == np.float32:
+        x, dt = np.ascontiguousarray(xyz), L.PTL_F32
+    else:
+        x, dt = L.as_f64(xyz), L.PTL_F64
+    if x.ndim != 2 or x.shape[1] != 3:
+        raise ValueError("xyz must be (N, 3)")
+    t = None if t01 is None else L.as_f64(t01)
+    if t is not None and len(t) != len(x):
+        raise ValueError("t01 must have one entry per point")
+    g = None if guess is None else L.as_f64(guess).reshape(16)
+    kiss, pose, ts, st = np.empty((4, 4)), np.empty((4, 4)), C.c_double(), L.IcpStats()
+    L.check(L.lib().ptl_icp_ekf_step(icp._h, ekf._h, L.dptr(rows) if len(rows) else None, len(rows), x.ctypes.data_as(C.c_void_p), dt, len(x),
+                                     None if t is None else L.dptr(t), None if g is None else L.dptr(g), int(bool(use_imu_prediction)),
+                                     L.dptr(kiss), L.dptr(pose), C.byref(ts), C.byref(st)))
+    icp.stats.append(st.as_dict())
+    return kiss, pose, ts.value
+
+
 def device_sync(device_id=0):
     L.check(L.lib().ptl_device_sync(device_id))
 

@@ -60,6 +60,7 @@ struct ptl_icp {
     size_t ev_used;
     // set by the sequence runner around a scan: the GN kernel waits for `gn_wait` (the EKF stream produced the guess)
     hipEvent_t gn_wait, gn_done;  // ... and `gn_done` is recorded right after it (a second event: two streams waiting on one measured slower)
+    hipEvent_t ev_step_guess, ev_step_gn;  // ptl_icp_ekf_step's own pair (created on first use)
     // ev_gn is recorded right after each GN launch: the map update (and the sequence runner's EKF step) start from it.
     // frame_down is double-buffered so that K3 of scan k+1 does not overwrite what K7 of scan k still reads.
     // the map update (K7-K10, rebuild) runs on `map_stream`: it needs the GN result (ev_gn) and must be complete before
@@ -117,7 +118,7 @@ static int icp_free(ptl_icp* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {h->ev_gn, h->ev_map})
+    for (hipEvent_t e : {h->ev_gn, h->ev_map, h->ev_step_guess, h->ev_step_gn})
         if (e) (void)hipEventDestroy(e);
     if (h->n_src_hint) (void)hipHostFree(h->n_src_hint);
     if (h->map_stream) (void)hipStreamDestroy(h->map_stream);
@@ -221,7 +222,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     h->own_stream = shared_stream == nullptr;
     h->stream = shared_stream;
     h->prof = false; h->prof_every = 1; h->ev_used = 0; h->gn_ms = 0; h->gn_launches = 0;
-    h->gn_wait = nullptr; h->gn_done = nullptr;
+    h->gn_wait = nullptr; h->gn_done = nullptr; h->ev_step_guess = nullptr; h->ev_step_gn = nullptr;
     h->lazy_map_stats = false;
     h->n_src_hint = nullptr;
     h->map_stream = nullptr; h->ev_map = nullptr; h->ev_map_valid = false;
@@ -1107,6 +1108,63 @@ extern "C" int ptl_ekf_ts(ptl_ekf* h, double* ts) {
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipMemcpyAsync(ts, (char*)h->st + (offsetof(EkfState, nav) + offsetof(EkfNav, cur_ts)), 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return PTL_OK;
+}
+
+// ================================================================================================ one scan of the driver loop, per-call handles
+// The reference's loop body (cli/ekf_bench.py:493-563) for host-fed data in ONE host round trip: the IMU samples that precede the scan
+// (processImu each), the registration with the filter's pose as its guess (--use-imu-prediction) or the caller's / the constant-velocity
+// one, processPose with the new pose.  Object by object (ESEKF.processImu x n, ekf.nav.pose_mat(), register_frame, processPose, nav again)
+// that is n + 2 launches and THREE synchronising read-backs per scan; here the filter's launches go to its own stream, the Gauss-Newton
+// kernel waits for the predicts on the device and reads the guess there, the update waits for the Gauss-Newton kernel on the device and
+// reads the pose there, and the host waits once.  Same kernels, same order of operations per handle: same bits.
+extern "C" int ptl_icp_ekf_step(ptl_icp* h, ptl_ekf* e, const double* imu_rows, int64_t n_imu, const void* xyz, int dtype, int64_t n,
+                                const double* t01, const double* guess, int32_t use_imu_prediction, double kiss_pose[16],
+                                double ekf_pose[16], double* ekf_ts, ptl_icp_stats* stats) {
+    if (!h || !e || (!imu_rows && n_imu > 0) || (!xyz && n > 0) || n < 0 || n_imu < 0) return set_err(PTL_ERR_ARG, "bad argument");
+    if (dtype != PTL_F32 && dtype != PTL_F64) return set_err(PTL_ERR_ARG, "dtype must be PTL_F32 or PTL_F64");
+    if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "scan has %lld points, capacity %lld", (long long)n, (long long)h->n_max);
+    if (h->cfg.device_id != e->cfg.device_id) return set_err(PTL_ERR_ARG, "registration on device %d, filter on device %d", h->cfg.device_id, e->cfg.device_id);
+    if (n_imu > e->buf_rows) return set_err(PTL_ERR_ARG, "at most %lld IMU samples per step", (long long)e->buf_rows);
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    if (!h->ev_step_guess) {
+        HIPCHK(hipEventCreateWithFlags(&h->ev_step_guess, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_step_gn, hipEventDisableTiming));
+    }
+    hipStream_t es = e->stream;
+    if (n_imu > 0) {  // processImu x n_imu (one launch: ptl_ekf_process_imu_batch's kernel)
+        HIPCHK(hipMemcpyAsync(e->d_buf, imu_rows, (size_t)n_imu * 56, hipMemcpyHostToDevice, es));
+        k_ekf_step<<<1, EKF_THREADS, 0, es>>>(e->st, e->d_buf, 0, (int)n_imu, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+    }
+    const size_t esz = dtype == PTL_F32 ? 4 : 8;
+    if (n) HIPCHK(hipMemcpyAsync(h->d_in, xyz, (size_t)n * 3 * esz, hipMemcpyHostToDevice, h->stream));
+    if (t01 && n) HIPCHK(hipMemcpyAsync(h->d_t01, t01, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    const double* guess_ptr = nullptr;
+    if (use_imu_prediction) {  // ekf.nav.pose_mat() as the guess, read on the device once the predicts are through
+        HIPCHK(hipEventRecord(h->ev_step_guess, es));
+        h->gn_wait = h->ev_step_guess;
+        guess_ptr = (const double*)((char*)e->st + offsetof(EkfState, pose));
+    } else if (guess) {
+        HIPCHK(hipMemcpyAsync(h->d_ext, guess, 16 * 8, hipMemcpyHostToDevice, h->stream));
+        guess_ptr = h->d_ext;
+    }
+    h->gn_done = h->ev_step_gn;
+    int rc = icp_enqueue_scan(h, dtype == PTL_F32 ? (const float*)h->d_in : nullptr, dtype == PTL_F64 ? (const double*)h->d_in : nullptr,
+                              t01 ? h->d_t01 : nullptr, n, guess_ptr);
+    h->gn_wait = nullptr; h->gn_done = nullptr;
+    if (rc) return rc;
+    // processPose(kiss pose): behind the Gauss-Newton kernel, on the filter's stream; its outputs (pose after the update, timestamp) land
+    // in the tail of the filter's staging buffer
+    double* d_out = e->d_buf + (size_t)e->buf_rows * 7;
+    HIPCHK(hipStreamWaitEvent(es, h->ev_step_gn, 0));
+    k_ekf_step<<<1, EKF_THREADS, 0, es>>>(e->st, e->d_buf, 0, 0, h->c.traj + 16 * (h->scans_done - 1), nullptr, d_out, d_out + 16, nullptr, 1);
+    double out[17];
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, es));
+    rc = icp_percall_finish(h, kiss_pose, stats);  // (synchronises the registration's stream: pose, statistics row, error flags)
+    HIPCHK(hipStreamSynchronize(es));
+    if (rc) return rc;
+    if (ekf_pose) memcpy(ekf_pose, out, 128);
+    if (ekf_ts) *ekf_ts = out[16];
     return PTL_OK;
 }
 

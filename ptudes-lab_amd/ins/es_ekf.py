@@ -90,6 +90,14 @@ class ESEKF:
         self._imu_initialized = True
         self._nav_cache = None
 
+    def _after_fused_step(self, n_imu: int, ts: float) -> None:
+        """bookkeeping after core.icp_ekf_step ran `n_imu` predicts and one update on this filter's device state (sequence.run_events)"""
+        if n_imu:
+            self._imu_idx += n_imu
+            self._imu_initialized = True
+        self._ts = float(ts)
+        self._nav_cache = None
+
     def processPose(self, pose_corr: np.ndarray, meas_cov: Optional[np.ndarray] = None) -> None:
         """update step with a 4x4 pose measurement and optional 6x6 covariance (es_ekf.py:259-329)"""
         if self._logging:

@@ -17,10 +17,17 @@ from .kiss import KissICPWrapper
 
 
 def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use_imu_prediction=False,
-               guess_fn=None, logging=False, device_id=0, stats=None, lazy_map_stats=True):
+               guess_fn=None, logging=False, device_id=0, stats=None, lazy_map_stats=True, fused=None):
     """Returns dict(res_t, res_poses, kiss_poses, kiss_icp, ekf, timings).  `guess_fn(ts)` (optional) supplies an
     external guess (the reference's --use-gt-guess, ekf_bench.py:536-542); `stats` (optional) is the StreamStatsTracker
-    the loop feeds (ekf_bench.py:497-499, :522-524), its time goes into timings["track"]."""
+    the loop feeds (ekf_bench.py:497-499, :522-524), its time goes into timings["track"].
+    fused (default: on unless the filter logs every sample): the IMU samples between two scans are held back and go to the device
+    together with the scan - ptl_icp_ekf_step: predicts, registration with the filter's pose read on the device, update, ONE wait
+    per scan instead of a read-back for the guess, one for the pose and one for the filter's state.  Same kernels in the same order:
+    the trajectory is the device-resident runner's bit for bit (the guess never leaves the device in either) and the call-by-call
+    loop's to 1e-9 m (there the guess makes a round trip through host arithmetic) - tests/test_gpu_dropin.py."""
+    if fused is None:
+        fused = not logging
     # (the loop reads poses only - ekf_bench.py:549-563: the registration need not wait for its map update, lazy_map_stats)
     kiss_icp = KissICPWrapper(metadata, _use_extrinsics=True, _min_range=kiss_min_range, _max_range=kiss_max_range,
                               device_id=device_id, lazy_map_stats=lazy_map_stats)
@@ -29,6 +36,7 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
     t_imu = t_corr = t_kiss = t_track = 0.0
     n_imu = n_corr = 0
     imus_per_scan = 1  # ekf_bench.py:491
+    held = []  # fused: the IMU samples since the last scan
     for ev in events:
         if ev[0] == "imu":
             if stats is not None:
@@ -36,7 +44,10 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
                 stats.trackImu(ev[1])
                 t_track += time.monotonic() - t1
             t1 = time.monotonic()
-            ekf.processImu(ev[1])
+            if fused:
+                held.append(ev[1])
+            else:
+                ekf.processImu(ev[1])
             t_imu += time.monotonic() - t1
             n_imu += 1
             imus_per_scan += 1
@@ -57,6 +68,30 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
             xyz, t01, ts = None, None, float(getattr(ev[1], "timestamp", [0])[-1]) * 1e-9 if hasattr(ev[1], "timestamp") else 0.0
         else:
             _, xyz, t01, ts = ev
+        if fused and ev[0] != "lidar_scan":
+            # the whole loop body in one call (the guess of --use-imu-prediction is read on the device)
+            if use_imu_prediction:
+                guess = None
+            elif guess_fn is not None:
+                guess = guess_fn(ts)
+            else:
+                guess = None  # constant velocity, formed on the device (kiss.py:102-105)
+            t1 = time.monotonic()
+            rows = np.array([[i.ts, *i.lacc, *i.avel] for i in held], dtype=np.float64).reshape(-1, 7)
+            kiss_pose, ekf_pose, ekf_ts = core.icp_ekf_step(kiss_icp._icp, ekf._ekf, rows, xyz, t01, guess, use_imu_prediction)
+            kiss_icp._log_pose(kiss_pose, ts)
+            ekf._after_fused_step(len(held), ekf_ts)
+            held = []
+            t_kiss += time.monotonic() - t1
+            n_corr += 1
+            kiss_poses.append(kiss_pose)
+            res_poses.append(ekf_pose)
+            res_t.append(ekf.ts)
+            continue
+        if held:  # (a scan type the fused entry does not take: flush the samples the call-by-call way)
+            for i in held:
+                ekf.processImu(i)
+            held = []
         if use_imu_prediction:
             guess = ekf.nav.pose_mat()
         elif guess_fn is not None:
@@ -77,6 +112,9 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
         kiss_poses.append(kiss_icp.pose)
         res_poses.append(ekf.nav.pose_mat())
         res_t.append(ekf.ts)
+    if held:  # samples behind the last scan
+        for i in held:
+            ekf.processImu(i)
     timings = dict(imu=t_imu / max(n_imu, 1), corr=t_corr / max(n_corr, 1), kiss=t_kiss / max(n_corr, 1),
                    track=t_track / max(n_corr, 1), n_imu=n_imu, n_corr=n_corr)
     return dict(res_t=res_t, res_poses=res_poses, kiss_poses=kiss_poses, kiss_icp=kiss_icp, ekf=ekf, timings=timings)

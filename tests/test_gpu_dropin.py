@@ -147,6 +147,31 @@ def test_calls_right_after_a_lazy_registration_are_ordered_behind_its_map_update
     assert np.array_equal(pa[np.lexsort(pa.T[::-1])], pb[np.lexsort(pb.T[::-1])])
 
 
+def test_fused_loop_body_equals_the_resident_run_and_the_call_by_call_loop(seq):
+    """sequence.run_events(fused=True): IMU samples held back and sent with the scan (ptl_icp_ekf_step: predicts, registration with the
+    filter's pose read on the device, update - one host wait per scan).  Against the device-resident runner (same kernels, the guess
+    never leaves the device): every pose and timestamp bit for bit; against the call-by-call loop (reference ekf_bench.py:493-563
+    object by object): 1e-9 m; the wrappers' logs (poses, sigmas, innovation) are filled the same way; constant-velocity mode too."""
+    n = 10
+    meta = SimpleNamespace(format=SimpleNamespace(columns_per_frame=seq.W, pixels_per_column=seq.H))
+    for use_imu in (True, False):
+        ev = list(sequence.synthetic_events(seq, n))
+        a = sequence.run_events(iter(ev), meta, use_imu_prediction=use_imu, fused=True)
+        b = sequence.run_events(iter(ev), meta, use_imu_prediction=use_imu, fused=False)
+        r = sequence.run_resident(seq, n, use_imu_prediction=use_imu, map_table_capacity=1 << 22)
+        assert len(a["res_poses"]) == n and a["timings"]["n_corr"] == n and a["timings"]["n_imu"] == b["timings"]["n_imu"]
+        assert np.array_equal(np.array(a["res_t"]), r["res_t"]) and np.array_equal(np.array(a["res_t"]), np.array(b["res_t"]))
+        assert np.array_equal(np.array(a["kiss_poses"]), r["kiss_poses"]), use_imu
+        assert np.array_equal(np.array(a["res_poses"]), r["res_poses"]), use_imu
+        assert np.abs(np.array(a["kiss_poses"]) - np.array(b["kiss_poses"])).max() < 1e-9
+        assert np.abs(np.array(a["res_poses"]) - np.array(b["res_poses"])).max() < 1e-9
+        ka, kb = a["kiss_icp"], b["kiss_icp"]
+        assert len(ka.poses) == len(kb.poses) == n and ka.poses_ts == kb.poses_ts
+        assert np.abs(np.array(ka._sigmas) - np.array(kb._sigmas)).max() < 1e-9 and np.abs(np.array(ka._err_dt) - np.array(kb._err_dt)).max() < 1e-9
+        assert a["ekf"].ts == b["ekf"].ts and a["ekf"]._imu_idx == b["ekf"]._imu_idx
+        assert np.abs(a["ekf"].nav.pos - b["ekf"].nav.pos).max() < 1e-9  # (the filter object is usable afterwards: state read on demand)
+
+
 def test_ouster_command_on_synthetic_writes_pose_files(tmp_path):
     fk, fn = tmp_path / "k.txt", tmp_path / "n.csv"
     res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "ouster", "--synthetic", "1002", "--end-scan", "5",
