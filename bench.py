@@ -580,36 +580,55 @@ def main():
         from ptudes_lab_amd import parallel
         box = {}
 
-        def _gather():
+        def _host_rows():
+            import torch
+            rows = torch.zeros((S, n_total, 8), dtype=torch.float64)
+            counts = []
+            for j in range(S):
+                o = outs[j]
+                counts.append(len(o["res_t"]))
+                rows[j, : counts[-1]] = torch.from_numpy(parallel.poses_to_rows(o["res_t"], o["res_poses"]))
+            return parallel.gather_trajectories(rows, counts, dist)
+
+        def _gather_rccl():
             try:
-                if shared_device:
-                    import torch
-                    rows = torch.zeros((S, n_total, 8), dtype=torch.float64)
-                    counts = []
-                    for j in range(S):
-                        o = outs[j]
-                        counts.append(len(o["res_t"]))
-                        rows[j, : counts[-1]] = torch.from_numpy(parallel.poses_to_rows(o["res_t"], o["res_poses"]))
-                    box["out"] = parallel.gather_trajectories(rows, counts, dist)
+                comm = parallel.Comm.over(dist, ctl, device_id=local_rank)  # rank 0 makes the id, gloo carries it, everybody joins
+                if S == 1:
+                    ptr, n_rows = runner.r.traj_device()
+                    box["out"] = comm.gather_rows(ptr, 1, n_total, [min(n_rows, n_total)])
                 else:
-                    comm = parallel.Comm.over(dist, ctl, device_id=local_rank)  # rank 0 makes the id, gloo carries it, everybody joins
-                    if S == 1:
-                        ptr, n_rows = runner.r.traj_device()
-                        box["out"] = comm.gather_rows(ptr, 1, n_total, [min(n_rows, n_total)])
-                    else:
-                        box["out"] = comm.gather_batch(runner)
-                    comm.close()
+                    box["out"] = comm.gather_batch(runner)
+                comm.close()
             except Exception as e:  # noqa: BLE001
                 box["err"] = repr(e)
 
-        th = threading.Thread(target=_gather, daemon=True)
-        th.start()
-        th.join(timeout=GATHER_TIMEOUT_S)
-        gathered = box.get("out")
-        gather_err = "no answer after %d s" % GATHER_TIMEOUT_S if th.is_alive() else box.get("err")
-        if gather_err is not None:
-            print(f"bench.py rank {rank}: trajectory gather failed: {gather_err}", file=sys.stderr, flush=True)
-        if parallel.max_over_ranks(0.0 if gather_err is None else 1.0, dist, device="cpu", group=ctl) > 0 and gather_err is None:
+        def _gather_gloo():
+            try:
+                box["out"] = _host_rows()
+            except Exception as e:  # noqa: BLE001
+                box["err"] = repr(e)
+
+        def _attempt(fn):
+            box.clear()
+            th = threading.Thread(target=fn, daemon=True)
+            th.start()
+            th.join(timeout=GATHER_TIMEOUT_S)
+            err = "no answer after %d s" % GATHER_TIMEOUT_S if th.is_alive() else box.get("err")
+            if err is not None:
+                print(f"bench.py rank {rank}: trajectory gather ({fn.__name__[8:]}) failed: {err}", file=sys.stderr, flush=True)
+            any_failed = parallel.max_over_ranks(0.0 if err is None else 1.0, dist, device="cpu", group=ctl) > 0
+            return box.get("out"), err, any_failed, th.is_alive()
+
+        gather_backend = "gloo, host rows (ranks share a GPU; RCCL refuses duplicate devices)" if shared_device else \
+            "RCCL ncclAllGather through libptudes_mi.so (ptl_batch_gather_trajectories), id over gloo"
+        gathered, gather_err, any_failed, stalled = _attempt(_gather_gloo if shared_device else _gather_rccl)
+        if any_failed and not shared_device and parallel.max_over_ranks(1.0 if stalled else 0.0, dist, device="cpu", group=ctl) == 0:
+            # the library's RCCL path raised somewhere (a first contact with a node's RCCL / xGMI set-up): the measurement above does not
+            # depend on it, so every rank falls back to host rows over the control plane - and the line says which way the rows came
+            rccl_err = gather_err or "failed on another rank"
+            gathered, gather_err, any_failed, stalled = _attempt(_gather_gloo)
+            gather_backend = f"gloo, host rows - FALLBACK after the RCCL gather failed: {rccl_err}"
+        if any_failed and gather_err is None:
             gather_err = "failed on another rank"  # every rank takes the same exit below
 
     if rank == 0:
@@ -790,8 +809,7 @@ def main():
             one.close()
         if gathered is not None:
             line["gathered_trajectories"] = {"sequences": len(gathered), "rows_each": sorted({len(v) for v in gathered.values()}),
-                                             "backend": "gloo, host rows (ranks share a GPU; RCCL refuses duplicate devices)" if shared_device
-                                                        else "RCCL ncclAllGather through libptudes_mi.so (ptl_batch_gather_trajectories), id over gloo"}
+                                             "backend": gather_backend}
             if args.dump_traj:
                 np.savez(args.dump_traj, **{f"rank{r}_seq{j}": v for (r, j), v in gathered.items()},
                          seeds=np.array([[r, j, args.seed_base + (j if args.equal_work else r + world * j)] for (r, j) in gathered]))

@@ -366,7 +366,7 @@ int ptl_batch_debug_set_map_points_per_thread(ptl_batch *b, int32_t points, int3
  * and pass of K1 + map update / K2-K4 in the free-running kernel, [5] threads per workgroup of the 8-lane kernels,
  * [6] lanes per point of the full search, [7] nearest other boxes in its first round, [8] voxels per survivor round,
  * [9] chunks phase A requests ahead, [10] 1000 x the pruning margin, [11] / [12] bytes per map-table / voxel-table
- * entry, [13] 1 when diagnostic clocks are compiled in. */
+ * entry, [13] 1 when diagnostic clocks are compiled in, [14] 1 for a build of the movement-budget experiment (make EXTRA=-DGN8_FAST=1; off in the product). */
 int ptl_build_info(int32_t out[16]);
 
 /* ---- multi-GPU: the final trajectory gather.  The reference has no distributed layer; the path shards

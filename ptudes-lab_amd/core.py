@@ -525,7 +525,7 @@ class BatchRunner:
 
 
 BUILD_INFO = ("kcand", "ans_row_doubles", "lds_points", "seq_u", "seq_u2", "gn8_threads", "lanes_per_point", "spec", "surv",
-              "prefetch", "keep_x1000", "tab_entry_bytes", "vds_entry_bytes", "diagnostics")
+              "prefetch", "keep_x1000", "tab_entry_bytes", "vds_entry_bytes", "diagnostics", "fast")
 
 
 def build_info():

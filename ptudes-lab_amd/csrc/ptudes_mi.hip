@@ -113,7 +113,7 @@ static int icp_free(ptl_icp* h) {
     (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
     void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vtab1, c.vtab2, c.bcnt1, c.bcnt2, h->fd_buf[0], h->fd_buf[1], c.src0,
-                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.bhdr, c.bfirst, c.free_stack, c.free_stack_s, c.mig_list, c.wg_clk, c.pc_key, c.pc_pb, c.pc_ans, c.gn_rows_ll, c.gn_xsum_ll,
+                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.bhdr, c.bfirst, c.free_stack, c.free_stack_s, c.mig_list, c.wg_clk, c.pc_key, c.pc_pb, c.pc_ans, c.pc_t1, c.gn_rows_ll, c.gn_xsum_ll,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter, h->d_row_mask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -283,6 +283,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= dalloc(&c.free_stack, c.pool_cap - c.n_small) == hipSuccess;
     ok &= dalloc(&c.free_stack_s, (size_t)(c.n_small > 0 ? c.n_small : 1)) == hipSuccess && dalloc(&c.mig_list, (size_t)(c.n_small > 0 ? c.n_small : 1)) == hipSuccess;
     ok &= dalloc(&c.pc_key, n) == hipSuccess && dalloc(&c.pc_pb, 32 * n) == hipSuccess && dalloc(&c.pc_ans, GN8_ANS_ROW * n) == hipSuccess;
+    if (GN8_FAST) ok &= dalloc(&c.pc_t1, 3 * n) == hipSuccess;  // (the movement-budget experiment's correspondences: off by default)
     ok &= hipHostMalloc((void**)&h->n_src_hint, sizeof(int)) == hipSuccess;
     if (h->n_src_hint) *h->n_src_hint = 0;
     ok &= dalloc(&c.gn_rows_ll, (size_t)2 * c.G * 64) == hipSuccess && hipMemset(c.gn_rows_ll, 0, (size_t)2 * c.G * 64 * 8) == hipSuccess;
@@ -311,7 +312,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
 static size_t icp_footprint_bytes(const ptl_icp_cfg* cfg) {
     const size_t n = (size_t)cfg->max_points_per_scan;
     const size_t bstride = ((size_t)cfg->max_points_per_voxel * 24 + 127) / 128 * 128;
-    const size_t per_point = 24 + 4 + 4 + 24 * 2 + 24 + 24 + 24 + 4 * 4 + 8 + 128 + GN8_ANS_ROW * 8 + 24 + 8;
+    const size_t per_point = 24 + 4 + 4 + 24 * 2 + 24 + 24 + 24 + 4 * 4 + 8 + 128 + GN8_ANS_ROW * 8 + 24 + (GN8_FAST ? 24 : 0) + 8;
     return n * per_point + (vds_table_slots(VDS1_SLOTS_PER_POINT, n) + vds_table_slots(VDS2_SLOTS_PER_POINT, n)) * sizeof(VdsEnt) + (size_t)cfg->map_table_capacity * sizeof(TabEnt) +
            (size_t)cfg->map_block_capacity * (bstride + 4 + 16 + 24) + (size_t)cfg->map_small_blocks * (SMALL_BYTES + 8 + 16 + 24) + (size_t)4096 * (128 + sizeof(ScanStats)) + (1u << 20);
 }
@@ -1963,7 +1964,7 @@ extern "C" int ptl_build_info(int32_t out[16]) {
     for (int i = 0; i < 16; ++i) out[i] = 0;
     out[0] = GN8_KCAND; out[1] = GN8_ANS_ROW; out[2] = GN8_LDS_PTS; out[3] = SEQ_U; out[4] = SEQ_U2; out[5] = GN8_MAX_THREADS;
     out[6] = GN8_LPB; out[7] = GN8_SPEC; out[8] = GN8_SURV; out[9] = GN8_PREFETCH; out[10] = (int32_t)(1000.0 * GN8_KEEP + 0.5);
-    out[11] = (int32_t)sizeof(TabEnt); out[12] = (int32_t)sizeof(VdsEnt);
+    out[11] = (int32_t)sizeof(TabEnt); out[12] = (int32_t)sizeof(VdsEnt); out[14] = GN8_FAST;
 #if defined(GN_PHASE_CLOCKS) || defined(SEQ_STAGE_CLOCKS) || defined(GN_IT0_CLOCK)
     out[13] = 1;
 #endif
@@ -2092,6 +2093,7 @@ RcclApi* rccl_api() {
     const char* names[] = {override_path, beside[0], beside[1], "librccl.so.1", "librccl.so"};
     for (const char* n : names) {
         if (!n || !*n) continue;
+        if (override_path && *override_path && n != override_path) break;  // PTL_RCCL_PATH is exclusive: that library or none
         api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (api.lib) break;
         snprintf(api.why, sizeof api.why, "%s", dlerror());

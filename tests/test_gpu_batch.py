@@ -556,3 +556,4 @@ def _oracle_run_cfg(sq, n, max_range, voxel_size):
         kiss.append(pose)
         res.append(ekf.pose_mat())
     return np.array(kiss), np.array(res), icp.stats
+

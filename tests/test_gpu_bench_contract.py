@@ -189,6 +189,26 @@ def test_bench_under_the_launcher_gathers_over_rccl():
 
 
 @pytest.mark.gpu
+def test_bench_falls_back_to_host_rows_when_the_rccl_gather_raises():
+    """first contact with a node whose RCCL does not come up must not void the measurement: the library's gather raises (here: PTL_RCCL_PATH
+    names a library that does not exist), every rank falls back to host rows over the gloo control plane, the line says so, exit code 0"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6",
+                          "--warmup", "3", "--seqs-per-gpu", "16", "--no-cpu-baseline", "--no-single-sequence", "--repeats", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, PTL_RCCL_PATH="/nonexistent/librccl.so.1"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")][0])
+    g = d["gathered_trajectories"]
+    assert g["sequences"] == 16 and g["rows_each"] == [9] and g["backend"].startswith("gloo, host rows - FALLBACK") and "librccl" in g["backend"]
+    assert "trajectory gather (rccl) failed" in res.stderr
+
+
+@pytest.mark.gpu
 def test_bench_verify_all_compares_every_sequence_with_its_single_run():
     """`--verify-all`: after the batched run every sequence is registered once more ALONE (single-sequence runner with a team's
     workgroup count) and compared bit for bit - the whole batch, not a sample"""
