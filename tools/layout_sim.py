@@ -63,11 +63,14 @@ for k in range(n):
 cnt = mc
 print(f"{which}: {n} sweeps of {H}x{W}, voxel {vs} m -> {len(cnt)} voxels, {cnt.sum()} points, {cnt.mean():.2f} points per voxel "
       f"(<= 4: {np.mean(cnt <= 4):.0%}, <= 9: {np.mean(cnt <= 9):.0%}, 20: {np.mean(cnt == 20):.0%})")
-lines512 = np.ceil((16 + 24 * cnt) / 128)  # header + the stored points, what a visit of the voxel reads
-print(f"  512-byte blocks: {lines512.mean():.2f} lines per visit of a voxel (header + its points), pool {len(cnt) * 512 / 1e6:.0f} MB live")
-cls = np.where(cnt <= 4, 128, np.where(cnt <= 9, 256, 512))
-print(f"  blocks of 128 / 256 / 512 B by fill: {np.mean(np.ceil((16 + 24 * cnt) / 128)):.2f} lines per visit (the same lines - the points are the points), "
-      f"pool {cls.sum() / 1e6:.0f} MB live ({cls.sum() / (len(cnt) * 512):.0%} of the fixed layout)")
+lines_r4 = np.ceil((16 + 24 * cnt) / 128)  # rounds 3-4: header + the stored points in the block
+lines = np.ceil(24 * cnt / 128)            # round 5: the block holds points only (header and first point in the block directory)
+print(f"  512-byte blocks: {lines.mean():.2f} lines per visit of a voxel (its points; {lines_r4.mean():.2f} with the round-4 header in front), pool {len(cnt) * 512 / 1e6:.0f} MB live; "
+      f"the prune pass reads {len(cnt) * 40 / 1e6:.1f} MB of directory per scan instead of {len(cnt) * 128 / 1e6:.1f} MB of block lines")
+cls = np.where(cnt <= 5, 128, 512)  # round 5's two classes: 128-byte blocks of 5 points, full blocks
+print(f"  two block classes (<= 5 points: 128 B, else 512 B): {np.mean(cnt <= 5):.0%} of the voxels small, pool {cls.sum() / 1e6:.0f} MB live "
+      f"({cls.sum() / (len(cnt) * 512):.0%} of the one-class layout); three classes (128 / 256 / 512 B by fill) would need "
+      f"{np.where(cnt <= 5, 128, np.where(cnt <= 10, 256, 512)).sum() / 1e6:.0f} MB")
 
 kk = mk
 kx, ky, kz = (kk >> 42) - (1 << 20), ((kk >> 21) & ((1 << 21) - 1)) - (1 << 20), (kk & ((1 << 21) - 1)) - (1 << 20)
