@@ -2096,13 +2096,6 @@ __device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, b
     }
     return p;
 }
-#ifndef GN8_OPT
-#define GN8_OPT 0   /* spare slots of a search pass refresh the rows of points that are about to need it (gn8_body, "optional searches"); make EXTRA=-DGN8_OPT=0: off */
-#endif
-#ifndef GN8_NEAR2
-#define GN8_NEAR2 4.0  /* ... a settled point whose remaining slack is below sqrt(GN8_NEAR2) times the step it has just made */
-#endif
-#define GN8_OPTW 64    /* optional entries a wavefront can note between two flushes */
 #ifndef GN8_FAST
 #define GN8_FAST 0  /* make EXTRA=-DGN8_FAST=1 (needs GN8_PREFETCH == 1): movement budgets in LDS - a point whose last row evaluation left room
                        (bound, runner-up, voxel faces) is settled from 24 bytes of pc_t1 until its path since then has used the room up.  Exact
@@ -2123,14 +2116,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
     c.gn_rows_ll = uniform_ptr(c.gn_rows_ll);
     const int G = GC > 0 ? GC : G_rt;
     __shared__ int2 missq[(GN8_MAX_THREADS / 64) * GN8_QWAVE];  // points whose answer row did not settle them: (index, slot of its position in posL or -1)
-    __shared__ int qcount[3][GN8_MAX_THREADS / 64];   // per wavefront: entries at the front / at the back of its region / optional entries
-    // Optional searches (round 5).  A pass of the search costs its chain of dependent round trips whether 9 or 64 points ride on it, and the
-    // points that NEED one come in odd numbers: 80 of them are a full pass and a quarter-full one.  The slots left over in the last pass
-    // go to settled points whose row is about to stop settling them (little slack left against the step they have just made, and a
-    // displacement since their last search that a fresh row would take out of the test): their rows are refreshed a pass early, for
-    // free, instead of next iteration as one more point that needs it.  Nothing else changes hands: such a point has already been
-    // accumulated from its row this iteration, the search's result for it goes to the row only.
-    __shared__ int2 optq[GN8_OPT ? (GN8_MAX_THREADS / 64) * GN8_OPTW : 1];
+    __shared__ int qcount[2][GN8_MAX_THREADS / 64];   // per wavefront: entries at the front / at the back of its region
     __shared__ double part[GN8_ROW_ENTRIES][16];
     __shared__ double redL8[64][GN8_ROW_ENTRIES];     // everybody's rows (G != 32)
     __shared__ double mom[GN8_ROW_ENTRIES];
@@ -2245,12 +2231,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
         for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
         int nq = 0, nqr = 0;  // this WAVEFRONT's queued points: row valid (from the front of its region) | row to be rebuilt (from the back)
         int nfast = 0, nfill = 0;  // this lane: point-iterations settled without their row | budgets set
-        int nqo = 0;               // this WAVEFRONT's optional entries since the last flush
         for (int qb = 0; qb < my_blocks; qb += NW) {
             int missA = -1;  // this lane's point of phase A when the answer row did not settle it
             bool rebA = true;  // ... and whether its probe row has to be rebuilt (first iteration, or the point changed voxel)
             int liA = -1;      // ... and where its position lives: slot in posL, or -1 = src_cur
-            int optA = -1;     // this lane's point when its row settled it with little to spare (an optional search, see optq)
 #ifdef GN_PHASE_CLOCKS
             const long long pa0 = GN_CLK();
 #endif
@@ -2331,12 +2315,6 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
                                 M[17] += (double)ctot_row;
                                 if (m < gate2) gn8_accumulate(M, s, t, kern, k2);
                                 miss = -1;
-                                if (GN8_OPT) {  // about to stop being settled?  little slack against the step just made, and a displacement a fresh row would remove
-                                    const double slack = row[GN8_ANS_D] - (dm + dd);
-                                    const double ux = s.x - p0.x, uy = s.y - p0.y, uz = s.z - p0.z;
-                                    const double step2 = ux * ux + uy * uy + uz * uz;
-                                    if (slack * slack < GN8_NEAR2 * step2 && delta2 >= step2) optA = i;
-                                }
                                 if (GN8_FAST && budgeted(qb)) {
                                     // How far may the point go on before a look at this row could say anything else?  A move by d changes
                                     // each of its distances by at most d: the test keeps passing while 2 d < bound - (distance +
@@ -2388,15 +2366,6 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
                 }
                 nq += __popcll(bf);   // (this wavefront's counts)
                 nqr += __popcll(br);
-                if (GN8_OPT) {
-                    const unsigned long long bo = __ballot(optA >= 0);
-                    if (optA >= 0) {
-                        const int po = nqo + __popcll(bo & below);
-                        if (po < GN8_OPTW) optq[(tq >> 6) * GN8_OPTW + po] = make_int2(optA, liA);
-                    }
-                    nqo += __popcll(bo);
-                    if (nqo > GN8_OPTW) nqo = GN8_OPTW;
-                }
 #ifdef GN_PHASE_CLOCKS
                 ph_miss += __popcll(bm); ph_a += GN_CLK() - c0;
 #endif
@@ -2406,8 +2375,8 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
             if (wg == 0 && tl == 0 && it > 0) { atomicAdd((unsigned long long*)&c.wg_clk[56], (unsigned long long)(pa1 - pa0)); atomicAdd((unsigned long long*)&c.wg_clk[57], (unsigned long long)(pa2 - pa1)); atomicAdd((unsigned long long*)&c.wg_clk[59], 1ull); }
 #endif
             if (qb + NW < my_blocks && ((qb / NW + 1) % GN8_QCHUNKS) != 0) continue;  // (a region holds GN8_QCHUNKS chunks whatever they bring)
-            if ((tl & 63) == 0) { qcount[0][tl >> 6] = nq; qcount[1][tl >> 6] = nqr; qcount[2][tl >> 6] = nqo; }
-            nq = 0; nqr = 0; nqo = 0;
+            if ((tl & 63) == 0) { qcount[0][tl >> 6] = nq; qcount[1][tl >> 6] = nqr; }
+            nq = 0; nqr = 0;
             __syncthreads();
             // search slots: the fronts of the regions, wavefront by wavefront, then - from the next wavefront's first slot on - the backs
             int cf[GN8_MAX_THREADS / 64], cb[GN8_MAX_THREADS / 64];
@@ -2418,15 +2387,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
                 nfront += cf[w]; nback += cb[w];
             }
             const int kback0 = (nfront + 7) & ~7, nmiss = kback0 + nback;
-            // optional searches: as many as the last pass has slots to spare (none when nobody needs a pass)
-            int co[GN8_MAX_THREADS / 64];
-            int nopt = 0;
-#pragma unroll
-            for (int w = 0; w < GN8_MAX_THREADS / 64; ++w) { co[w] = (GN8_OPT && w < NW) ? qcount[2][w] : 0; nopt += co[w]; }
-            const int per_pass = NT / GN8_LPB;
-            const int spare = (GN8_OPT && it > 0 && nmiss > 0) ? ((nmiss + per_pass - 1) / per_pass) * per_pass - nmiss : 0;
-            const int take = nopt < spare ? nopt : spare, nall = nmiss + take;
-            if (tl == 0) xcnt[0] += (unsigned)(nfront + nback + take);
+            if (tl == 0) xcnt[0] += (unsigned)(nfront + nback);
 #ifdef GN_PHASE_CLOCKS
             if (wg == 0 && tl == 0 && it < 24) st->dbg_sums[8 + it] += (double)(nfront + nback);  // misses by iteration index
 #endif
@@ -2445,21 +2406,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
             auto phaseB = [&](auto lp_tag) {
                 constexpr int LPB = decltype(lp_tag)::value;
                 const int laneL = tl & (LPB - 1), gb = (tl & 63) & ~(LPB - 1);
-                for (int k = tl / LPB; __any(k < nall); k += NT / LPB) {
-                  if (k < nfront || (k >= kback0 && k < nall)) {
+                for (int k = tl / LPB; __any(k < nmiss); k += NT / LPB) {
+                  if (k < nfront || (k >= kback0 && k < nmiss)) {
                     [[maybe_unused]] const long long b0 = GN_CLK();
-                    const bool optional = k >= nmiss;  // a settled point whose row is refreshed in a spare slot: nothing to accumulate
-                    int2 qe;
-                    if (!optional) qe = missq[qslot(k)];
-                    else {  // the (k - nmiss)-th optional entry in wavefront order
-                        int j = k - nmiss, q = 0;
-#pragma unroll
-                        for (int w = 0; w < GN8_MAX_THREADS / 64; ++w) {
-                            if (j >= 0 && j < co[w]) q = w * GN8_OPTW + j;
-                            j -= co[w];
-                        }
-                        qe = optq[GN8_OPT ? q : 0];
-                    }
+                    const int2 qe = missq[qslot(k)];
                     const int i = qe.x;
                     const V3 s = qe.y >= 0 ? v3(posL[0][qe.y], posL[1][qe.y], posL[2][qe.y])  // (the point's position now: from the LDS copy,
                                            : v3(c.src_cur[3 * (size_t)i], c.src_cur[3 * (size_t)i + 1], c.src_cur[3 * (size_t)i + 2]);  // or what phase A has just written)
@@ -2485,7 +2435,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
                         atomicAdd(&st->dbg_sums[cat], 1.0);  // 5 voxel changed | 6 no answer stored | 7 same neighbour | 4 another neighbour
                     }
 #endif
-                    if (laneL == 0 && !optional) {
+                    if (laneL == 0) {
                         M[17] += (double)ctot;
                         if (found && m < gate2) gn8_accumulate(M, s, t, kern, k2);
                     }
