@@ -63,8 +63,11 @@ class Comm:
 
     def close(self):
         if getattr(self, "_h", None):
-            from . import _lib as L
-            L.lib().ptl_comm_destroy(self._h)
+            try:
+                from . import _lib as L
+                L.lib().ptl_comm_destroy(self._h)
+            except Exception:  # noqa: BLE001  (interpreter shutdown: the library may be gone already)
+                pass
             self._h = None
 
     __del__ = close
