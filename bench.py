@@ -574,11 +574,10 @@ def main():
     # final trajectory gather: the only collective (T x 8 NC-GT rows per sequence: the library's ncclAllGather, device rows in, host
     # rows out; host rows over gloo when several ranks share one GPU, which RCCL refuses).  It runs after the timed region and brings
     # the RCCL communicator up; a failure or a stall there is reported in the line AND in the exit code.
-    gathered, gather_err = None, None
+    gathered, gather_err, rccl_stalled = None, None, False
     if dist is not None and with_ekf:
         import threading
         from ptudes_lab_amd import parallel
-        box = {}
 
         def _host_rows():
             import torch
@@ -590,7 +589,7 @@ def main():
                 rows[j, : counts[-1]] = torch.from_numpy(parallel.poses_to_rows(o["res_t"], o["res_poses"]))
             return parallel.gather_trajectories(rows, counts, dist)
 
-        def _gather_rccl():
+        def _gather_rccl(box):
             try:
                 comm = parallel.Comm.over(dist, ctl, device_id=local_rank)  # rank 0 makes the id, gloo carries it, everybody joins
                 if S == 1:
@@ -602,15 +601,15 @@ def main():
             except Exception as e:  # noqa: BLE001
                 box["err"] = repr(e)
 
-        def _gather_gloo():
+        def _gather_gloo(box):
             try:
                 box["out"] = _host_rows()
             except Exception as e:  # noqa: BLE001
                 box["err"] = repr(e)
 
         def _attempt(fn):
-            box.clear()
-            th = threading.Thread(target=fn, daemon=True)
+            box = {}  # (its own: a thread that is stuck in an earlier attempt must not write into a later one's)
+            th = threading.Thread(target=fn, args=(box,), daemon=True)
             th.start()
             th.join(timeout=GATHER_TIMEOUT_S)
             err = "no answer after %d s" % GATHER_TIMEOUT_S if th.is_alive() else box.get("err")
@@ -622,9 +621,11 @@ def main():
         gather_backend = "gloo, host rows (ranks share a GPU; RCCL refuses duplicate devices)" if shared_device else \
             "RCCL ncclAllGather through libptudes_mi.so (ptl_batch_gather_trajectories), id over gloo"
         gathered, gather_err, any_failed, stalled = _attempt(_gather_gloo if shared_device else _gather_rccl)
-        if any_failed and not shared_device and parallel.max_over_ranks(1.0 if stalled else 0.0, dist, device="cpu", group=ctl) == 0:
-            # the library's RCCL path raised somewhere (a first contact with a node's RCCL / xGMI set-up): the measurement above does not
-            # depend on it, so every rank falls back to host rows over the control plane - and the line says which way the rows came
+        if any_failed and not shared_device:
+            # the library's RCCL path raised or did not answer somewhere (a first contact with a node's RCCL / xGMI set-up): the measurement
+            # above does not depend on it, so every rank falls back to host rows over the control plane - and the line says which way the
+            # rows came.  (A thread stuck inside RCCL stays behind as a daemon; such a rank leaves without the collective shutdown below.)
+            rccl_stalled = parallel.max_over_ranks(1.0 if stalled else 0.0, dist, device="cpu", group=ctl) > 0
             rccl_err = gather_err or "failed on another rank"
             gathered, gather_err, any_failed, stalled = _attempt(_gather_gloo)
             gather_backend = f"gloo, host rows - FALLBACK after the RCCL gather failed: {rccl_err}"
@@ -817,11 +818,15 @@ def main():
             line["gathered_trajectories"] = {"error": gather_err}
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
-        if gather_err is not None:  # a communicator in an unknown state: leave without the collective shutdown, and say so
+        if gather_err is not None:  # no gather at all (the fallback failed too): leave without the collective shutdown, and say so in the exit code
             sys.stdout.flush()
             sys.stderr.flush()
             os._exit(3)
         dist.barrier(group=ctl)
+        if with_ekf and rccl_stalled:  # the rows came the other way; a thread is still inside RCCL: no collective shutdown, no atexit
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
