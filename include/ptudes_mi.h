@@ -356,9 +356,10 @@ int ptl_batch_debug_set_map_points_per_thread(ptl_batch *b, int32_t points, int3
  * Memory: one sequence of a batch holds 480 B per point of points_per_scan of work buffers (probe and answer rows, ...:
  * 63 MB at 128x1024), its two per-scan voxel tables (64 and 16 slots of 16 B per point: 134 + 34 MB - sparse on purpose,
  * a taken line costs a claim a dependent read), map_table_capacity x 16 B (256 MB at the default 2^24 slots: sparse for
- * the same reason, see ptl_icp_default_cfg), map_block_capacity x (block size + 4) B (512-B blocks at 20 points per
- * voxel: 256 MB at the default 512 k blocks) and its resident sweeps (n_scans x points_per_scan x 12 B): ~770 MB +
- * sweeps at the defaults.  ptl_batch_create checks the sum against
+ * the same reason, see ptl_icp_default_cfg), map_block_capacity x (block size + 44) B (512-B blocks of points at 20 points per
+ * voxel, 40 B of block directory - header and first point - and 4 B of free stack each: 278 MB at the default 512 k blocks),
+ * map_small_blocks x (128 + 48) B when the second block class is on, and its resident sweeps (n_scans x points_per_scan x 12 B):
+ * ~790 MB + sweeps at the defaults.  ptl_batch_create checks the sum against
  * hipMemGetInfo and fails with PTL_ERR_CAPACITY and the numbers when it does not fit. */
 
 /* Compile-time constants of the loaded build that a caller's byte model depends on (bench.py EXEC_COST): [0] candidates
