@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 5's measurements of the final state on the GPU box (run through gpurun, part A or B):
 #   tools/round5_evidence.sh A|B TAG      -> gpurun_out/TAG_*   (copy what should be judged into profiles/)
+# Before part A, in the build container (the diagnostic builds travel with the snapshot; *.so is git-ignored):
+#   make -C ptudes-lab_amd/csrc OUT=$PWD/tools/variants/lib_phases.so PHASES=1 && make -C ptudes-lab_amd/csrc OUT=$PWD/tools/variants/lib_stages.so STAGES=1
 # A: GPU suite + smoke, the driver's command (bench line, kernel stats, dispatches, HBM counters), the same command again with that
 #    counter pass in place (roofline.frac = measured), 200 steps, SQ / L2 counters, phase and stage clocks (diagnostic builds in
 #    tools/variants/), the --icp-only line (BASELINE config 2 as written)
