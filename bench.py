@@ -176,12 +176,39 @@ def cpu_baseline(seq, n_total, use_imu_prediction, budget_s=20.0, with_ekf=True,
         if dm > d1:
             kiss, res = kiss_m, res_m
     multi = vm > v1
-    return dict(value=max(v1, vm), unit="scans/s", cores=cores if multi else 1, kind="port",
+    upstream = upstream_kiss_leg(seq, min(n_total, max(d1, dm)), budget_s / 3.0, kiss)
+    return dict(value=max(v1, vm), unit="scans/s", cores=cores if multi else 1, kind="port", upstream_kiss_icp=upstream,
                 single_thread_value=v1, multi_thread_value=vm if cores > 1 else None,
                 sample=f"first {dm if multi else d1} sweeps of sequence seed {seq.seed} (cold start), "
                        f"{sm if multi else s1:.1f} s wall on {cores if multi else 1} threads "
                        f"(plus {d1} sweeps / {s1:.1f} s single-thread), oracle/liboracle.so; host has "
                        f"{os.cpu_count()} logical cores, {cores} usable under the cgroup quota"), kiss, res
+
+
+def upstream_kiss_leg(seq, n, budget_s, kiss_oracle):
+    """if and only if `import kiss_icp` (0.2.9 / 0.2.10) succeeds on this box, the same array feed through the
+    upstream package, driven by the calls the reference makes (oracle/upstream_kiss.py; ICP only, ground-truth-free constant-velocity
+    guess), timed, and compared with the oracle's ICP-only trajectory when that is what the oracle ran.  Never required: returns
+    {"available": False, "why": ...} otherwise.  No reference file is involved."""
+    from oracle import upstream_kiss as up
+    mod, ver = up.available()
+    if mod is None:
+        return {"available": False, "why": ver}
+    icp = up.Upstream(seq.max_range, seq.min_range)
+    t01 = seq.column_times()
+    spent, done = 0.0, 0
+    for k in range(n):
+        xyz = np.asarray(seq.scan(k), np.float64)
+        sel = np.linalg.norm(xyz, axis=1) > 0
+        t0 = time.perf_counter()
+        icp.register_frame(xyz[sel], t01[sel])
+        spent += time.perf_counter() - t0
+        done += 1
+        if spent >= budget_s:
+            break
+    return {"available": True, "kind": f"upstream kiss-icp {ver}", "value": done / spent, "unit": "scans/s", "sweeps": done,
+            "mode": "ICP only, constant-velocity guess (reference kiss.py:102-105)",
+            "poses_last": np.asarray(icp.poses[-1]).tolist()}
 
 
 def _free_port():
@@ -247,26 +274,40 @@ def launch_ranks(n, argv, worker=None, timeout_s=3600.0, out=None):
     return worst
 
 
-def code_id():
-    """identity of the kernel sources the loaded library was built from (sha256 over csrc/*.hip, *.h and the Makefile, 12 hex
-    digits): recorded in the line and in every PMC summary, so that a counter pass collected on an older kernel is not taken
-    for this build's traffic without saying so"""
+def source_code_id(flags=""):
+    """csrc/Makefile's CODE_ID recomputed from the source tree: sha256 over the kernel sources, the C-ABI header, the Makefile and the
+    experiment flags (none for the product build), 12 hex digits"""
     import glob
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ptudes-lab_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
-        h.update(os.path.basename(f).encode())
+    files = sorted(glob.glob(os.path.join(d, "*.hip"))) + sorted(glob.glob(os.path.join(d, "*.h"))) + \
+        [os.path.join(d, "..", "..", "include", "ptudes_mi.h"), os.path.join(d, "Makefile")]
+    for f in files:
         h.update(open(f, "rb").read())
+    h.update((flags + "\n").encode())
     return h.hexdigest()[:12]
 
 
+def code_id():
+    """identity of the LOADED library (ptl_code_id: baked in by csrc/Makefile from its sources and flags): recorded in the line and in
+    every PMC summary, so that a counter pass collected on another build - an older kernel, an experiment build behind PTL_LIB_PATH,
+    a stale .so - is not taken for this build's traffic.  Falls back to the source tree's id for a library that
+    predates the symbol."""
+    try:
+        from ptudes_lab_amd import _lib
+        return _lib.lib().ptl_code_id().decode()
+    except Exception:  # noqa: BLE001
+        return source_code_id()
+
+
 def pmc_traffic_for(workload_key, scans_per_launch=None, code=None):
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC pass (profiles/) whose recorded workload
-    is THIS run's workload, or None: a counter value belongs to the workload it was collected on.  The free-running kernel's
-    summaries record bytes per SCAN (a launch carries as many scans as the run asks for: the same workload at another step
-    count moves the same bytes per scan) - scaled here by this run's scans per launch; per-launch kernels record bytes per
-    launch.  The latest matching file wins."""
+    """The committed rocprofv3 PMC pass (profiles/) whose recorded workload is THIS run's workload, or None: a counter value
+    belongs to the workload it was collected on.  Returns a dict: bytes (HBM bytes per launch of the dominant kernel: the
+    free-running kernel's summaries record bytes per SCAN, scaled here by this run's scans per launch; per-launch kernels record
+    bytes per launch), file, stale (collected on another build than the loaded one), and what the pass covered - warmup, steps,
+    executed_bytes_per_scan (None for summaries that predate those fields).  A pass of this very build beats a later file of
+    another build; among equals the latest file wins."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json"))):
@@ -276,18 +317,32 @@ def pmc_traffic_for(workload_key, scans_per_launch=None, code=None):
             continue
         if d.get("workload_key") != workload_key:
             continue
-        stale = code is not None and d.get("code_id") != code  # collected on other kernel sources than the loaded build's
+        stale = code is not None and d.get("code_id") != code  # collected on another build than the loaded library
         if d.get("traffic_bytes_per_scan") is not None and scans_per_launch:
-            cand = (d["traffic_bytes_per_scan"] * scans_per_launch, os.path.basename(f), stale)
+            nbytes = d["traffic_bytes_per_scan"] * scans_per_launch
         elif d.get("traffic_bytes_per_launch") is not None and not scans_per_launch:
-            cand = (d["traffic_bytes_per_launch"], os.path.basename(f), stale)
+            nbytes = d["traffic_bytes_per_launch"]
         else:
             continue
-        if best is None or not stale or best[2]:  # a pass of this very build beats a later file of another build
+        cand = {"bytes": nbytes, "file": os.path.basename(f), "stale": stale, "warmup": d.get("warmup"), "steps": d.get("steps"),
+                "executed_bytes_per_scan": d.get("executed_bytes_per_scan"), "per_scan": d.get("traffic_bytes_per_scan") is not None}
+        if best is None or not stale or best["stale"]:
             best = cand
-    if best is not None and code is None:
-        return best[:2]
     return best
+
+
+def pmc_for_this_run(pmc, W, K, exec_bytes_per_scan):
+    """How a counter pass of this workload and build may speak for THIS run.  A free-running summary is bytes per scan
+    over the scans the pass covered; per-scan traffic changes with the scans (the map grows, the iteration count falls), so:
+    same warm-up and step counts -> ("same scans", bytes); other counts, both runs' executed bytes per scan known -> ("scaled", bytes x
+    the ratio of executed bytes per scan, this run : the pass); else (None, None) and the line keeps the executed-byte model."""
+    if not pmc or pmc["stale"]:
+        return None, None
+    if not pmc["per_scan"] or (pmc["warmup"], pmc["steps"]) == (W, K):
+        return "same scans", pmc["bytes"]
+    if pmc["executed_bytes_per_scan"] and exec_bytes_per_scan:
+        return "scaled", pmc["bytes"] * exec_bytes_per_scan / pmc["executed_bytes_per_scan"]
+    return None, None
 
 
 def workload_key(args, S):
@@ -403,6 +458,9 @@ def main():
         # hand-overs of the single-sequence pipeline from 63 to 110 us per scan, measured with one rank in round 1).
         dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
         ctl = dist.group.WORLD
+        # the RCCL id travels over a group of its own: a rank stuck in that broadcast (its thread is abandoned after GATHER_TIMEOUT_S)
+        # must not interleave with the control plane's collectives on `ctl`
+        id_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
 
     K, W, S = args.steps, args.warmup, args.seqs_per_gpu
     n_total = W + K
@@ -575,7 +633,7 @@ def main():
     # rows out; host rows over gloo when several ranks share one GPU, which RCCL refuses).  It runs after the timed region and brings
     # the RCCL communicator up; a failure or a stall there is reported in the line AND in the exit code.
     gathered, gather_err, rccl_stalled = None, None, False
-    if dist is not None and with_ekf:
+    if dist is not None:
         import threading
         from ptudes_lab_amd import parallel
 
@@ -585,13 +643,17 @@ def main():
             counts = []
             for j in range(S):
                 o = outs[j]
-                counts.append(len(o["res_t"]))
-                rows[j, : counts[-1]] = torch.from_numpy(parallel.poses_to_rows(o["res_t"], o["res_poses"]))
+                if with_ekf:
+                    t_rows, p_rows = o["res_t"], o["res_poses"]
+                else:  # ICP only: the registration's own poses, stamped with the scan index (what ptl_batch_gather_trajectories sends then)
+                    t_rows, p_rows = np.arange(len(o["kiss_poses"]), dtype=np.float64), o["kiss_poses"]
+                counts.append(len(t_rows))
+                rows[j, : counts[-1]] = torch.from_numpy(parallel.poses_to_rows(t_rows, p_rows))
             return parallel.gather_trajectories(rows, counts, dist)
 
         def _gather_rccl(box):
             try:
-                comm = parallel.Comm.over(dist, ctl, device_id=local_rank)  # rank 0 makes the id, gloo carries it, everybody joins
+                comm = parallel.Comm.over(dist, id_group, device_id=local_rank)  # rank 0 makes the id, gloo carries it, everybody joins
                 if S == 1:
                     ptr, n_rows = runner.r.traj_device()
                     box["out"] = comm.gather_rows(ptr, 1, n_total, [min(n_rows, n_total)])
@@ -618,10 +680,12 @@ def main():
             any_failed = parallel.max_over_ranks(0.0 if err is None else 1.0, dist, device="cpu", group=ctl) > 0
             return box.get("out"), err, any_failed, th.is_alive()
 
+        host_only = shared_device or (S == 1 and not with_ekf)  # (a single ICP-only sequence keeps no rows on the device)
         gather_backend = "gloo, host rows (ranks share a GPU; RCCL refuses duplicate devices)" if shared_device else \
+            "gloo, host rows (single ICP-only sequence)" if host_only else \
             "RCCL ncclAllGather through libptudes_mi.so (ptl_batch_gather_trajectories), id over gloo"
-        gathered, gather_err, any_failed, stalled = _attempt(_gather_gloo if shared_device else _gather_rccl)
-        if any_failed and not shared_device:
+        gathered, gather_err, any_failed, stalled = _attempt(_gather_gloo if host_only else _gather_rccl)
+        if any_failed and not host_only:
             # the library's RCCL path raised or did not answer somewhere (a first contact with a node's RCCL / xGMI set-up): the measurement
             # above does not depend on it, so every rank falls back to host rows over the control plane - and the line says which way the
             # rows came.  (A thread stuck inside RCCL stays behind as a daemon; such a rank leaves without the collective shutdown below.)
@@ -661,14 +725,20 @@ def main():
             avg_exec = R * exec_bytes / launches
             achieved = avg_exec / avg_gn_s if avg_gn_s > 0 else 0.0
         exec_achieved = achieved  # executed-byte model (free-running) / algorithmic bytes (the per-launch kernels)
-        fresh_pmc = bool(pmc) and not pmc[2] and avg_gn_s > 0
-        if fresh_pmc:  # a counter pass of THIS workload on THIS build's kernel sources: what the memory system moved is the roofline figure
-            achieved = pmc[0] / avg_gn_s
+        exec_per_scan = (exec_bytes / max(n_timed, 1)) if free else None
+        pmc_how, pmc_bytes = pmc_for_this_run(pmc, W, K, exec_per_scan) if avg_gn_s > 0 else (None, None)
+        fresh_pmc = pmc_how is not None
+        if fresh_pmc:  # a counter pass of THIS workload on THIS build: what the memory system moved is the roofline figure
+            achieved = pmc_bytes / avg_gn_s
         roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
                 "frac_of_copy_rate": achieved / HBM_COPY_RATE,
-                "frac_kind": ("HBM traffic of the dominant kernel (rocprofv3 PMC pass of this workload on this build's kernel sources, profiles/" + pmc[1] +
-                              ": 2 x FETCH_SIZE + WRITE_SIZE, corrected as the guide prescribes) / launch time (HIP events, this run) / peak; "
+                "frac_kind": ("HBM traffic of the dominant kernel (rocprofv3 PMC pass of this workload on this build, profiles/" + pmc["file"] +
+                              ": 2 x FETCH_SIZE + WRITE_SIZE, corrected as the guide prescribes"
+                              + (f"; the pass covered the same scans as this run: warm-up {W}, {K} steps" if pmc_how == "same scans" else
+                                 f"; the pass covered warm-up {pmc['warmup']}, {pmc['steps']} steps, this run warm-up {W}, {K} steps: its bytes per scan are "
+                                 f"SCALED by the ratio of executed bytes per scan, this run : the pass = {exec_per_scan / pmc['executed_bytes_per_scan']:.4f}")
+                              + ") / launch time (HIP events, this run) / peak; "
                               "frac_of_copy_rate: / the 6.29 TB/s a streaming copy reaches on this part" if fresh_pmc else
                               "executed bytes: every load / store the kernel issued, at the width requested (bench.py EXEC_COST x the "
                               "kernel's own counters, DESIGN.md 3) / launch time / peak - no counter pass of this build and workload is committed" if free else
@@ -681,9 +751,11 @@ def main():
                 "executed_bytes_per_scan": (exec_bytes / max(n_timed, 1)) if free else None,
                 "executed_split_per_scan": ({"gauss_newton": exec_gn / max(n_timed, 1), "stages": exec_stages / max(n_timed, 1)} if free else None),
                 "executed_counters_per_scan": ({k: v / max(n_timed, 1) for k, v in cnt_tot.items()} if free else None),
-                "traffic": pmc[0] if pmc else None, "traffic_source": pmc[1] if pmc else None,
-                "traffic_stale": (pmc[2] if pmc else None),  # true: the PMC pass was collected on other kernel sources than this build's (config.code_id)
-                "measured_frac": (pmc[0] / avg_gn_s / HBM_PEAK) if (pmc and avg_gn_s > 0) else None,
+                "traffic": (pmc_bytes if fresh_pmc else pmc["bytes"]) if pmc else None, "traffic_source": pmc["file"] if pmc else None,
+                "traffic_stale": (pmc["stale"] if pmc else None),  # true: the PMC pass was collected on another build than the loaded library (config.code_id)
+                "traffic_scans": (None if not pmc else {"how": pmc_how or ("other build" if pmc["stale"] else "other scans, not scalable: frac keeps the executed model"),
+                                                        "pass_warmup": pmc["warmup"], "pass_steps": pmc["steps"], "run_warmup": W, "run_steps": K}),
+                "measured_frac": ((pmc_bytes if fresh_pmc else pmc["bytes"]) / avg_gn_s / HBM_PEAK) if (pmc and avg_gn_s > 0) else None,
                 "kernel": ("k_gn_loop8" if args.gn_lanes == 8 else "k_gn_loop") if S == 1 else
                           "kx_seq_run" if free else ("kx_gn_loop" if args.gn_lanes == 32 else "kx_gn_loop8"),
                 "avg_launch_us": 1e6 * avg_gn_s, "launches": gn_n,
@@ -710,6 +782,7 @@ def main():
                                    f"min/max range {args.min_range}/{args.max_range} m, voxel {(args.voxel_size or args.max_range / 100):.2f} m"
                                    + (f" [{args.workload_name}]" if args.workload_name else ""),
                        "workload_key": wkey, "code_id": cid,
+                       "library_built_from_this_source_tree": cid == source_code_id(),  # false: an experiment build (flags) or a stale .so
                        "sequences_per_gpu": S, "sequence_seeds": seeds_txt,
                        "driver": "single sequence" if S == 1 else
                                  "free-running (one persistent launch, every sequence at its own pace)" if free else "lockstep (one launch per stage)",
@@ -823,7 +896,7 @@ def main():
             sys.stderr.flush()
             os._exit(3)
         dist.barrier(group=ctl)
-        if with_ekf and rccl_stalled:  # the rows came the other way; a thread is still inside RCCL: no collective shutdown, no atexit
+        if rccl_stalled:  # the rows came the other way; a thread is still inside RCCL: no collective shutdown, no atexit
             sys.stdout.flush()
             sys.stderr.flush()
             os._exit(0)

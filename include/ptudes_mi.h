@@ -22,6 +22,7 @@
 #define PTUDES_MI_H
 
 #include <stdint.h>
+#include <string.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -36,6 +37,24 @@ extern "C" {
 #define PTL_F32 0
 #define PTL_F64 1
 
+/* ---- ABI guard.  Every configuration struct starts with {struct_size, abi_version}: the CALLER writes sizeof(its own struct) and the
+ * PTL_ABI_VERSION it was compiled / written against (PTL_CFG_INIT does both) BEFORE handing the struct to the library, and
+ * ptl_*_default_cfg / ptl_*_create refuse a struct whose size or version is not the library's with PTL_ERR_ARG and both numbers in
+ * ptl_last_error() - without writing a byte.  A binding in another language (ctypes, cgo, JNI) that was written against an older header
+ * therefore fails at its first call instead of being overrun by the library's memset or read past its end (a field appended to
+ * ptl_icp_cfg did exactly that to round 5's documented stub).  ptl_abi_version() / ptl_sizeof_cfg() let such a binding assert its
+ * layout at load time (INTEGRATION.md section 2 does).  Bump PTL_ABI_VERSION with every change of a struct or a prototype. */
+#define PTL_ABI_VERSION 6
+#define PTL_CFG_ICP 0
+#define PTL_CFG_EKF 1
+#define PTL_CFG_SEQ 2
+#define PTL_CFG_ICP_STATS 3
+#define PTL_CFG_INIT(cfg_ptr) do { memset((cfg_ptr), 0, sizeof *(cfg_ptr)); (cfg_ptr)->struct_size = (uint32_t)sizeof *(cfg_ptr); (cfg_ptr)->abi_version = PTL_ABI_VERSION; } while (0)
+int ptl_abi_version(void);
+/* the library's sizeof for PTL_CFG_ICP / _EKF / _SEQ / _ICP_STATS (the three configuration structs and the per-scan counter row);
+ * -1 for an unknown id */
+int64_t ptl_sizeof_cfg(int which);
+
 const char *ptl_last_error(void);
 /* 1 when a HIP device is usable (the only backend); never falls back to a CPU path */
 int ptl_backend(void);
@@ -48,6 +67,8 @@ int ptl_device_sync(int device_id); /* hipDeviceSynchronize on that device */
 typedef struct ptl_icp ptl_icp;
 
 typedef struct {
+    uint32_t struct_size;         /* sizeof(ptl_icp_cfg) as the CALLER knows it - set before ptl_icp_default_cfg (PTL_CFG_INIT) */
+    uint32_t abi_version;         /* PTL_ABI_VERSION as the caller knows it */
     /* algorithm parameters: reference kiss.py:40-43 + kiss-icp 0.2.10 config defaults */
     double max_range;             /* kiss.py:25, ekf_bench.py:360-363 */
     double min_range;             /* kiss.py:24,43 */
@@ -93,7 +114,8 @@ typedef struct {
     int64_t map_points;
 } ptl_icp_stats;
 
-/* fills every field with the reference defaults for (max_range, min_range) (kiss.py:21-43) */
+/* fills every field with the reference defaults for (max_range, min_range) (kiss.py:21-43); cfg->struct_size / abi_version must
+ * already hold the caller's values (PTL_CFG_INIT) - a mismatch is refused with PTL_ERR_ARG and nothing is written */
 int ptl_icp_default_cfg(ptl_icp_cfg *cfg, double max_range, double min_range);
 /* KissICPWrapper.__init__ (kiss.py:21-52) */
 int ptl_icp_create(const ptl_icp_cfg *cfg, ptl_icp **out);
@@ -201,6 +223,8 @@ int ptl_icp_debug_set_epoch(ptl_icp *h, uint32_t epoch);
 typedef struct ptl_ekf ptl_ekf;
 
 typedef struct {
+    uint32_t struct_size; /* sizeof(ptl_ekf_cfg) as the caller knows it (PTL_CFG_INIT) */
+    uint32_t abi_version;
     double init_grav[3]; /* es_ekf.py:75 */
     double init_bacc[3]; /* es_ekf.py:76 */
     double init_bgyr[3]; /* es_ekf.py:77 */
@@ -228,6 +252,8 @@ int ptl_ekf_ts(ptl_ekf *h, double *ts);         /* ESEKF.ts (:186-189) */
 typedef struct ptl_seq ptl_seq;
 
 typedef struct {
+    uint32_t struct_size; /* sizeof(ptl_seq_cfg) as the caller knows it (PTL_CFG_INIT); icp and ekf carry their own */
+    uint32_t abi_version;
     ptl_icp_cfg icp;
     ptl_ekf_cfg ekf;
     int64_t n_scans;
@@ -369,6 +395,10 @@ int ptl_batch_debug_set_map_points_per_thread(ptl_batch *b, int32_t points, int3
  * [9] chunks phase A requests ahead, [10] 1000 x the pruning margin, [11] / [12] bytes per map-table / voxel-table
  * entry, [13] 1 when diagnostic clocks are compiled in, [14] 1 for a build of the movement-budget experiment (make EXTRA=-DGN8_FAST=1; off in the product). */
 int ptl_build_info(int32_t out[16]);
+/* identity of what THIS library was built from: sha256 over the kernel sources, the Makefile and the experiment flags (12 hex digits,
+ * csrc/Makefile CODE_ID).  bench.py records it in its line and tools/pmc_summary.py in every counter summary: a counter pass speaks
+ * for the build it ran on, whatever the source tree looks like by then. */
+const char *ptl_code_id(void);
 
 /* ---- multi-GPU: the final trajectory gather.  The reference has no distributed layer; the path shards
  * across independent sequences only (one rank per GPU, no data-path collective) and its ONE collective is the all-gather of every

@@ -17,8 +17,21 @@ c_d_p = C.POINTER(C.c_double)
 c_i64_p = C.POINTER(C.c_int64)
 
 
-class IcpCfg(C.Structure):
-    _fields_ = [("max_range", C.c_double), ("min_range", C.c_double), ("voxel_size", C.c_double),
+ABI_VERSION = 6  # PTL_ABI_VERSION of the include/ptudes_mi.h this binding was written against
+
+
+class _Cfg(C.Structure):
+    """A configuration struct of the header: starts with {struct_size, abi_version}, which the CALLER fills in before the library
+    sees the struct (PTL_CFG_INIT) - ptl_*_default_cfg / ptl_*_create refuse a layout that is not theirs instead of overrunning it."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(type(self))
+        self.abi_version = ABI_VERSION
+
+
+class IcpCfg(_Cfg):
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("max_range", C.c_double), ("min_range", C.c_double), ("voxel_size", C.c_double),
                 ("max_points_per_voxel", C.c_int32), ("initial_threshold", C.c_double),
                 ("min_motion_th", C.c_double), ("deskew", C.c_int32), ("max_iterations", C.c_int32),
                 ("convergence", C.c_double), ("device_id", C.c_int32), ("scan_cols", C.c_int32),
@@ -37,13 +50,13 @@ class IcpStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-class EkfCfg(C.Structure):
-    _fields_ = [("init_grav", C.c_double * 3), ("init_bacc", C.c_double * 3), ("init_bgyr", C.c_double * 3),
+class EkfCfg(_Cfg):
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("init_grav", C.c_double * 3), ("init_bacc", C.c_double * 3), ("init_bgyr", C.c_double * 3),
                 ("device_id", C.c_int32)]
 
 
-class SeqCfg(C.Structure):
-    _fields_ = [("icp", IcpCfg), ("ekf", EkfCfg), ("n_scans", C.c_int64), ("points_per_scan", C.c_int64),
+class SeqCfg(_Cfg):
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("icp", IcpCfg), ("ekf", EkfCfg), ("n_scans", C.c_int64), ("points_per_scan", C.c_int64),
                 ("n_imu", C.c_int64), ("use_imu_prediction", C.c_int32), ("with_ekf", C.c_int32)]
 
 
@@ -51,6 +64,8 @@ _vp = C.c_void_p
 _vpp = C.POINTER(C.c_void_p)
 # every exported symbol of include/ptudes_mi.h with its prototype
 PROTOTYPES = {
+    "ptl_abi_version": (C.c_int, []),
+    "ptl_sizeof_cfg": (C.c_int64, [C.c_int]),
     "ptl_last_error": (C.c_char_p, []),
     "ptl_backend": (C.c_int, []),
     "ptl_device_count": (C.c_int, []),
@@ -140,6 +155,7 @@ PROTOTYPES = {
     "ptl_batch_debug_stall_block": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "ptl_batch_debug_set_map_points_per_thread": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int32)]),
     "ptl_build_info": (C.c_int, [C.POINTER(C.c_int32)]),
+    "ptl_code_id": (C.c_char_p, []),
     "ptl_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "ptl_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, _vpp]),
     "ptl_comm_destroy": (C.c_int, [_vp]),
@@ -172,6 +188,13 @@ def lib():
             f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             f.restype = res
             f.argtypes = args
+        if hasattr(L, "ptl_abi_version"):
+            # the binding's layouts against the loaded library's, before any struct changes hands
+            have = (L.ptl_abi_version(), [L.ptl_sizeof_cfg(i) for i in range(4)])
+            want = (ABI_VERSION, [C.sizeof(t) for t in (IcpCfg, EkfCfg, SeqCfg, IcpStats)])
+            if have != want and not older:
+                raise RuntimeError(f"{LIB_PATH}: ABI version / sizeof(icp cfg, ekf cfg, seq cfg, icp stats) = {have}, this binding "
+                                   f"(ptudes-lab_amd/_lib.py) was written for {want}: rebuild the library or update the binding")
         _lib = L
     return _lib
 

@@ -36,6 +36,26 @@ extern "C" int ptl_device_count(void) {
 }
 extern "C" int ptl_backend(void) { return ptl_device_count() > 0 ? 1 : 0; }
 
+// ---- ABI guard (include/ptudes_mi.h): a configuration struct says how big its writer thinks it is and which ABI it was written against
+extern "C" int ptl_abi_version(void) { return PTL_ABI_VERSION; }
+extern "C" int64_t ptl_sizeof_cfg(int which) {
+    switch (which) {
+        case PTL_CFG_ICP: return (int64_t)sizeof(ptl_icp_cfg);
+        case PTL_CFG_EKF: return (int64_t)sizeof(ptl_ekf_cfg);
+        case PTL_CFG_SEQ: return (int64_t)sizeof(ptl_seq_cfg);
+        case PTL_CFG_ICP_STATS: return (int64_t)sizeof(ptl_icp_stats);
+    }
+    return -1;
+}
+// (the two leading words are read only: on a mismatch nothing of the caller's memory is written)
+static int abi_check(const char* what, uint32_t size_caller, uint32_t abi_caller, size_t size_lib) {
+    if (size_caller == (uint32_t)size_lib && abi_caller == (uint32_t)PTL_ABI_VERSION) return PTL_OK;
+    return set_err(PTL_ERR_ARG, "%s: the caller's struct_size = %u, abi_version = %u; this library's sizeof(%s) = %zu, PTL_ABI_VERSION = %d "
+                   "- set both before the call (PTL_CFG_INIT) and rebuild / rewrite the binding against this library's include/ptudes_mi.h",
+                   what, size_caller, abi_caller, what, size_lib, PTL_ABI_VERSION);
+}
+#define ABI_CHECK(what, p) do { int rc_ = abi_check(#what, (p)->struct_size, (p)->abi_version, sizeof(what)); if (rc_) return rc_; } while (0)
+
 // ================================================================================================ ICP
 struct ptl_icp {
     ptl_icp_cfg cfg;
@@ -78,7 +98,8 @@ struct ptl_icp {
 
 extern "C" int ptl_icp_default_cfg(ptl_icp_cfg* cfg, double max_range, double min_range) {
     if (!cfg) return set_err(PTL_ERR_ARG, "cfg is null");
-    memset(cfg, 0, sizeof *cfg);
+    ABI_CHECK(ptl_icp_cfg, cfg);
+    PTL_CFG_INIT(cfg);
     cfg->max_range = max_range;
     cfg->min_range = min_range;
     cfg->voxel_size = max_range / 100.0;  // kiss-icp load_config
@@ -183,6 +204,7 @@ static int icp_reset_device(ptl_icp* h) {
 
 static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, ptl_icp** out, bool batch_member = false) {
     if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
+    ABI_CHECK(ptl_icp_cfg, cfg);
     // the search maps one lane of a 32-lane group to one stored point of a voxel: more than 32 per voxel would be stored and never examined
     if (cfg->max_points_per_voxel < 1 || cfg->max_points_per_voxel > 32) return set_err(PTL_ERR_ARG, "max_points_per_voxel must be in [1, 32]");
     if (cfg->map_block_capacity < 1 || cfg->map_small_blocks < 0 || cfg->map_block_capacity + cfg->map_small_blocks >= (1 << 24) - 1)
@@ -1011,7 +1033,8 @@ struct ptl_ekf {
 
 extern "C" int ptl_ekf_default_cfg(ptl_ekf_cfg* cfg) {
     if (!cfg) return set_err(PTL_ERR_ARG, "cfg is null");
-    memset(cfg, 0, sizeof *cfg);
+    ABI_CHECK(ptl_ekf_cfg, cfg);
+    PTL_CFG_INIT(cfg);
     cfg->init_grav[2] = -9.782940329221166;  // GRAV * DOWN (es_ekf.py:75, ins/data.py:10)
     return PTL_OK;
 }
@@ -1025,6 +1048,7 @@ static int ekf_reset(ptl_ekf* h) {
 }
 static int ekf_create_impl(const ptl_ekf_cfg* cfg, hipStream_t shared, ptl_ekf** out) {
     if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
+    ABI_CHECK(ptl_ekf_cfg, cfg);
     if (ptl_device_count() <= cfg->device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->device_id);
     HIPCHK(hipSetDevice(cfg->device_id));
     ptl_ekf* h = new ptl_ekf();
@@ -1126,16 +1150,24 @@ extern "C" int ptl_icp_ekf_step(ptl_icp* h, ptl_ekf* e, const double* imu_rows, 
     if (dtype != PTL_F32 && dtype != PTL_F64) return set_err(PTL_ERR_ARG, "dtype must be PTL_F32 or PTL_F64");
     if (n > h->n_max) return set_err(PTL_ERR_CAPACITY, "scan has %lld points, capacity %lld", (long long)n, (long long)h->n_max);
     if (h->cfg.device_id != e->cfg.device_id) return set_err(PTL_ERR_ARG, "registration on device %d, filter on device %d", h->cfg.device_id, e->cfg.device_id);
-    if (n_imu > e->buf_rows) return set_err(PTL_ERR_ARG, "at most %lld IMU samples per step", (long long)e->buf_rows);
     HIPCHK(hipSetDevice(h->cfg.device_id));
     if (!h->ev_step_guess) {
         HIPCHK(hipEventCreateWithFlags(&h->ev_step_guess, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_step_gn, hipEventDisableTiming));
     }
     hipStream_t es = e->stream;
-    if (n_imu > 0) {  // processImu x n_imu (one launch: ptl_ekf_process_imu_batch's kernel)
-        HIPCHK(hipMemcpyAsync(e->d_buf, imu_rows, (size_t)n_imu * 56, hipMemcpyHostToDevice, es));
-        k_ekf_step<<<1, EKF_THREADS, 0, es>>>(e->st, e->d_buf, 0, (int)n_imu, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+    // processImu x n_imu (ptl_ekf_process_imu_batch's kernel).  Any count is served, like the call-by-call loop (a long IMU-only prefix,
+    // dropped lidar frames, a 1 kHz IMU): what does not fit the staging buffer goes first, buf_rows samples at a time with a wait for
+    // the buffer's reuse; the last buf_rows or fewer ride on this step's single wait.
+    int64_t off = 0;
+    for (; n_imu - off > e->buf_rows; off += e->buf_rows) {
+        HIPCHK(hipMemcpyAsync(e->d_buf, imu_rows + 7 * off, (size_t)e->buf_rows * 56, hipMemcpyHostToDevice, es));
+        k_ekf_step<<<1, EKF_THREADS, 0, es>>>(e->st, e->d_buf, 0, (int)e->buf_rows, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+        HIPCHK(hipStreamSynchronize(es));
+    }
+    if (n_imu > off) {
+        HIPCHK(hipMemcpyAsync(e->d_buf, imu_rows + 7 * off, (size_t)(n_imu - off) * 56, hipMemcpyHostToDevice, es));
+        k_ekf_step<<<1, EKF_THREADS, 0, es>>>(e->st, e->d_buf, 0, (int)(n_imu - off), nullptr, nullptr, nullptr, nullptr, nullptr, 0);
     }
     const size_t esz = dtype == PTL_F32 ? 4 : 8;
     if (n) HIPCHK(hipMemcpyAsync(h->d_in, xyz, (size_t)n * 3 * esz, hipMemcpyHostToDevice, h->stream));
@@ -1212,6 +1244,9 @@ extern "C" int ptl_seq_destroy(ptl_seq* s) {
 }
 extern "C" int ptl_seq_create(const ptl_seq_cfg* cfg, ptl_seq** out) {
     if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
+    ABI_CHECK(ptl_seq_cfg, cfg);
+    ABI_CHECK(ptl_icp_cfg, &cfg->icp);
+    ABI_CHECK(ptl_ekf_cfg, &cfg->ekf);
     if (cfg->n_scans < 1 || cfg->points_per_scan < 1) return set_err(PTL_ERR_ARG, "empty sequence");
     if (ptl_device_count() <= cfg->icp.device_id) return set_err(PTL_ERR_HIP, "no HIP device %d (the HIP backend is the only backend)", cfg->icp.device_id);
     HIPCHK(hipSetDevice(cfg->icp.device_id));
@@ -1539,6 +1574,9 @@ extern "C" int ptl_batch_destroy(ptl_batch* b) {
 }
 extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl_batch** out) {
     if (!cfg || !out) return set_err(PTL_ERR_ARG, "null argument");
+    ABI_CHECK(ptl_seq_cfg, cfg);
+    ABI_CHECK(ptl_icp_cfg, &cfg->icp);
+    ABI_CHECK(ptl_ekf_cfg, &cfg->ekf);
     if (n_sequences < 1 || n_sequences > GN_MAX_SEQ) return set_err(PTL_ERR_ARG, "n_sequences must be in [1, %d]", GN_MAX_SEQ);
     if (cfg->n_scans < 1 || cfg->points_per_scan < 1) return set_err(PTL_ERR_ARG, "empty sequence");
     if ((cfg->icp.gn_workgroups & 31) || cfg->icp.gn_workgroups > 512) return set_err(PTL_ERR_ARG, "batched runs need gn_workgroups = a multiple of 32 (8 XCDs x up to 4 sequences each), at most 512");
@@ -1959,6 +1997,10 @@ extern "C" int ptl_batch_sched_counters(ptl_batch* b, int32_t s, uint64_t out[4]
 // compile-time constants of this build that callers' byte models depend on (bench.py EXEC_COST):
 //   [0] GN8_KCAND  [1] doubles per answer row  [2] GN8_LDS_PTS  [3] SEQ_U  [4] SEQ_U2  [5] GN8_MAX_THREADS  [6] GN8_LPB  [7] GN8_SPEC
 //   [8] GN8_SURV  [9] GN8_PREFETCH  [10] 1000 x GN8_KEEP  [11] bytes per map table entry  [12] bytes per VDS entry  [13] diagnostics compiled in
+#ifndef PTL_CODE_ID
+#define PTL_CODE_ID "unknown"
+#endif
+extern "C" const char* ptl_code_id(void) { return PTL_CODE_ID; }
 extern "C" int ptl_build_info(int32_t out[16]) {
     if (!out) return set_err(PTL_ERR_ARG, "null argument");
     for (int i = 0; i < 16; ++i) out[i] = 0;
@@ -2123,6 +2165,11 @@ struct ptl_comm {
     ncclComm_t comm;
     int world, rank, device_id;
     hipStream_t stream;
+    // staging of the gather, kept between calls (grow-only): send [per_rank], recv [world x per_rank] on the device, the host mirror of recv
+    double *d_send, *d_recv;
+    size_t cap_send, cap_recv;
+    std::vector<double> host;
+    bool broken;  // a local failure aborted the communicator (ncclCommAbort): the peers' collective fails instead of hanging, every later call is refused
 };
 extern "C" int ptl_comm_unique_id(uint8_t id[PTL_COMM_ID_BYTES]) {
     if (!id) return set_err(PTL_ERR_ARG, "null argument");
@@ -2142,6 +2189,7 @@ extern "C" int ptl_comm_create(const uint8_t id[PTL_COMM_ID_BYTES], int32_t worl
     HIPCHK(hipSetDevice(device_id));
     ptl_comm* c = new ptl_comm();
     c->comm = nullptr; c->world = world; c->rank = rank; c->device_id = device_id; c->stream = nullptr;
+    c->d_send = nullptr; c->d_recv = nullptr; c->cap_send = 0; c->cap_recv = 0; c->broken = false;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_err(PTL_ERR_HIP, "stream creation failed"); }
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
@@ -2159,7 +2207,9 @@ extern "C" int ptl_comm_destroy(ptl_comm* c) {
     RcclApi* api = rccl_api();
     (void)hipSetDevice(c->device_id);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (api && c->comm) (void)api->CommDestroy(c->comm);
+    if (api && c->comm && !c->broken) (void)api->CommDestroy(c->comm);
+    if (c->d_send) (void)hipFree(c->d_send);
+    if (c->d_recv) (void)hipFree(c->d_recv);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PTL_OK;
@@ -2167,44 +2217,71 @@ extern "C" int ptl_comm_destroy(ptl_comm* c) {
 // every rank: S sequences x T rows x 8 doubles on the DEVICE (padded with anything) and S row counts on the host; same S and T on every rank.
 // rows_out [world][S][T][8] and counts_out [world][S] on the host, filled on every rank.  One ncclAllGather: the counts ride behind the rows
 // in the same send buffer (as doubles - exact for any count below 2^53).
+// A failure on THIS rank between communicator creation and the collective must not leave the peers waiting in ncclAllGather for ever
+// (they sit in hipStreamSynchronize without a time-out): the communicator is aborted, which fails their collective.
+static int comm_fail(ptl_comm* c, RcclApi* api, int rc) {
+    if (api && api->CommAbort && c->comm && !c->broken) (void)api->CommAbort(c->comm);
+    c->broken = true;
+    return rc;
+}
 extern "C" int ptl_gather_trajectories(ptl_comm* c, const double* d_rows, int64_t S, int64_t T, const int64_t* counts,
                                        double* rows_out, int64_t* counts_out) {
+    // arguments first: nothing is allocated, staged or sent for a call that is wrong in itself (the peers of a rank that returns HERE
+    // are the caller's to tell - every rank validates the same S and T, and a bad count aborts the communicator below)
     if (!c || !d_rows || !counts || !rows_out || !counts_out || S < 1 || T < 1) return set_err(PTL_ERR_ARG, "bad argument");
+    if (c->broken) return set_err(PTL_ERR_STATE, "the communicator was aborted after an earlier failure on this rank: create a new one");
     RcclApi* api = rccl_api();
     if (!api) return set_err(PTL_ERR_STATE, "%s", rccl_why());
+    for (int64_t s = 0; s < S; ++s)
+        if (counts[s] < 0 || counts[s] > T) return comm_fail(c, api, set_err(PTL_ERR_ARG, "count of sequence %lld outside [0, T]", (long long)s));
     HIPCHK(hipSetDevice(c->device_id));
-    const size_t per_rank = (size_t)S * (size_t)T * 8 + (size_t)S;
-    double *d_send = nullptr, *d_recv = nullptr;
-    HIPCHK(dalloc(&d_send, per_rank));
-    if (dalloc(&d_recv, per_rank * (size_t)c->world) != hipSuccess) { (void)hipFree(d_send); return set_err(PTL_ERR_HIP, "gather buffer allocation failed"); }
-    std::vector<double> cnt((size_t)S);
-    for (int64_t s = 0; s < S; ++s) {
-        if (counts[s] < 0 || counts[s] > T) { (void)hipFree(d_send); (void)hipFree(d_recv); return set_err(PTL_ERR_ARG, "count of sequence %lld outside [0, T]", (long long)s); }
-        cnt[(size_t)s] = (double)counts[s];
+    const size_t per_rank = (size_t)S * (size_t)T * 8 + (size_t)S, all = per_rank * (size_t)c->world;
+    if (c->cap_send < per_rank) {
+        if (c->d_send) (void)hipFree(c->d_send);
+        c->d_send = nullptr; c->cap_send = 0;
+        if (dalloc(&c->d_send, per_rank) != hipSuccess) return comm_fail(c, api, set_err(PTL_ERR_HIP, "gather buffer allocation failed (%.1f MB)", per_rank * 8 / 1e6));
+        c->cap_send = per_rank;
     }
-    int rc = PTL_OK;
-    std::vector<double> host(per_rank * (size_t)c->world);
-    do {
-        if (hipMemcpyAsync(d_send, d_rows, (size_t)S * T * 64, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
-            hipMemcpyAsync(d_send + (size_t)S * T * 8, cnt.data(), (size_t)S * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = set_err(PTL_ERR_HIP, "gather staging failed"); break; }
-        ncclResult_t r = api->AllGather(d_send, d_recv, per_rank, ncclDouble, c->comm, c->stream);
-        if (r != ncclSuccess) { rc = set_err(PTL_ERR_HIP, "ncclAllGather: %s", api->GetErrorString(r)); break; }
-        if (hipMemcpyAsync(host.data(), d_recv, host.size() * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) { rc = set_err(PTL_ERR_HIP, "gather read-back failed: %s", hipGetErrorString(hipGetLastError())); break; }
-    } while (0);
-    (void)hipFree(d_send); (void)hipFree(d_recv);
-    if (rc) return rc;
-    for (int r = 0; r < c->world; ++r) {
-        const double* p = host.data() + per_rank * (size_t)r;
-        memcpy(rows_out + (size_t)r * S * T * 8, p, (size_t)S * T * 64);
-        for (int64_t s = 0; s < S; ++s) counts_out[(size_t)r * S + s] = (int64_t)p[(size_t)S * T * 8 + s];
+    if (c->cap_recv < all) {
+        if (c->d_recv) (void)hipFree(c->d_recv);
+        c->d_recv = nullptr; c->cap_recv = 0;
+        if (dalloc(&c->d_recv, all) != hipSuccess) return comm_fail(c, api, set_err(PTL_ERR_HIP, "gather buffer allocation failed (%.1f MB)", all * 8 / 1e6));
+        c->cap_recv = all;
+    }
+    if (c->host.size() < all + (size_t)S) c->host.resize(all + (size_t)S);
+    double* cnt = c->host.data() + all;  // (the counts as doubles, staged behind the mirror: exact below 2^53)
+    for (int64_t s = 0; s < S; ++s) cnt[s] = (double)counts[s];
+    if (hipMemcpyAsync(c->d_send, d_rows, (size_t)S * T * 64, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(c->d_send + (size_t)S * T * 8, cnt, (size_t)S * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return comm_fail(c, api, set_err(PTL_ERR_HIP, "gather staging failed: %s", hipGetErrorString(hipGetLastError())));
+    ncclResult_t r = api->AllGather(c->d_send, c->d_recv, per_rank, ncclDouble, c->comm, c->stream);
+    if (r != ncclSuccess) return comm_fail(c, api, set_err(PTL_ERR_HIP, "ncclAllGather: %s", api->GetErrorString(r)));
+    if (hipMemcpyAsync(c->host.data(), c->d_recv, all * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return comm_fail(c, api, set_err(PTL_ERR_HIP, "gather read-back failed: %s", hipGetErrorString(hipGetLastError())));
+    for (int rk = 0; rk < c->world; ++rk) {
+        const double* p = c->host.data() + per_rank * (size_t)rk;
+        memcpy(rows_out + (size_t)rk * S * T * 8, p, (size_t)S * T * 64);
+        for (int64_t s = 0; s < S; ++s) counts_out[(size_t)rk * S + s] = (int64_t)p[(size_t)S * T * 8 + s];
     }
     return PTL_OK;
+}
+// ICP-only batches have no filter and so no NC-GT rows of its making: the registration's own poses (KissICP.poses, reference kiss.py:130,
+// what `ekf-bench ouster` writes when no filter corrects them) as rows [scan index, x, y, z, qx, qy, qz, qw]
+__global__ void k_kiss_rows(const double* traj16, int n, double* rows8) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n) return;
+    const double* T = traj16 + 16 * (size_t)k;
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    double q[4];
+    R_to_quat(R, q);
+    double* o = rows8 + 8 * (size_t)k;
+    o[0] = (double)k; o[1] = T[3]; o[2] = T[7]; o[3] = T[11];
+    o[4] = q[0]; o[5] = q[1]; o[6] = q[2]; o[7] = q[3];
 }
 // ... of a batch: the rows its filter kernel wrote for every sequence (ptl_batch_copy_traj's source), T = the batch's n_scans
 extern "C" int ptl_batch_gather_trajectories(ptl_batch* b, ptl_comm* c, double* rows_out, int64_t* counts_out) {
     if (!b || !c || !rows_out || !counts_out) return set_err(PTL_ERR_ARG, "null argument");
-    if (!b->cfg.with_ekf) return set_err(PTL_ERR_STATE, "trajectory rows need with_ekf");
     if (c->device_id != b->cfg.icp.device_id) return set_err(PTL_ERR_ARG, "communicator on device %d, batch on device %d", c->device_id, b->cfg.icp.device_id);
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
     HIPCHK(hipStreamSynchronize(b->side));
@@ -2214,8 +2291,12 @@ extern "C" int ptl_batch_gather_trajectories(ptl_batch* b, ptl_comm* c, double* 
     HIPCHK(dalloc(&d_rows, (size_t)S * T * 8));
     std::vector<int64_t> counts((size_t)S, b->n_out < T ? b->n_out : T);
     hipError_t e = hipMemsetAsync(d_rows, 0, (size_t)S * T * 64, b->stream);
-    for (int64_t s = 0; s < S && e == hipSuccess; ++s)
-        if (counts[(size_t)s] > 0) e = hipMemcpyAsync(d_rows + (size_t)s * T * 8, b->d_rows[s], (size_t)counts[(size_t)s] * 64, hipMemcpyDeviceToDevice, b->stream);
+    for (int64_t s = 0; s < S && e == hipSuccess; ++s) {
+        const int64_t n = counts[(size_t)s];
+        if (n <= 0) continue;
+        if (b->cfg.with_ekf) e = hipMemcpyAsync(d_rows + (size_t)s * T * 8, b->d_rows[s], (size_t)n * 64, hipMemcpyDeviceToDevice, b->stream);
+        else { k_kiss_rows<<<(int)((n + 63) / 64), 64, 0, b->stream>>>(b->icp[s]->c.traj, (int)n, d_rows + (size_t)s * T * 8); e = hipGetLastError(); }
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     if (e != hipSuccess) { (void)hipFree(d_rows); return set_err(PTL_ERR_HIP, "row staging failed: %s", hipGetErrorString(e)); }
     const int rc = ptl_gather_trajectories(c, d_rows, S, T, counts.data(), rows_out, counts_out);

@@ -76,9 +76,20 @@ class Comm:
 def broadcast_id(dist, group, make_id):
     """rank 0 of `group` calls make_id() -> bytes; every rank returns those bytes (hex through a broadcast of objects: any
     control-plane backend carries it)"""
-    box = [make_id().hex() if dist.get_rank(group) == 0 else None]
+    # A make_id() that raises on rank 0 (librccl cannot be opened: the case bench.py's gloo fallback exists for) must not leave the other
+    # ranks blocked in this broadcast while rank 0 moves on to other collectives of the same group: the error travels IN the broadcast
+    # and every rank raises together (ADVICE r5).
+    box = [None]
+    if dist.get_rank(group) == 0:
+        try:
+            box = [("id", make_id().hex())]
+        except Exception as e:  # noqa: BLE001
+            box = [("error", repr(e))]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if hasattr(dist, "get_global_rank") else 0, group=group)
-    return bytes.fromhex(box[0])
+    kind, payload = box[0]
+    if kind != "id":
+        raise RuntimeError(f"rank 0 could not make the communicator id: {payload}")
+    return bytes.fromhex(payload)
 
 
 def shard_sequences(n_sequences: int, rank: int, world: int):

@@ -25,7 +25,11 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
     together with the scan - ptl_icp_ekf_step: predicts, registration with the filter's pose read on the device, update, ONE wait
     per scan instead of a read-back for the guess, one for the pose and one for the filter's state.  Same kernels in the same order:
     the trajectory is the device-resident runner's bit for bit (the guess never leaves the device in either) and the call-by-call
-    loop's to 1e-9 m (there the guess makes a round trip through host arithmetic) - tests/test_gpu_dropin.py."""
+    loop's to 1e-9 m (there the guess makes a round trip through host arithmetic) - tests/test_gpu_dropin.py.  Any number of IMU
+    samples between two scans is served (the entry point feeds what exceeds its staging buffer in chunks).
+    timings: in the fused form `kiss` is the whole loop body of a scan (predicts + registration + update, one call) and `imu` /
+    `corr` only count the host's hold-back (about 0): the reference's three per-stage means (ekf_bench.py:590-595) exist
+    separately only with fused=False; timings["fused"] says which form ran."""
     if fused is None:
         fused = not logging
     # (the loop reads poses only - ekf_bench.py:549-563: the registration need not wait for its map update, lazy_map_stats)
@@ -45,6 +49,8 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
                 t_track += time.monotonic() - t1
             t1 = time.monotonic()
             if fused:
+                # what ESEKF.processImu does to the sample on the host before anything else (es_ekf.py:194-196): imu.dt = ts - the previous sample's ts (0.0 before the first)
+                ev[1].dt = ev[1].ts - (held[-1].ts if held else ekf.ts)
                 held.append(ev[1])
             else:
                 ekf.processImu(ev[1])
@@ -116,7 +122,7 @@ def run_events(events, metadata, *, kiss_min_range=1.0, kiss_max_range=70.0, use
         for i in held:
             ekf.processImu(i)
     timings = dict(imu=t_imu / max(n_imu, 1), corr=t_corr / max(n_corr, 1), kiss=t_kiss / max(n_corr, 1),
-                   track=t_track / max(n_corr, 1), n_imu=n_imu, n_corr=n_corr)
+                   track=t_track / max(n_corr, 1), n_imu=n_imu, n_corr=n_corr, fused=bool(fused))
     return dict(res_t=res_t, res_poses=res_poses, kiss_poses=kiss_poses, kiss_icp=kiss_icp, ekf=ekf, timings=timings)
 
 

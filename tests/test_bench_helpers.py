@@ -47,16 +47,31 @@ def test_roofline_traffic_only_from_a_pmc_pass_of_the_same_workload(tmp_path, mo
     (prof / "r09_x_pmc_hbm_traffic_b.json").write_text(json.dumps({"workload_key": k8, "traffic_bytes_per_launch": 9.6e11, "traffic_bytes_per_scan": 1.0e8}))
     (prof / "r01_n_pmc_hbm_traffic.json").write_text(json.dumps({"k_gn_loop_traffic_bytes_per_launch": 2.5e7}))  # round-1 form: no key
     monkeypatch.setattr(b, "ROOT", str(tmp_path))
-    assert b.pmc_traffic_for(lock16) == (1.0e9, "r09_x_pmc_hbm_traffic_a.json")
-    assert b.pmc_traffic_for(k8, scans_per_launch=160) == (1.6e10, "r09_x_pmc_hbm_traffic_b.json")  # 8 sequences x 20 steps in one launch
+    def got(p):
+        return None if p is None else (p["bytes"], p["file"], p["stale"])
+
+    assert got(b.pmc_traffic_for(lock16)) == (1.0e9, "r09_x_pmc_hbm_traffic_a.json", False)
+    assert got(b.pmc_traffic_for(k8, scans_per_launch=160)) == (1.6e10, "r09_x_pmc_hbm_traffic_b.json", False)  # 8 sequences x 20 steps in one launch
     assert b.pmc_traffic_for(k16, scans_per_launch=320) is None  # another workload's counters are not this run's
     # ... and to the kernel sources it ran on: a pass of another build is reported as stale, a pass of this build wins
     (prof / "r09_y_pmc_hbm_traffic_c.json").write_text(json.dumps({"workload_key": k8, "code_id": "abc", "traffic_bytes_per_scan": 2.0e8}))
-    assert b.pmc_traffic_for(k8, 160, code="abc") == (3.2e10, "r09_y_pmc_hbm_traffic_c.json", False)
-    assert b.pmc_traffic_for(k8, 160, code="zzz")[2] is True
+    assert got(b.pmc_traffic_for(k8, 160, code="abc")) == (3.2e10, "r09_y_pmc_hbm_traffic_c.json", False)
+    assert b.pmc_traffic_for(k8, 160, code="zzz")["stale"] is True
     (prof / "r09_z_pmc_hbm_traffic_d.json").write_text(json.dumps({"workload_key": k8, "code_id": "old", "traffic_bytes_per_scan": 3.0e8}))
-    assert b.pmc_traffic_for(k8, 160, code="abc") == (3.2e10, "r09_y_pmc_hbm_traffic_c.json", False)
-    assert len(b.code_id()) == 12
+    assert got(b.pmc_traffic_for(k8, 160, code="abc")) == (3.2e10, "r09_y_pmc_hbm_traffic_c.json", False)
+    assert len(b.code_id()) == 12 and b.code_id() == b.source_code_id()  # the in-tree library is built from the tree (csrc/Makefile CODE_ID)
+    # a per-scan summary speaks for a run of OTHER warm-up / step counts only through the executed-byte ratio
+    (prof / "r09_zz_pmc_hbm_traffic_e.json").write_text(json.dumps({"workload_key": k8, "code_id": "abc", "traffic_bytes_per_scan": 1.0e8,
+                                                                       "warmup": 5, "steps": 20, "executed_bytes_per_scan": 8.0e7}))
+    p = b.pmc_traffic_for(k8, 160, code="abc")
+    assert p["file"] == "r09_zz_pmc_hbm_traffic_e.json" and (p["warmup"], p["steps"]) == (5, 20)
+    assert b.pmc_for_this_run(p, 5, 20, 8.2e7) == ("same scans", 1.6e10)
+    how, nbytes = b.pmc_for_this_run(p, 10, 200, 7.2e7)
+    assert how == "scaled" and abs(nbytes - 1.6e10 * 0.9) < 1.0
+    assert b.pmc_for_this_run(p, 10, 200, None) == (None, None)  # nothing to scale by: the line keeps the executed model
+    assert b.pmc_for_this_run(dict(p, stale=True), 5, 20, 8.0e7) == (None, None)
+    old = b.pmc_traffic_for(lock16)  # per-launch kernels: the key itself carries the counts
+    assert b.pmc_for_this_run(old, 1, 2, None) == ("same scans", 1.0e9)
 
 
 def test_executed_byte_model_follows_the_loaded_build():

@@ -172,6 +172,35 @@ def test_fused_loop_body_equals_the_resident_run_and_the_call_by_call_loop(seq):
         assert np.abs(a["ekf"].nav.pos - b["ekf"].nav.pos).max() < 1e-9  # (the filter object is usable afterwards: state read on demand)
 
 
+def test_fused_loop_takes_any_number_of_imu_samples_between_two_scans(seq):
+    """A feed with a long IMU-only prefix / a 1 kHz IMU / dropped lidar frames: more samples between two scans than the filter's staging
+    buffer holds (1024).  The fused loop body must serve them like the call-by-call loop does (reference cli/ekf_bench.py:493-563 takes
+    any count) - the same filter state bit for bit (same kernel, same rows, chunked) - and stamp every held sample's `dt` the way
+    ESEKF.processImu does (es_ekf.py:194-196)."""
+    meta = SimpleNamespace(format=SimpleNamespace(columns_per_frame=seq.W, pixels_per_column=seq.H))
+    rng = np.random.default_rng(3)
+    n_pre = 2500
+    t0 = float(seq.imu[0, 0]) - n_pre * 0.001
+
+    def feed():
+        for i in range(n_pre):  # standing still for 2.5 s at 1 kHz before the first sweep
+            yield ("imu", IMU(np.array([0.0, 0.0, 9.78]) + 1e-3 * rng.standard_normal(3), 1e-4 * rng.standard_normal(3), t0 + 0.001 * i))
+        yield from sequence.synthetic_events(seq, 3)
+
+    rng = np.random.default_rng(3)
+    ev = list(feed())
+    a = sequence.run_events(iter(ev), meta, use_imu_prediction=True, fused=True)
+    dts_fused = [e[1].dt for e in ev if e[0] == "imu"]
+    b = sequence.run_events(iter(ev), meta, use_imu_prediction=True, fused=False)
+    dts_calls = [e[1].dt for e in ev if e[0] == "imu"]
+    assert dts_fused == dts_calls and dts_fused[0] == ev[0][1].ts and abs(dts_fused[5] - 0.001) < 1e-6
+    assert a["timings"]["n_imu"] == b["timings"]["n_imu"] == n_pre + 30 and a["timings"]["fused"] and not b["timings"]["fused"]
+    assert a["ekf"]._imu_idx == b["ekf"]._imu_idx and a["ekf"].ts == b["ekf"].ts
+    assert np.array_equal(np.array(a["res_t"]), np.array(b["res_t"]))
+    assert np.abs(np.array(a["res_poses"]) - np.array(b["res_poses"])).max() < 1e-9
+    assert np.abs(np.array(a["kiss_poses"]) - np.array(b["kiss_poses"])).max() < 1e-9
+
+
 def test_ouster_command_on_synthetic_writes_pose_files(tmp_path):
     fk, fn = tmp_path / "k.txt", tmp_path / "n.csv"
     res = CliRunner().invoke(ptudes_cli, ["ekf-bench", "ouster", "--synthetic", "1002", "--end-scan", "5",

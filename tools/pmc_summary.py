@@ -23,6 +23,11 @@ try:
     out["code_id"] = line["config"].get("code_id")  # the kernel sources the pass ran on (bench.py code_id)
     out["dominant_kernel"] = line["roofline"]["kernel"]
     out["bench_value_under_profiler"] = line["value"]
+    # the scans the pass covers: a free-running summary is per scan, and a scan's traffic depends on WHICH scans (the map grows, the
+    # iteration count falls) - bench.py takes the figure as it is only for the same warm-up and step counts and otherwise scales it by
+    # the ratio of executed bytes per scan between the two runs
+    out["warmup"], out["steps"] = line.get("warmup"), line.get("steps")
+    out["executed_bytes_per_scan"] = line["roofline"].get("executed_bytes_per_scan")
     n_timed = line["roofline"]["launches"] if line["roofline"]["kernel"] == "kx_seq_run" else line["steps"]
 except Exception as e:  # noqa: BLE001
     out["workload_key"] = None

@@ -1,0 +1,48 @@
+#!/bin/bash
+# Round 6's measurements on the GPU box (run through gpurun):   tools/round6_evidence.sh PART TAG   -> gpurun_out/TAG_*
+# Before, in the build container (the diagnostic builds travel with the snapshot; *.so is git-ignored):
+#   make -C ptudes-lab_amd/csrc OUT=$PWD/tools/variants/lib_phases.so PHASES=1 && make -C ptudes-lab_amd/csrc OUT=$PWD/tools/variants/lib_stages.so STAGES=1
+# T:  the GPU suite + smoke
+# C5: BASELINE config 5 measured like the default workload (none of this existed): phase clocks of the Gauss-Newton
+#     loop, stage clocks, SQ and L2 counters - 160 dense sequences on teams of 4
+# D:  the default workload's line (driver's command), kernel stats, dispatches, HBM counters, 200 steps
+# B5: config 5's line, kernel stats, dispatches, HBM counters
+R="${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it)}"
+PART="${1:?T, C5, D or B5}"; TAG="${2:-r06_a}"
+O="$R/gpurun_out"; mkdir -p "$O"; V="$R/tools/variants"
+cd "$R"
+C5="--seqs-per-gpu 160 --team-wgs 4 --rows 64 --cols 2048 --max-range 100 --voxel-size 0.1 --steps 40 --warmup 20 --map-blocks 600000 --map-small-blocks 2200000 --map-table 33554432 --workload-name config5 --no-single-sequence"
+case "$PART" in
+T)
+  timeout 3000 python3 -m pytest tests -m gpu -x -q --durations=5 > "$O/${TAG}_pytest.txt" 2>&1; echo "pytest rc $?" >> "$O/${TAG}_pytest.txt"; tail -4 "$O/${TAG}_pytest.txt"
+  python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a "$O/${TAG}_pytest.txt"
+  ;;
+C5)
+  PTL_TOOL_WORKLOAD=config5 PTL_LIB_PATH="$V/lib_phases.so" timeout 900 python3 tools/phase_batch.py 160 4 60 > "$O/${TAG}_config5_gn_phase_clocks.txt" 2>&1; tail -3 "$O/${TAG}_config5_gn_phase_clocks.txt" | cut -c1-400
+  PTL_TOOL_WORKLOAD=config5 PTL_LIB_PATH="$V/lib_stages.so" timeout 900 python3 tools/stage_clocks.py 160 4 60 > "$O/${TAG}_config5_stage_clocks_teams_of_4.txt" 2>&1; tail -3 "$O/${TAG}_config5_stage_clocks_teams_of_4.txt" | cut -c1-400
+  timeout 1500 bash tools/pmc_sq.sh kx_seq_run $C5 > "$O/${TAG}_config5_sq_counters_kx_seq_run.txt" 2>&1; cat "$O/${TAG}_config5_sq_counters_kx_seq_run.txt"
+  { timeout 600 bash tools/pmc_any.sh kx_seq_run "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" --repeats 1 $C5; timeout 600 bash tools/pmc_any.sh kx_seq_run "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum" --repeats 1 $C5; } > "$O/${TAG}_config5_l2_counters_kx_seq_run.txt" 2>&1; cat "$O/${TAG}_config5_l2_counters_kx_seq_run.txt"
+  ;;
+D)
+  bash tools/profile_round.sh "$TAG" --gpus 1 --steps 20 --warmup 5 > "$O/${TAG}_prof.txt" 2>&1; tail -2 "$O/${TAG}_prof.txt" | cut -c1-300
+  cp "$O/${TAG}_pmc_hbm_traffic.json" "$R/profiles/"   # (on the box: the line below finds this build's counter pass)
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$O/${TAG}_bench_with_counters.json" 2> "$O/${TAG}_bench_with_counters.err"
+  python3 bench.py --steps 200 --warmup 20 > "$O/${TAG}_bench_200steps.json" 2> "$O/${TAG}_bench_200steps.err"
+  ;;
+B5)
+  bash tools/profile_round.sh "${TAG}_config5" $C5 > "$O/${TAG}_config5_prof.txt" 2>&1; tail -2 "$O/${TAG}_config5_prof.txt" | cut -c1-300
+  cp "$O/${TAG}_config5_pmc_hbm_traffic.json" "$R/profiles/"
+  python3 bench.py $C5 --cpu-budget 20 > "$O/${TAG}_config5_bench_with_counters.json" 2> "$O/${TAG}_config5_bench_with_counters.err"
+  ;;
+esac
+python3 - "$O" "$TAG" <<'PY'
+import glob, json, sys
+O, T = sys.argv[1:3]
+for f in sorted(glob.glob(f"{O}/{T}_*bench*.json")):
+    try:
+        d = json.load(open(f)); r = d["roofline"]
+        print(f.split("/")[-1], round(d["value"], 1), "frac", round(r["frac"], 3), "stale", r["traffic_stale"], "exec", r["executed_frac"] and round(r["executed_frac"], 3),
+              "MB/scan", r["traffic"] and round(r["traffic"] / r["scans_per_launch"] / 1e6, 1), d.get("parity_vs_oracle"), [round(x) for x in (d.get("sequence_phases_us_per_scan") or {"mean": []})["mean"]])
+    except Exception as e:
+        print(f, "failed", e)
+PY

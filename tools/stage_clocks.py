@@ -15,10 +15,17 @@ from ptudes_lab_amd import _lib as L, core, synth  # noqa: E402
 
 S, G = int(sys.argv[1]), int(sys.argv[2])
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+# PTL_TOOL_WORKLOAD=config5: BASELINE config 5 (64 x 2048 sweeps, 0.1 m voxels, 100 m range, two block classes) instead of the default workload
+if os.environ.get("PTL_TOOL_WORKLOAD") == "config5":
+    SEQ_KW = dict(H=64, W=2048, max_range=100.0)
+    RUN_KW = dict(max_range=100.0, voxel_size=0.1, scan_cols=2048, map_block_capacity=600000, map_small_blocks=2200000, map_table_capacity=1 << 25)
+    RUN_KW.update({k[4:].lower(): int(v) for k, v in os.environ.items() if k.startswith("PTL_KW_")})  # e.g. PTL_KW_MAP_TABLE_CAPACITY=...
+else:
+    SEQ_KW, RUN_KW = {}, {}
 W = 10
-seqs = [synth.make_sequence(seed=1000 + s, n_scans=n) for s in range(S)]
+seqs = [synth.make_sequence(seed=1000 + s, n_scans=n, **SEQ_KW) for s in range(S)]
 n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
-b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=True, with_ekf=True, team_workgroups=G)
+b = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, use_imu_prediction=True, with_ekf=True, team_workgroups=G, **RUN_KW)
 for s, sq in enumerate(seqs):
     for k in range(n):
         b.upload_scan(s, k, sq.scan(k))
