@@ -355,6 +355,8 @@ def workload_key(args, S):
             f"{'cv' if args.const_velocity else 'imu'}"
             f"{'' if not args.icp_only else '_icponly'}{'' if not args.gn_lanes else '_L%d' % args.gn_lanes}"
             f"{'' if not getattr(args, 'map_small_blocks', 0) else '_sb%d' % args.map_small_blocks}"
+            f"{'' if not getattr(args, 'range_input', False) else '_range'}"
+            f"{'' if not getattr(args, 'ray_jitter_deg', 0.0) else '_jit%g' % args.ray_jitter_deg}"
             + (f"_free_g{getattr(args, 'gn_wgs', 0) or 256}x{getattr(args, 'gn_threads', 0) or 512}_t{getattr(args, 'team_wgs', 0)}" if free else ""))
 
 
@@ -366,6 +368,33 @@ def default_team_wgs(S):
 def free_running(args, S):
     """does this run use the free-running batch driver (one persistent launch, every sequence at its own pace)?"""
     return S > 1 and not args.lockstep and args.gn_lanes in (0, 8)
+
+
+class RangeFeed:
+    """A synth.Sequence seen through its range images (--range-input): `range_image(k)` = the sweep as the sensor reports it (u32
+    millimetres per pixel, 0 = no return: reference kiss.py:59-61 works on such a scan), `scan(k)` = the points the device LUT makes of
+    it (ptl_lut_apply: exactly what K1 computes) - what the oracle and the CPU baseline are fed, so both sides see the same points.
+    The synthetic sensor counts its columns counter-clockwise (column j looks along 2 pi j / W and fires at j / W of the sweep); an
+    Ouster counts clockwise (XYZLut: 2 pi (1 - v / W)), so the LUT gets a lidar_to_sensor that mirrors y - pixel column v is then
+    synthetic column v, and the per-column times of the deskew (kiss.py:34-35) are the firing times."""
+
+    def __init__(self, sq, lut):
+        self._sq, self._lut = sq, lut
+
+    def __getattr__(self, name):
+        return getattr(self._sq, name)
+
+    def range_image(self, k):
+        x = np.asarray(self._sq.scan(k), dtype=np.float64)
+        return np.round(np.sqrt((x * x).sum(axis=1)) * 1000.0).astype(np.uint32)
+
+    def scan(self, k):
+        return self._lut(self.range_image(k))
+
+
+def synthetic_lut(core, rows, cols, device_id=0):
+    l2s = np.diag([1.0, -1.0, 1.0, 1.0])
+    return core.Lut(rows, cols, np.linspace(45.0, -45.0, rows), np.zeros(rows), 0.0, l2s, None, device_id=device_id)
 
 
 def main():
@@ -410,6 +439,13 @@ def main():
     ap.add_argument("--map-table", type=int, default=0, help="map hash-table slots (power of two)")
     ap.add_argument("--map-small-blocks", type=int, default=0, help="small (128-byte, 5-point) voxel blocks beside the --map-blocks full ones: sparse maps (config 5)")
     ap.add_argument("--rebuild-every", type=int, default=0, help="scans between two rebuilds of the map hash table (tombstones dropped; 0 = library default)")
+    ap.add_argument("--range-input", action="store_true",
+                    help="sweeps enter as raw range images (SURVEY.md 8(f) rank 1: 512 KB of u32 millimetres per 128x1024 sweep instead of 1.57 MB of "
+                         "float32 xyz; reference kiss.py:28-29, 59-61) and stay range images in HBM: 240 sequences x 1 000 sweeps fit (126 GB). "
+                         "The LUT is the synthetic sensor's; oracle and CPU baseline get the same points through the numpy restatement of the LUT")
+    ap.add_argument("--ray-jitter-deg", type=float, default=0.0,
+                    help="per-ray angular jitter of the synthetic sensor (takes the sampling lattice away: 21-28 Gauss-Newton iterations per scan "
+                         "instead of 35-40, DESIGN.md 6) - the stage-bound regime; part of the workload key")
     ap.add_argument("--workload-name", type=str, default="")
     ap.add_argument("--device", type=int, default=-1, help="GPU index for this rank (default LOCAL_RANK %% visible devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -488,16 +524,31 @@ def main():
 
     def make_seq(j, s):
         return synth.make_sequence(seed=args.seed_base + s, n_scans=(n_cpu if j == 0 else n_total), H=args.rows, W=args.cols,
-                                   min_range=args.min_range, max_range=args.max_range)
+                                   min_range=args.min_range, max_range=args.max_range, ray_jitter_deg=args.ray_jitter_deg)
+    lut = synthetic_lut(core, args.rows, args.cols, local_rank) if args.range_input else None
+    if lut is not None:
+        _make = make_seq
+
+        def make_seq(j, s):  # noqa: F811
+            return RangeFeed(_make(j, s), lut)
     seq0 = make_seq(0, 0 if args.equal_work else rank)
     n_imu = seq0.imu_range_for_scan(n_total - 1)[1] if with_ekf else 0
+
+    def feed_sweep(r, k, sq, j=None):
+        """sweep k of sq into runner r (a batch takes the sequence slot j)"""
+        if lut is not None:
+            r.upload_range(*(() if j is None else (j,)), k, sq.range_image(k))
+        else:
+            r.upload_scan(*(() if j is None else (j,)), k, sq.scan(k))
     # S == 1: the single-sequence runner (its Gauss-Newton kernel caches hash probes across iterations);
     # S > 1: all sequences of this rank advance in lockstep in one batched runner (one launch per stage for all)
     class _One:
         def __init__(self):
             self.r = core.SeqRunner(n_total, pps, n_imu, max_range=args.max_range, min_range=args.min_range,
                                     use_imu_prediction=use_imu, with_ekf=with_ekf, device_id=local_rank, **icp_over)
+            if lut is not None: self.r.set_lut(lut)
         def upload_scan(self, j, k, x): self.r.upload_scan(k, x)
+        def upload_range(self, j, k, x): self.r.upload_range(k, x)
         def upload_imu(self, j, rows, ends): self.r.upload_imu(rows, ends)
         def run(self, n): self.r.run(n)
         def enqueue(self, n): self.r.enqueue(n)
@@ -514,7 +565,10 @@ def main():
                                                             min_range=args.min_range, use_imu_prediction=use_imu,
                                                             with_ekf=with_ekf, device_id=local_rank, free_running=free,
                                                             scans_per_launch=args.scans_per_launch,
-                                                            team_workgroups=args.team_wgs if free else 0, **icp_over)
+                                                            team_workgroups=args.team_wgs if free else 0,
+                                                            range_input=lut is not None, **icp_over)
+            if S > 1 and lut is not None:
+                runner.set_lut(lut)
             break
         except RuntimeError as e:
             # the DEFAULT sequence count is sized for the 288 GB of an MI355X (about 0.8 GB per sequence): on a part with less memory -
@@ -533,9 +587,12 @@ def main():
     for j, sq in enumerate(seqs):
         for k in range(n_total):
             ta = time.perf_counter()
-            x = sq.scan(k)
+            x = sq.range_image(k) if lut is not None else sq.scan(k)
             tb = time.perf_counter()
-            runner.upload_scan(j, k, x)
+            if lut is not None:
+                runner.upload_range(j, k, x)
+            else:
+                runner.upload_scan(j, k, x)
             t_render += tb - ta
             t_upload += time.perf_counter() - tb
         runner.upload_imu(j, sq.imu[:n_imu] if with_ekf else np.zeros((0, 7)),
@@ -780,6 +837,8 @@ def main():
                         "note": "each repeat = cold start + W untimed warm-up sweeps + exactly K timed steps (barrier + synchronize on both sides)"},
             "config": {"workload": f"synthetic {args.rows}x{args.cols} sweeps, random-walk SE(3) GT, {mode_txt}, "
                                    f"min/max range {args.min_range}/{args.max_range} m, voxel {(args.voxel_size or args.max_range / 100):.2f} m"
+                                   + (", sweeps as raw range images (u32 mm per pixel, 4 resident bytes per pixel; LUT on device)" if args.range_input else "")
+                                   + (f", ray pattern jittered by +-{args.ray_jitter_deg:g} deg per ray and sweep" if args.ray_jitter_deg else "")
                                    + (f" [{args.workload_name}]" if args.workload_name else ""),
                        "workload_key": wkey, "code_id": cid,
                        "library_built_from_this_source_tree": cid == source_code_id(),  # false: an experiment build (flags) or a stale .so
@@ -844,8 +903,10 @@ def main():
                                      with_ekf=with_ekf, device_id=local_rank,
                                      **dict({k: v for k, v in icp_over.items() if k != "map_small_blocks"}, gn_workgroups=team_g, gn_lanes_per_point=8, gn_threads=args.gn_threads or 512,
                                             map_block_capacity=icp_over.get("map_block_capacity", 1 << 19) + icp_over.get("map_small_blocks", 0)))
+                if lut is not None:
+                    one.set_lut(lut)
                 for k in range(n_total):
-                    one.upload_scan(k, seqs[j].scan(k))
+                    feed_sweep(one, k, seqs[j])
                 one.upload_imu(seqs[j].imu[:n_imu] if with_ekf else np.zeros((0, 7)),
                                [seqs[j].imu_range_for_scan(k)[1] if with_ekf else 0 for k in range(n_total)])
                 one.run(n_total)
@@ -861,8 +922,10 @@ def main():
             one = core.SeqRunner(n_total, pps, n_imu, max_range=args.max_range, min_range=args.min_range,
                                  use_imu_prediction=use_imu, with_ekf=with_ekf, device_id=local_rank,
                                  **{k: v for k, v in icp_over.items() if k not in ("gn_lanes_per_point", "gn_threads", "gn_workgroups", "map_small_blocks")})
+            if lut is not None:
+                one.set_lut(lut)
             for k in range(n_total):
-                one.upload_scan(k, sq.scan(k))
+                feed_sweep(one, k, sq)
             one.upload_imu(sq.imu[:n_imu] if with_ekf else np.zeros((0, 7)),
                            [sq.imu_range_for_scan(k)[1] if with_ekf else 0 for k in range(n_total)])
             one.run(W)

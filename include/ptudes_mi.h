@@ -261,6 +261,11 @@ typedef struct {
     int64_t n_imu;
     int32_t use_imu_prediction; /* ekf_bench.py:533-535 */
     int32_t with_ekf;           /* 0 => ICP only (BASELINE config 2) */
+    int32_t range_input;        /* batches: 1 => every sweep arrives as a raw range image (ptl_batch_set_lut + ptl_batch_upload_range) and is KEPT as
+                                 * one: 4 resident bytes per pixel instead of the 12 of a float32 xyz sweep - 240 sequences x 1 000 sweeps of 128x1024 are
+                                 * 126 GB instead of 377 GB (the reference walks a recording of any length, data.py:31-77).  ptl_batch_upload_scan is then
+                                 * refused.  0 (default): 12-byte slots, either form may be uploaded.  Ignored by ptl_seq_create. */
+    int32_t reserved0;
 } ptl_seq_cfg;
 
 int ptl_seq_create(const ptl_seq_cfg *cfg, ptl_seq **out);
@@ -355,8 +360,10 @@ int ptl_batch_team_workgroups(ptl_batch *b, int32_t *team_workgroups, int32_t *t
 /* Executed-work counters of sequence `seq`, cumulative since the cold start - what the kernels requested from memory, as
  * opposed to the brute-force counts of ptl_icp_stats: [0] full 27-voxel searches (points the answer cache did not
  * settle), [1] probe rows rebuilt (27 hash probes each), [2] stored map points read by the searches, [3] Gauss-Newton
- * iterations, [4] / [5] voxel claims of down-sampling pass 1 / 2, [6] source point-iterations, [7] scans. */
-int ptl_batch_exec_counters(ptl_batch *b, int32_t seq, uint64_t out[8]);
+ * iterations, [4] / [5] voxel claims of down-sampling pass 1 / 2, [6] source point-iterations, [7] scans, [8] point-iterations settled as
+ * "nothing in reach" (the point's last search found its 27 voxels empty and it has not left its voxel: neither a row evaluation nor a
+ * search - exact, the map does not change inside a registration), [9..15] reserved (0). */
+int ptl_batch_exec_counters(ptl_batch *b, int32_t seq, uint64_t out[16]);
 /* Where the scans of sequence `seq` ran in the free-running kernel, cumulative since the cold start: out[0] scans run by a
  * team of another XCD than the sequence's home XCD (seq & 7) - a team whose own XCD had nothing for it; out[1] scans that
  * ran on another XCD than the sequence's previous scan (the cross-XCD hand-overs: the previous scan's data sits in another
@@ -393,7 +400,7 @@ int ptl_batch_debug_set_map_points_per_thread(ptl_batch *b, int32_t points, int3
  * and pass of K1 + map update / K2-K4 in the free-running kernel, [5] threads per workgroup of the 8-lane kernels,
  * [6] lanes per point of the full search, [7] nearest other boxes in its first round, [8] voxels per survivor round,
  * [9] chunks phase A requests ahead, [10] 1000 x the pruning margin, [11] / [12] bytes per map-table / voxel-table
- * entry, [13] 1 when diagnostic clocks are compiled in, [14] 1 for a build of the movement-budget experiment (make EXTRA=-DGN8_FAST=1; off in the product). */
+ * entry, [13] 1 when diagnostic clocks are compiled in, [14] reserved (0; rounds 5's movement-budget experiment is gone from the sources). */
 int ptl_build_info(int32_t out[16]);
 /* identity of what THIS library was built from: sha256 over the kernel sources, the Makefile and the experiment flags (12 hex digits,
  * csrc/Makefile CODE_ID).  bench.py records it in its line and tools/pmc_summary.py in every counter summary: a counter pass speaks

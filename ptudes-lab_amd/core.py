@@ -393,8 +393,11 @@ class BatchRunner:
 
     def __init__(self, n_sequences, n_scans, points_per_scan, n_imu, *, max_range=70.0, min_range=1.0,
                  use_imu_prediction=False, with_ekf=True, device_id=0, ekf=None, free_running=None, scans_per_launch=0,
-                 team_workgroups=0, **icp_over):
+                 team_workgroups=0, range_input=False, **icp_over):
+        """range_input: every sweep will arrive as a raw range image (set_lut + upload_range) and stays one in HBM - 4 bytes per pixel
+        resident instead of 12 (include/ptudes_mi.h ptl_seq_cfg.range_input)"""
         cfg = L.SeqCfg()
+        cfg.range_input = int(bool(range_input))
         icp_over.setdefault("gn_lanes_per_point", 8)  # a workgroup walks ~200 points per iteration here: the throughput form
         if icp_over["gn_lanes_per_point"] == 8:
             icp_over.setdefault("gn_threads", 512)
@@ -427,11 +430,11 @@ class BatchRunner:
         return g.value, t.value
 
     EXEC_COUNTERS = ("searches", "rows_rebuilt", "map_points_read", "gn_iterations", "vds1_claims", "vds2_claims",
-                     "point_iterations", "scans")
+                     "point_iterations", "scans", "settled_nothing_in_reach")
 
     def exec_counters(self, s):
         """executed-work counters of sequence s, cumulative since the cold start (include/ptudes_mi.h ptl_batch_exec_counters)"""
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         L.check(L.lib().ptl_batch_exec_counters(self._h, s, out))
         return dict(zip(self.EXEC_COUNTERS, (int(v) for v in out)))
 

@@ -108,9 +108,9 @@ struct DevState {
     // free-running kernel, cumulative since the cold start (ptl_batch_sched_counters): [0] scans run by a team of another XCD than the
     // sequence's home XCD, [1] scans that ran on another XCD than the scan before (cross-XCD hand-overs), [2] XCC id of the last scan + 1
     unsigned long long sched_cnt[4];
-    // 8-lane Gauss-Newton loop, cumulative like exec_cnt: [0] point-iterations settled WITHOUT their answer row (24 bytes of pc_t1 instead of
-    // the 144-byte row), [1] budgets set (24 bytes of pc_t1 written)
-    unsigned long long fast_cnt[2];
+    // 8-lane Gauss-Newton loop, cumulative like exec_cnt: point-iterations settled as "nothing in reach" (the point's last search found its 27
+    // voxels empty and it has not left its voxel since: no row evaluation, no search)
+    unsigned long long empty_cnt;
 };
 
 struct Ctx {
@@ -157,7 +157,6 @@ struct Ctx {
     const double* ext_guess;  // device 4x4 or null
     unsigned long long* pc_key;  // [n_max]      multi-pass probe cache: voxel key of source point i at its last probe
     int* pc_pb;                  // [n_max][32]  and the 27 probe results (block id | count << 24, -1 = absent)
-    double* pc_t1;               // [n_max][3]  8-lane kernel: the correspondence of a point whose answer row needs no look (GN8_FAST, gn8_body)
     double* pc_ans;              // [n_max][GN8_ANS_ROW]  8-lane kernel: exact answer cache (s0 | the K nearest candidates | distance bound of the others | order ids, counts)
     unsigned long long* gn_rows_ll;  // [2][G][64]      per-workgroup sums as (32 data bits | 32 flag bits) words
     unsigned long long* gn_xsum_ll;  // [2][8][8][64]   per-group sums, one copy per consumer slot
@@ -1660,6 +1659,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void k_gn_loop(Ctx c, int mode) {
 #define GN8_ANS_ROW ((3 + 3 * GN8_KCAND + 3 + 1) & ~1)  /* doubles per answer row: s0 (3) | the K nearest candidates (3 each) | bound | ids, counts (packed) | voxel key of s0 [| pad]
                                                           (K = 4: 18 doubles = 144 B as before - the key sits where the padding was, and phase A no longer reads pc_key[]) */
 #define GN8_ANS_D (3 + 3 * GN8_KCAND)
+#define GN8_NOTHING_IN_REACH (-2.0)  /* bound slot of an answer row: the search found the point's 27 voxels empty (gn8_search -> phase A of gn8_body) */
 #ifndef GN8_SPEC
 #define GN8_SPEC 2            /* how many of the nearest other boxes the first search round takes along, their loads in flight with the own voxel's (0 .. 3; make SPEC=n) */
 #endif
@@ -1985,6 +1985,7 @@ __device__ __forceinline__ void gn8_search(const Ctx& c, int i, int it, V3 s, do
     double sl2 = -1.0;
     if (found && D2 < 1.0e300) sl2 = sqrt(D2) * (1.0 - 1e-6) - 1e-9;  // (a little less is stored: the margin of the test)
     else if (found) sl2 = 1.0e300;  // nobody else in reach of this voxel
+    else if (ctot == 0) sl2 = GN8_NOTHING_IN_REACH;  // the 27 voxels around this key hold no point at all: true for as long as the point keeps the voxel
     if (laneL == 0) {  // s0 | ... | bound | order ids (10 bits each), candidate count of the 27 voxels, candidates in the row
         arow[0] = s.x; arow[1] = s.y; arow[2] = s.z;
         arow[GN8_ANS_D] = sl2;
@@ -2026,9 +2027,7 @@ __device__ __forceinline__ double sums_from_moments(int e, const double* M) {
 }
 
 #define GN8_ROW_ENTRIES 18   /* 16 moments, pair count, candidate count */
-#ifndef GN8_PREFETCH
-#define GN8_PREFETCH 1        /* chunks phase A requests ahead (1 or 2; make PF=2) */
-#endif
+#define GN8_PREFETCH 1        /* chunks phase A requests ahead (ptl_build_info) */
 #ifndef GN8_LDS_PTS
 #define GN8_LDS_PTS (6 * 512) /* source-point positions a workgroup keeps in LDS (72 KB) */
 #endif
@@ -2073,9 +2072,7 @@ struct Gn8Pre {
 };
 // want_pos: the point's previous position comes from memory (the scan's first iteration: src0; later: src_cur for the points
 // that do not fit the workgroup's LDS copy, gn8_body)
-// fast: the point's answer row needs no look this iteration (its movement budget lasts, gn8_body): only its correspondence is fetched -
-// 24 bytes of pc_t1 into the row's first three slots instead of the 144-byte row
-__device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, bool first, bool want_pos, bool fast = false) {
+__device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, bool first, bool want_pos) {
     Gn8Pre p;
     p.px = p.py = p.pz = 0.0; p.key = EMPTY_KEY;
 #pragma unroll
@@ -2083,10 +2080,7 @@ __device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, b
     if (valid) {
         const double* sp0 = first ? c.src0 : c.src_cur;
         if (want_pos) { p.px = sp0[3 * (size_t)i]; p.py = sp0[3 * (size_t)i + 1]; p.pz = sp0[3 * (size_t)i + 2]; }
-        if (fast) {
-            const double* t1 = c.pc_t1 + 3 * (size_t)i;
-            p.r[0].x = t1[0]; p.r[0].y = t1[1]; p.r[1].x = t1[2];
-        } else if (!first) {  // (the voxel key of the row's s0 travels in the row: no separate read of pc_key[])
+        if (!first) {  // (the voxel key of the row's s0 travels in the row: no separate read of pc_key[])
             const double2* row = (const double2*)(c.pc_ans + GN8_ANS_ROW * (size_t)i);
 #pragma unroll
             for (int k = 0; k < GN8_ANS_ROW / 2; ++k) p.r[k] = row[k];
@@ -2096,15 +2090,6 @@ __device__ __forceinline__ Gn8Pre gn8_preload(const Ctx& c, int i, bool valid, b
     }
     return p;
 }
-#ifndef GN8_FAST
-#define GN8_FAST 0  /* make EXTRA=-DGN8_FAST=1 (needs GN8_PREFETCH == 1): movement budgets in LDS - a point whose last row evaluation left room
-                       (bound, runner-up, voxel faces) is settled from 24 bytes of pc_t1 until its path since then has used the room up.  Exact
-                       (37 batch / parity / hand-over tests green), 17 % fewer executed bytes per scan (81.9 -> 67.6 MB: half of the later
-                       point-iterations skip their 144-byte row), and 9.6 % SLOWER (40.26 k -> 36.4 k scans/s, Gauss-Newton 2 290 -> 2 621 us
-                       per scan, two same-box pairs; config 5: 2 089 -> 2 077): the rows are streamed a chunk ahead and cost bandwidth the
-                       loop has to spare, the budget's arithmetic (advance, fill, a second evaluation path every wavefront walks as well)
-                       costs issue slots phase A does not have.  Off; profiles/r05_c_experiments_not_kept.txt */
-#endif
 template <int PC, int GC>
 __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_rt, const int wg) {
     // the base pointers of the loop's arrays in scalar registers (the free-running kernel's accesses are flat_*: left alone, each
@@ -2112,7 +2097,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
     Ctx c = c_in;
     c.pc_ans = uniform_ptr(c.pc_ans); c.pc_key = uniform_ptr(c.pc_key); c.pc_pb = uniform_ptr(c.pc_pb);
     c.tab = uniform_ptr(c.tab); c.blocks = uniform_ptr(c.blocks);
-    c.src0 = uniform_ptr(c.src0); c.src_cur = uniform_ptr(c.src_cur); c.pc_t1 = uniform_ptr(c.pc_t1);
+    c.src0 = uniform_ptr(c.src0); c.src_cur = uniform_ptr(c.src_cur);
     c.gn_rows_ll = uniform_ptr(c.gn_rows_ll);
     const int G = GC > 0 ? GC : G_rt;
     __shared__ int2 missq[(GN8_MAX_THREADS / 64) * GN8_QWAVE];  // points whose answer row did not settle them: (index, slot of its position in posL or -1)
@@ -2125,27 +2110,16 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
     __shared__ double Tsh[12];
     __shared__ int flag_done2[2];
     __shared__ long long cand_total_sh;
-    __shared__ unsigned xcnt[6];  // executed-work counters of this workgroup and scan: searches | rows rebuilt | stored points read | - | settled without a row | budgets set
+    __shared__ unsigned xcnt[4];  // executed-work counters of this workgroup and scan: searches | rows rebuilt | stored points read | points settled as 'nothing in reach'
     // The current positions of the workgroup's source points live in LDS for the whole loop (every iteration moves every point:
     // 24 B read + 24 B written per point-iteration otherwise, a sixth of the loop's memory traffic): chunk q of the workgroup
     // (blockDim points) at [q blockDim, (q + 1) blockDim).  Chunks beyond the array (a team of 2 on a scan of > 6144 source
     // points) keep theirs in src_cur.
     __shared__ double posL[3][GN8_LDS_PTS];
-    // Movement budgets (round 5).  When the row of a point is evaluated and settles it, the evaluation also says how far the point may
-    // still move before anything about that answer can change: half the room left in the row's test (bound - distance - displacement),
-    // half the lead of the winner over the row's runner-up, the distance to the nearest face of its voxel.  While the PATH the point
-    // has travelled since stays below that, a look at the row would settle it again, with the same winner, in the same voxel
-    // (triangle inequality on every term): the iteration fetches the 24 bytes of the winner (pc_t1) instead of the 144-byte row.
-    // The decision needs the budget (here) and this iteration's step (positions are in LDS) only, so it is made BEFORE the loads of a
-    // chunk are requested - one load per lane either way, no second pass (round 4's two-tier rows failed on that).  budL <= 0: look.
-    // (GN8_FAST, off by default: measured slower - see the switch)
-    __shared__ float budL[GN8_FAST ? GN8_LDS_PTS : 1];
-    __shared__ unsigned short ctotL[GN8_FAST ? GN8_LDS_PTS : 1];  // candidate count of the point's 27 voxels (what a settled point adds to sum C_i)
     DevState* st = c.st;
     const int tid = threadIdx.x;
     const int NT = blockDim.x, NG32 = blockDim.x >> 5, NW = blockDim.x >> 6;
-    if (tid < 6) xcnt[tid] = 0u;
-    if (GN8_FAST) for (int k = tid; k < GN8_LDS_PTS; k += (int)blockDim.x) budL[k] = -1.0f;  // (no budget: the first look at a row sets one)
+    if (tid < 4) xcnt[tid] = 0u;
     const int n = __builtin_amdgcn_readfirstlane(st->n_src);
     const unsigned epoch = (unsigned)__builtin_amdgcn_readfirstlane((int)st->gn_epoch);
     if (wg == 0 && tid == 0 && mode == 0) flush_map_stats(c, st);
@@ -2192,34 +2166,13 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
     int tl = tid;
     auto chunk_point = [&](int qb, int& i) -> bool { const int q = qb + (tl >> 6); i = ((q * G + wg) << 6) + (tl & 63); return q < my_blocks && i < n; };
     auto pos_in_lds = [&](int qb) -> bool { return (qb / NW + 1) * NT <= GN8_LDS_PTS; };
-    // (two chunks ahead, GN8_PREFETCH = 2: tried - no faster, the loop got 3 % slower)
-    // chunks whose points carry a movement budget: positions in LDS, and not an iteration's first chunk (its loads are requested
-    // before the iteration's increment exists - the budget could not be advanced in time)
-    auto budgeted = [&](int qb) -> bool { return GN8_FAST != 0 && qb >= NW && pos_in_lds(qb); };
+    // (two chunks ahead - make PF=2 of rounds 3-5 - was no faster: the second row buffer spills; profiles/r03_b_geometry_and_variants.txt)
     auto preload_chunk = [&](int qb, bool first) -> Gn8Pre {
         int i2;
         const bool v2 = chunk_point(qb, i2);
-        const bool fast2 = GN8_FAST != 0 && !first && v2 && budgeted(qb) && budL[GN8_FAST ? (qb / NW) * NT + tl : 0] > 0.0f;
-        return gn8_preload(c, i2, v2, first, first || !pos_in_lds(qb), fast2);
-    };
-    // once per chunk and iteration, before the chunk's loads are requested: the budget pays for this iteration's step
-    // (|E p - p|, rounded up in single precision); what is left decides between the 24-byte and the 144-byte load
-    auto advance_budgets = [&](int qb, const double* Ecur) {
-        int i2;
-        if (!GN8_FAST || !budgeted(qb) || !chunk_point(qb, i2)) return;
-        const int li2 = GN8_FAST ? (qb / NW) * NT + tl : 0;
-        const float b = budL[li2];
-        if (!(b > 0.0f)) return;
-        const double px = posL[0][li2], py = posL[1][li2], pz = posL[2][li2];
-        const double dx = (Ecur[0] * px + Ecur[1] * py + Ecur[2] * pz + Ecur[9]) - px;
-        const double dy = (Ecur[3] * px + Ecur[4] * py + Ecur[5] * pz + Ecur[10]) - py;
-        const double dz = (Ecur[6] * px + Ecur[7] * py + Ecur[8] * pz + Ecur[11]) - pz;
-        const float st2 = __double2float_ru((dx * dx + dy * dy + dz * dz) * (1.0 + 1e-9));  // (the position itself is formed a little differently: a relative 1e-9 covers it)
-        budL[li2] = b - (sqrtf(st2) * 1.000001f + 1e-9f);  // (the root within an ulp, the product and the difference within half an ulp each: 1e-6 relative covers them)
+        return gn8_preload(c, i2, v2, first, first || !pos_in_lds(qb));
     };
     Gn8Pre pre = preload_chunk(0, true);
-    [[maybe_unused]] Gn8Pre pre2 = pre;
-    if (GN8_PREFETCH > 1) pre2 = preload_chunk(NW, true);
     for (int it = 0; it < c.max_iter; ++it) {
         asm volatile("" : "+v"(tl));
         [[maybe_unused]] const int lane32 = tl & 31, grp32 = tl >> 5;
@@ -2230,9 +2183,10 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
 #pragma unroll
         for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] = 0.0;
         int nq = 0, nqr = 0;  // this WAVEFRONT's queued points: row valid (from the front of its region) | row to be rebuilt (from the back)
-        int nfast = 0, nfill = 0;  // this lane: point-iterations settled without their row | budgets set
+        int nemp = 0;         // this WAVEFRONT's points settled as "nothing in reach" in this iteration
         for (int qb = 0; qb < my_blocks; qb += NW) {
             int missA = -1;  // this lane's point of phase A when the answer row did not settle it
+            int nempty = 0;  // ... 1 when it was settled as "nothing in reach" (executed-work counter)
             bool rebA = true;  // ... and whether its probe row has to be rebuilt (first iteration, or the point changed voxel)
             int liA = -1;      // ... and where its position lives: slot in posL, or -1 = src_cur
 #ifdef GN_PHASE_CLOCKS
@@ -2254,16 +2208,9 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
                 int i;
                 const bool valid = chunk_point(qb, i);
                 const Gn8Pre cur = pre;
-                // was this lane's point loaded the short way?  (decided when the chunk's loads were requested: advance_budgets; the
-                // budget is not touched again before this point)
                 const bool lds = pos_in_lds(qb);
                 const int li = (qb / NW) * NT + tl;
-                const bool fastA = GN8_FAST != 0 && valid && it > 0 && budgeted(qb) && budL[GN8_FAST ? li : 0] > 0.0f;
-                if (GN8_FAST && qb + NW < my_blocks && it > 0) advance_budgets(qb + NW, Esh);
-                if (GN8_PREFETCH > 1) {
-                    pre = pre2;
-                    if (qb + 2 * NW < my_blocks) pre2 = preload_chunk(qb + 2 * NW, it == 0);  // in flight while this chunk and the next are evaluated
-                } else if (qb + NW < my_blocks) pre = preload_chunk(qb + NW, it == 0);
+                if (qb + NW < my_blocks) pre = preload_chunk(qb + NW, it == 0);  // in flight while this chunk is evaluated
                 int miss = -1;
                 if (valid) {
                     Rt E;
@@ -2274,18 +2221,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
                     if (lds) { posL[0][li] = s.x; posL[1][li] = s.y; posL[2][li] = s.z; liA = li; }
                     else { c.src_cur[3 * (size_t)i] = s.x; c.src_cur[3 * (size_t)i + 1] = s.y; c.src_cur[3 * (size_t)i + 2] = s.z; }
                     miss = i;
-                    if (fastA) {
-                        // the budget lasts: a look at the row would settle the point with this very candidate (the expression below is the
-                        // one the row's evaluation and the search form for it), in the same voxel
-                        const V3 t = v3(cur.r[0].x, cur.r[0].y, cur.r[1].x);
-                        const double dx = t.x - s.x, dy = t.y - s.y, dz = t.z - s.z;
-                        const double m = dx * dx + dy * dy + dz * dz;
-                        M[17] += (double)ctotL[GN8_FAST ? li : 0];
-                        if (m < gate2) gn8_accumulate(M, s, t, kern, k2);
-                        miss = -1;
-                        rebA = false;
-                        ++nfast;
-                    } else if (it > 0) {
+                    if (it > 0) {
                         const unsigned long long old_key = cur.key;
                         const int kx = voxel_index(s.x, c.vs, inv_vs), ky = voxel_index(s.y, c.vs, inv_vs), kz = voxel_index(s.z, c.vs, inv_vs);
                         if (old_key == pack_key(kx, ky, kz)) {
@@ -2315,32 +2251,17 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
                                 M[17] += (double)ctot_row;
                                 if (m < gate2) gn8_accumulate(M, s, t, kern, k2);
                                 miss = -1;
-                                if (GN8_FAST && budgeted(qb)) {
-                                    // How far may the point go on before a look at this row could say anything else?  A move by d changes
-                                    // each of its distances by at most d: the test keeps passing while 2 d < bound - (distance +
-                                    // displacement), the winner keeps its lead while 2 d < runner-up - winner, and the point keeps its
-                                    // voxel while d < its distance to the nearest voxel face (a multiple of the voxel size on any axis).
-                                    // A little less is kept (rounding of the comparisons it stands for, single precision of the store).
-                                    double room = row[GN8_ANS_D] - (dm + dd);
-                                    if (m2 < 1.0e300) room = fmin(room, sqrt(m2) - dm);
-                                    room *= 0.5;
-                                    const double qx = s.x * inv_vs, qy = s.y * inv_vs, qz = s.z * inv_vs;
-                                    const double fx = qx - floor(qx), fy = qy - floor(qy), fz = qz - floor(qz);
-                                    const double face = fmin(fmin(fmin(fx, 1.0 - fx), fmin(fy, 1.0 - fy)), fmin(fz, 1.0 - fz)) * c.vs;
-                                    room = fmin(room, face) * (1.0 - 1e-5) - 1e-6;
-                                    const float bud = __double2float_rd(room);
-                                    budL[GN8_FAST ? li : 0] = bud;
-                                    if (bud > 0.0f) {
-                                        ctotL[GN8_FAST ? li : 0] = (unsigned short)ctot_row;
-                                        double* t1 = c.pc_t1 + 3 * (size_t)i;
-                                        t1[0] = t.x; t1[1] = t.y; t1[2] = t.z;
-                                        ++nfill;
-                                    }
-                                }
+                            } else if (row[GN8_ANS_D] == GN8_NOTHING_IN_REACH) {
+                                // The last search of this point found its 27 voxels EMPTY, and it still sits in the same voxel: the same 27
+                                // voxels, and the map does not change inside a registration - a search would find nothing again
+                                // (GetCorrespondences: no neighbour, no pair, no candidate).  Settled without one.  With 0.1 m voxels
+                                // (BASELINE config 5) 5-30 % of a sweep's source points look into empty neighbourhoods, at every one of
+                                // a scan's ~50 iterations: most of its repeated searches were these.
+                                miss = -1;
+                                nempty = 1;
                             }
                         }
                     }
-                    if (GN8_FAST && miss >= 0 && budgeted(qb)) budL[GN8_FAST ? li : 0] = -1.0f;  // (a search follows: its row gets a budget at its first evaluation)
                 }
                 missA = miss;
             }
@@ -2366,6 +2287,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
                 }
                 nq += __popcll(bf);   // (this wavefront's counts)
                 nqr += __popcll(br);
+                nemp += __popcll(__ballot(nempty != 0));
 #ifdef GN_PHASE_CLOCKS
                 ph_miss += __popcll(bm); ph_a += GN_CLK() - c0;
 #endif
@@ -2454,17 +2376,12 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
             {   // (queue flushed before the last chunk: its loads are requested again rather than carried across the search;
                 // after the last chunk nothing is loaded - chunk_point says so - and the stale values are dead for the compiler too)
                 pre = preload_chunk(qb + NW, it == 0);
-                if (GN8_PREFETCH > 1) pre2 = preload_chunk(qb + 2 * NW, it == 0);
             }
         }
         // the next iteration's first chunk: positions and answer rows as this iteration leaves them (the searches above have
         // written theirs), requested now - they arrive while the sums are exchanged and the system is solved
         pre = preload_chunk(0, false);
-        if (GN8_PREFETCH > 1) pre2 = preload_chunk(NW, false);
-        if (GN8_FAST) {  // (integer sums over the workgroup: any order gives the same totals)
-            for (int o = 32; o > 0; o >>= 1) { nfast += __shfl_xor(nfast, o); nfill += __shfl_xor(nfill, o); }
-            if ((tl & 63) == 0 && (nfast | nfill)) { atomicAdd(&xcnt[4], (unsigned)nfast); atomicAdd(&xcnt[5], (unsigned)nfill); }
-        }
+        if ((tl & 63) == 0 && nemp) atomicAdd(&xcnt[3], (unsigned)nemp);
         const long long c1 = GN_CLK();
         // ---- workgroup reduction, fixed tree: the 64 lanes of a wavefront (DPP inside the rows, two crossbar steps across
         // them), then the wavefronts in order
@@ -2667,7 +2584,7 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
     __syncthreads();
     if (tid == 0 && c.wg_clk) { c.wg_clk[wg] += ph[0]; c.wg_clk[G + wg] += ph_miss; }
     if (tid < 3 && xcnt[tid]) atomicAdd(&st->exec_cnt[tid], (unsigned long long)xcnt[tid]);  // (integer sums: any order gives the same totals)
-    if (tid >= 4 && tid < 6 && xcnt[tid]) atomicAdd(&st->fast_cnt[tid - 4], (unsigned long long)xcnt[tid]);
+    if (tid == 3 && xcnt[3]) atomicAdd(&st->empty_cnt, (unsigned long long)xcnt[3]);
     if (wg == 0 && tid == 0) {
         Rt T;
         for (int k = 0; k < 9; ++k) T.R[k] = Tsh[k];

@@ -134,7 +134,7 @@ static int icp_free(ptl_icp* h) {
     (void)hipSetDevice(h->cfg.device_id);
     Ctx& c = h->c;
     void* ptrs[] = {c.pts, c.slot1, c.slot2, c.vtab1, c.vtab2, c.bcnt1, c.bcnt2, h->fd_buf[0], h->fd_buf[1], c.src0,
-                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.bhdr, c.bfirst, c.free_stack, c.free_stack_s, c.mig_list, c.wg_clk, c.pc_key, c.pc_pb, c.pc_ans, c.pc_t1, c.gn_rows_ll, c.gn_xsum_ll,
+                    c.src_cur, c.fdw, c.coltab, c.pslot, c.nxt, c.prank, c.plen, c.tab, c.blocks, c.bhdr, c.bfirst, c.free_stack, c.free_stack_s, c.mig_list, c.wg_clk, c.pc_key, c.pc_pb, c.pc_ans, c.gn_rows_ll, c.gn_xsum_ll,
                     c.st, c.traj, c.sstats, h->d_in, h->d_t01, h->d_ext, h->d_counter, h->d_row_mask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -305,7 +305,6 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
     ok &= dalloc(&c.free_stack, c.pool_cap - c.n_small) == hipSuccess;
     ok &= dalloc(&c.free_stack_s, (size_t)(c.n_small > 0 ? c.n_small : 1)) == hipSuccess && dalloc(&c.mig_list, (size_t)(c.n_small > 0 ? c.n_small : 1)) == hipSuccess;
     ok &= dalloc(&c.pc_key, n) == hipSuccess && dalloc(&c.pc_pb, 32 * n) == hipSuccess && dalloc(&c.pc_ans, GN8_ANS_ROW * n) == hipSuccess;
-    if (GN8_FAST) ok &= dalloc(&c.pc_t1, 3 * n) == hipSuccess;  // (the movement-budget experiment's correspondences: off by default)
     ok &= hipHostMalloc((void**)&h->n_src_hint, sizeof(int)) == hipSuccess;
     if (h->n_src_hint) *h->n_src_hint = 0;
     ok &= dalloc(&c.gn_rows_ll, (size_t)2 * c.G * 64) == hipSuccess && hipMemset(c.gn_rows_ll, 0, (size_t)2 * c.G * 64 * 8) == hipSuccess;
@@ -334,7 +333,7 @@ static int icp_create_impl(const ptl_icp_cfg* cfg, hipStream_t shared_stream, pt
 static size_t icp_footprint_bytes(const ptl_icp_cfg* cfg) {
     const size_t n = (size_t)cfg->max_points_per_scan;
     const size_t bstride = ((size_t)cfg->max_points_per_voxel * 24 + 127) / 128 * 128;
-    const size_t per_point = 24 + 4 + 4 + 24 * 2 + 24 + 24 + 24 + 4 * 4 + 8 + 128 + GN8_ANS_ROW * 8 + 24 + (GN8_FAST ? 24 : 0) + 8;
+    const size_t per_point = 24 + 4 + 4 + 24 * 2 + 24 + 24 + 24 + 4 * 4 + 8 + 128 + GN8_ANS_ROW * 8 + 24 + 8;
     return n * per_point + (vds_table_slots(VDS1_SLOTS_PER_POINT, n) + vds_table_slots(VDS2_SLOTS_PER_POINT, n)) * sizeof(VdsEnt) + (size_t)cfg->map_table_capacity * sizeof(TabEnt) +
            (size_t)cfg->map_block_capacity * (bstride + 4 + 16 + 24) + (size_t)cfg->map_small_blocks * (SMALL_BYTES + 8 + 16 + 24) + (size_t)4096 * (128 + sizeof(ScanStats)) + (1u << 20);
 }
@@ -1585,14 +1584,15 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     {   // the whole batch has to fit the device: say so here, with numbers, instead of failing part-way through the allocations
         ptl_icp_cfg ic0 = cfg->icp;
         if (ic0.max_points_per_scan < cfg->points_per_scan) ic0.max_points_per_scan = cfg->points_per_scan;
-        const size_t per_seq = icp_footprint_bytes(&ic0) + (size_t)cfg->n_scans * (size_t)cfg->points_per_scan * 12 +
+        const size_t slot0 = cfg->range_input ? 4 : 12;  // resident bytes per pixel of a sweep
+        const size_t per_seq = icp_footprint_bytes(&ic0) + (size_t)cfg->n_scans * (size_t)cfg->points_per_scan * slot0 +
                                (size_t)(cfg->n_imu > 0 ? cfg->n_imu : 1) * 56 + (size_t)cfg->n_scans * (128 + 8 + 64 + 4) + (64u << 10);
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && per_seq * (size_t)n_sequences > free_b)
             return set_err(PTL_ERR_CAPACITY, "batch of %d sequences needs %.1f GB of device memory (%.0f MB per sequence: %.0f MB of work buffers, map table "
                            "and block pool, %.0f MB of sweeps), %.1f GB are free of %.1f GB: fewer sequences, fewer resident sweeps or a smaller map_block_capacity",
                            n_sequences, per_seq * (double)n_sequences / 1e9, per_seq / 1e6, icp_footprint_bytes(&ic0) / 1e6,
-                           (double)cfg->n_scans * cfg->points_per_scan * 12 / 1e6, free_b / 1e9, total_b / 1e9);
+                           (double)cfg->n_scans * cfg->points_per_scan * slot0 / 1e6, free_b / 1e9, total_b / 1e9);
     }
     ptl_batch* b = new ptl_batch();
     b->cfg = *cfg;
@@ -1628,7 +1628,7 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
         if (rc == PTL_OK) rc = ekf_create_impl(&ec, b->stream, &b->ekf[s]);
         while (rc == PTL_OK && b->icp[s]->traj_cap < cfg->n_scans) rc = icp_grow_traj(b->icp[s]);
         if (rc == PTL_OK &&
-            (hipMalloc((void**)&b->d_scans[s], (size_t)cfg->n_scans * cfg->points_per_scan * 12) != hipSuccess ||
+            (hipMalloc((void**)&b->d_scans[s], (size_t)cfg->n_scans * cfg->points_per_scan * (cfg->range_input ? 4 : 12)) != hipSuccess ||
              dalloc(&b->d_imu[s], nim * 7) != hipSuccess || dalloc(&b->d_res_poses[s], (size_t)cfg->n_scans * 16) != hipSuccess ||
              dalloc(&b->d_res_t[s], (size_t)cfg->n_scans) != hipSuccess || dalloc(&b->d_rows[s], (size_t)cfg->n_scans * 8) != hipSuccess ||
              dalloc(&b->d_imu_end[s], (size_t)cfg->n_scans) != hipSuccess))
@@ -1648,7 +1648,7 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
 }
 extern "C" int ptl_batch_upload_scan(ptl_batch* b, int32_t s, int64_t k, const float* xyz) {
     if (!b || !xyz || s < 0 || s >= b->S || k < 0 || k >= b->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
-    if (b->is_range) return set_err(PTL_ERR_STATE, "this batch holds range images");
+    if (b->is_range || b->cfg.range_input) return set_err(PTL_ERR_STATE, "this batch holds range images");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
     const size_t bytes = (size_t)b->cfg.points_per_scan * 12;
     HIPCHK(hipMemcpy((char*)b->d_scans[s] + (size_t)k * bytes, xyz, bytes, hipMemcpyHostToDevice));
@@ -1658,7 +1658,7 @@ extern "C" int ptl_batch_upload_range(ptl_batch* b, int32_t s, int64_t k, const 
     if (!b || !range_mm || s < 0 || s >= b->S || k < 0 || k >= b->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
     if (!b->lut) return set_err(PTL_ERR_STATE, "set the LUT first (ptl_batch_set_lut)");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
-    const size_t slot = (size_t)b->cfg.points_per_scan * 12;
+    const size_t slot = (size_t)b->cfg.points_per_scan * (b->cfg.range_input ? 4 : 12);
     HIPCHK(hipMemcpy((char*)b->d_scans[s] + (size_t)k * slot, range_mm, (size_t)b->cfg.points_per_scan * 4, hipMemcpyHostToDevice));
     return PTL_OK;
 }
@@ -1700,7 +1700,7 @@ static int batch_push_ctx(ptl_batch* b) {
         if (b->is_range) { c.lut_dir = b->lut->dir; c.lut_off = b->lut->off; c.row_mask = b->icp[s]->d_row_mask; }
         h[s].c = c;
         h[s].scan_base = b->d_scans[s];
-        h[s].scan_stride_floats = (long long)b->cfg.points_per_scan * 3;
+        h[s].scan_stride_floats = (long long)b->cfg.points_per_scan * (b->cfg.range_input ? 1 : 3);
         h[s].input_is_range = b->is_range;
         h[s].n_scans = (int)b->cfg.n_scans;
         h[s].fd_buf[0] = b->icp[s]->fd_buf[0]; h[s].fd_buf[1] = b->icp[s]->fd_buf[1];
@@ -2006,7 +2006,7 @@ extern "C" int ptl_build_info(int32_t out[16]) {
     for (int i = 0; i < 16; ++i) out[i] = 0;
     out[0] = GN8_KCAND; out[1] = GN8_ANS_ROW; out[2] = GN8_LDS_PTS; out[3] = SEQ_U; out[4] = SEQ_U2; out[5] = GN8_MAX_THREADS;
     out[6] = GN8_LPB; out[7] = GN8_SPEC; out[8] = GN8_SURV; out[9] = GN8_PREFETCH; out[10] = (int32_t)(1000.0 * GN8_KEEP + 0.5);
-    out[11] = (int32_t)sizeof(TabEnt); out[12] = (int32_t)sizeof(VdsEnt); out[14] = GN8_FAST;
+    out[11] = (int32_t)sizeof(TabEnt); out[12] = (int32_t)sizeof(VdsEnt); out[14] = 0;
 #if defined(GN_PHASE_CLOCKS) || defined(SEQ_STAGE_CLOCKS) || defined(GN_IT0_CLOCK)
     out[13] = 1;
 #endif
@@ -2067,12 +2067,14 @@ extern "C" int ptl_batch_seq_clocks(ptl_batch* b, int32_t s, int64_t out[8]) {
     return PTL_OK;
 }
 // executed-work counters of sequence s (DevState::exec_cnt), cumulative since the cold start
-extern "C" int ptl_batch_exec_counters(ptl_batch* b, int32_t s, uint64_t out[8]) {
+extern "C" int ptl_batch_exec_counters(ptl_batch* b, int32_t s, uint64_t out[16]) {
     if (!b || !out || s < 0 || s >= b->S) return set_err(PTL_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
     HIPCHK(hipStreamSynchronize(b->side));
     HIPCHK(hipStreamSynchronize(b->stream));
+    memset(out, 0, 16 * sizeof(uint64_t));
     HIPCHK(hipMemcpy(out, (char*)b->icp[s]->c.st + offsetof(DevState, exec_cnt), 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out + 8, (char*)b->icp[s]->c.st + offsetof(DevState, empty_cnt), sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PTL_OK;
 }
 extern "C" int ptl_batch_gn_phases(ptl_batch* b, int64_t out[8]) {
