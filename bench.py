@@ -70,15 +70,17 @@ EXEC_COST = {
     "exchange_word": 8, "exchange_words_per_row": 36,
     # stages, per raw point: K1 f32 xyz (12) + slot1 write (4) | K3 slot1 (4)   (round 4: K3b / K4 walk the compact frame_downsample, not the raw indices)
     "raw_point": 12 + 4 + 4,
-    # per valid point: K1 writes the deskewed point (24), K3 reads the slot's winner index (4)
-    "valid_point": 24 + 4,
-    # per voxel claim (run head) of either down-sampling pass: key read (8) + compare-and-swap (8) + index read (4) + atomicMin (4)
-    "vds_claim": 24,
-    # per frame_down point: K3 reads the point (24), writes fd (24), releases the pass-1 slot (12); K3b reads fd (24), writes its pass-2 slot (4); K4 reads slot (4) + index (4);
+    # per valid point: K1 writes the deskewed point (24)   (round 6: only a run's head keeps its slot, so K3 reads the slot's winner index
+    # per CLAIM, not per valid point)
+    "valid_point": 24,
+    # per voxel claim (run head) of either down-sampling pass: key read (8) + compare-and-swap (8) + index read (4) + atomicMin (4), and
+    # the winner index K3 / K4 read back through the head's slot (4)
+    "vds_claim": 24 + 4,
+    # per frame_down point: K3 reads the point (24), writes fd (24), releases the pass-1 slot (12); K3b reads fd (24), writes its pass-2 slot (4); K4 reads slot (4) (the winner index: per claim, below);
     # map insert a: fd read (24), world point written (24), table key read (8), list push (4), slot + link written (8);
     # b: slot (4) + table entry (16: the stored count comes with it) + list walk (~8) + world point (24) read, block written (24);
     # c: none in the free-running kernel - the prune pass counts the batch in (round 4; before: rank + length written and read back, block header read)
-    "down_point": (24 + 24 + 12) + (24 + 4) + (4 + 4) + (24 + 24 + 8 + 4 + 8) + (4 + 16 + 8 + 24 + 24),
+    "down_point": (24 + 24 + 12) + (24 + 4) + 4 + (24 + 24 + 8 + 4 + 8) + (4 + 16 + 8 + 24 + 24),
     # per source point: K4 reads + writes it (48) and releases its pass-2 slot (12)
     "source_point": 48 + 12,
     # prune: header (12) + first point (24) of every block below the pool's high-water mark (~ live voxels); the publish of a voxel the

@@ -586,14 +586,13 @@ __device__ __forceinline__ void d_deskew_vds1(const Ctx& c, const Slice sl, cons
         K1_CLK(22);
         vds_bid_u<U>(c.vtab1, slot, head, idx, &st->err_flags);
         K1_CLK(23);
+        // Only the HEAD of a run of equal keys can be its voxel's first point in scan order (every other point of the run has a lower
+        // index of the same voxel right beside it in this wavefront), so only heads keep their slot: K3 then reads the slot's winner
+        // for 46 k points of a sweep instead of 120 k (scattered 16-byte reads), and the heads' slots need not be handed down the runs
+        // (a ballot, a count and a shuffle per point).  Round 6.
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned long long heads = __ballot(head[u]);
-            const unsigned long long below = heads & (~0ull >> (63 - lane));
-            const int my_head = below ? 63 - __clzll((long long)below) : lane;
-            const int hs = __shfl(slot[u], my_head);
-            if (idx[u] < c.n_in) c.slot1[idx[u]] = keyed[u] ? hs : -1;
-        }
+        for (int u = 0; u < U; ++u)
+            if (idx[u] < c.n_in) c.slot1[idx[u]] = head[u] ? slot[u] : -1;
     }
     K1_CLK(24);
     if (wave_valid) {
@@ -809,13 +808,8 @@ __device__ __forceinline__ void d_vds2_fd(const Ctx& c, const Slice sl) {
     }
     vds_bid_u<U>(c.vtab2, slot, head, idx, &c.st->err_flags);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const unsigned long long heads = __ballot(head[u]);
-        const unsigned long long below = heads & (~0ull >> (63 - lane));  // heads at or below this lane
-        const int my_head = below ? 63 - __clzll((long long)below) : lane;
-        const int hs = __shfl(slot[u], my_head);
-        if (act[u]) c.slot2[idx[u]] = hs;
-    }
+    for (int u = 0; u < U; ++u)
+        if (act[u]) c.slot2[idx[u]] = head[u] ? slot[u] : -1;  // (only a run's head can win its voxel: see K1)
 }
 // ... and its winners counted per block (the drivers with one launch per stage; the free-running kernel looks back in K4)
 template <int U>
@@ -2714,44 +2708,89 @@ __device__ __forceinline__ void d_map_insert_a(const Ctx& c, const double* pts_i
     int nx[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) nx[u] = (slot[u] >= 0) ? atomicExch(&c.tab[slot[u]].head, idx[u]) : -1;
-    {   // the new voxels take their blocks from the pool: every step for all U points at once (the pops, then the reads of the
+    {   // The new voxels take their blocks from the pool: every step for all U points at once (the pops, then the reads of the
         // free stack, then the headers) - step by step per point it is a chain of dependent memory round trips per u, and some
-        // lane of a wavefront creates a voxel for nearly every u
+        // lane of a wavefront creates a voxel for nearly every u.
+        // The pool's counters (free tops, live voxels, high-water marks, table entries used) sit in ONE line of the state: an atomic
+        // per created voxel on each of them is a queue of same-address atomics at one L2 channel - BASELINE config 5 creates ~30 k
+        // voxels per scan, 120 k serialised atomics, and its insert a took 1 007 us of a 1 870 us map update (profiles/
+        // r06_a_config5_stage_clocks...).  Round 6: a wavefront counts its creations over all U points with ballots and sends ONE
+        // atomic per counter and pass; lane l's r-th creation of point u takes pool index base - 1 - (creations before it in (u, lane)
+        // order) - the indices the lanes would have got one by one in that order.
+        const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+        const bool lead = (threadIdx.x & 63) == 0;
         int top[U], blk[U];
         bool small[U];
-        if (c.n_small > 0) {  // (uniform) two classes: a new voxel starts in a small block; the full pool only when the small one has run out
+        unsigned long long mc[U];
+        int pre[U], tot = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) { top[u] = created[u] ? atomicSub(&st->free_top_s, 1) - 1 : -1; small[u] = created[u]; }
+        for (int u = 0; u < U; ++u) { mc[u] = __ballot(created[u]); pre[u] = tot; tot += __popcll(mc[u]); top[u] = -1; blk[u] = -1; small[u] = false; }
+        if (tot > 0) {  // (uniform over the wavefront)
+            int* first_top = c.n_small > 0 ? &st->free_top_s : &st->free_top;  // two classes: a new voxel starts in a small block
+            int base = 0;
+            if (lead) base = atomicSub(first_top, tot);
+            base = __shfl(base, 0);
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (created[u] && top[u] < 0) { atomicAdd(&st->free_top_s, 1); small[u] = false; top[u] = atomicSub(&st->free_top, 1) - 1; }
-        } else {
+                if (created[u]) { top[u] = base - 1 - (pre[u] + __popcll(mc[u] & below)); small[u] = c.n_small > 0; }
+            // what the first pool could not serve (its top went below zero): given back in one piece; with two classes those voxels go to
+            // the full pool (only when the small one has run out), with one class the pool is exhausted
+            unsigned long long mf[U];
+            int pre2[U], nf = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) { top[u] = created[u] ? atomicSub(&st->free_top, 1) - 1 : -1; small[u] = false; }
-        }
+            for (int u = 0; u < U; ++u) { mf[u] = __ballot(created[u] && top[u] < 0); pre2[u] = nf; nf += __popcll(mf[u]); }
+            if (nf > 0) {
+                int base2 = 0;
+                if (lead) {
+                    atomicAdd(first_top, nf);  // (the prune pass pushes at the top: it must not find it negative)
+                    if (c.n_small > 0) base2 = atomicSub(&st->free_top, nf);
+                }
+                base2 = __shfl(base2, 0);
+                int back = 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            blk[u] = -1;
-            if (!created[u]) continue;
-            if (top[u] < 0) atomicAdd(&st->free_top, 1);  // pool exhausted: put the count back (the prune pass pushes at free_top: it must not find it negative)
-            else blk[u] = small[u] ? c.free_stack_s[top[u]] : c.free_stack[top[u]];
-        }
+                for (int u = 0; u < U; ++u)
+                    if (created[u] && top[u] < 0) {
+                        small[u] = false;
+                        if (c.n_small > 0) top[u] = base2 - 1 - (pre2[u] + __popcll(mf[u] & below));
+                    }
+                if (c.n_small > 0) {  // ... and the full pool's own shortfall
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!created[u]) continue;
-            if (blk[u] >= 0) {
-                int* h = blk_hdr(c, blk[u]);
-                h[0] = 0;
-                h[1] = slot[u];
-                h[2] = 0;  // (points of a batch waiting to be counted in: FUSE form of insert b / prune)
-                atomicAdd(&st->n_live, 1);
-                if (small[u]) atomicMax(&st->pool_hw_s, blk[u] + 1); else atomicMax(&st->pool_hw, blk[u] + 1);
-            } else {
-                atomicOr(&st->err_flags, ERR_POOL);
+                    for (int u = 0; u < U; ++u) back += __popcll(__ballot(created[u] && top[u] < 0));
+                    if (lead && back > 0) atomicAdd(&st->free_top, back);
+                }
             }
-            c.tab[slot[u]].blk = blk[u];
-            const unsigned used = atomicAdd(&st->tab_used, 1u) + 1u;
-            if (used > (c.tmask + 1u) / 4u * 3u) { atomicOr(&st->err_flags, ERR_TABLE); MAP_DIAG_AT(st, 1, used, c.tmask); }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (created[u] && top[u] >= 0) blk[u] = small[u] ? c.free_stack_s[top[u]] : c.free_stack[top[u]];
+            int live = 0, hw_s = 0, hw_f = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!created[u]) continue;
+                if (blk[u] >= 0) {
+                    int* h = blk_hdr(c, blk[u]);
+                    h[0] = 0;
+                    h[1] = slot[u];
+                    h[2] = 0;  // (points of a batch waiting to be counted in: FUSE form of insert b / prune)
+                    ++live;
+                    if (small[u]) hw_s = max(hw_s, blk[u] + 1); else hw_f = max(hw_f, blk[u] + 1);
+                } else {
+                    atomicOr(&st->err_flags, ERR_POOL);
+                }
+                c.tab[slot[u]].blk = blk[u];
+            }
+            // one atomic per counter and wavefront: live voxels, the high-water marks, table entries used
+            for (int o = 32; o > 0; o >>= 1) {
+                live += __shfl_xor(live, o);
+                hw_s = max(hw_s, __shfl_xor(hw_s, o));
+                hw_f = max(hw_f, __shfl_xor(hw_f, o));
+            }
+            if (lead) {
+                if (live > 0) atomicAdd(&st->n_live, live);
+                if (hw_s > 0) atomicMax(&st->pool_hw_s, hw_s);
+                if (hw_f > 0) atomicMax(&st->pool_hw, hw_f);
+                const unsigned used = atomicAdd(&st->tab_used, (unsigned)tot) + (unsigned)tot;
+                if (used > (c.tmask + 1u) / 4u * 3u) { atomicOr(&st->err_flags, ERR_TABLE); MAP_DIAG_AT(st, 1, used, c.tmask); }
+            }
         }
     }
 #pragma unroll

@@ -119,8 +119,10 @@ def test_executed_byte_model():
     _, gn_big, _ = b.executed_bytes(dict(cnt, point_iterations=7 * 4072), big, 131072, 1, 1024)
     assert c["point_iteration_later"] == 144 and gn_big == 24 * 4072 + 48 * 1000 * 7 + 144 * 6 * 4072 + c["search"] * 5000 - 136 * 4072 + c["row_rebuilt"] * 10 + 24 * 5000 + 7 * 1 * 2 * 36 * 8
     assert stages == c["raw_point"] * 131072 + c["valid_point"] * 100000 + c["down_point"] * 30000 + c["source_point"] * 1000 \
-        + c["map_voxel"] * 20000 + 96 * 1024 + 24 * 340
-    assert c["map_voxel"] == 36 and c["down_point"] == 240  # (round 4: insert c is part of the prune pass, the stored count comes with the table entry)
+        + c["map_voxel"] * 20000 + 96 * 1024 + c["vds_claim"] * 340
+    # (round 4: insert c is part of the prune pass, the stored count comes with the table entry; round 6: only a run's head keeps its voxel
+    # slot, so the winner index is read per claim - not per valid point / frame_down entry)
+    assert c["map_voxel"] == 36 and c["down_point"] == 236 and c["valid_point"] == 24 and c["vds_claim"] == 28
     assert tot == gn + stages
     # a first scan (empty map: no iteration) costs its stages only
     tot0, gn0, _ = b.executed_bytes(dict(cnt, searches=0, rows_rebuilt=0, map_points_read=0, gn_iterations=0, point_iterations=0),
