@@ -61,7 +61,13 @@ class KissICPWrapper:
         # way on the device; the per-scan `stats` rows then carry no map size (core.Icp)
         # (the per-call handle keeps a 2^22-slot map table - 64 MB, cleared at every construction - instead of the batch default's 2^24: one
         # sequence over the whole chip holds its probe results in registers and gains little from a sparser table)
-        icp_over.setdefault("map_table_capacity", 1 << 22)
+        # ... unless the caller sizes the block pool up (small voxels, a dense map): the table raises its capacity flag at 3/4 of its slots,
+        # tombstones included - the default follows the pool, the next power of two >= 8 slots per block
+        blocks = int(icp_over.get("map_block_capacity", 0))
+        table = 1 << 22
+        while table < 8 * blocks:
+            table <<= 1
+        icp_over.setdefault("map_table_capacity", table)
         self._icp = core.Icp(_max_range, _min_range, device_id=device_id, scan_cols=w,
                              max_points_per_scan=max(h * w, 1024), lazy_map_stats=lazy_map_stats, **icp_over)
         c = self._icp.cfg

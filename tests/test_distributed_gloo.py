@@ -119,3 +119,43 @@ def test_communicator_id_travels_over_the_control_plane():
     import pytest
     with pytest.raises(ValueError):
         parallel.Comm(b"short", 1, 0)
+
+
+def _id_fail_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    idg = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60))  # the id's own group, as bench.py does
+
+    def make():
+        raise OSError("librccl.so could not be opened")
+
+    err = None
+    try:
+        parallel.broadcast_id(dist, idg, make)
+    except RuntimeError as e:
+        err = str(e)
+    # the control plane is still in step on every rank: the collective that follows (bench.py: has anybody failed?) completes
+    worst = parallel.max_over_ranks(1.0 if err else 0.0, dist, device="cpu", group=dist.group.WORLD)
+    q.put((rank, err, worst))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_id_on_rank_0_raises_on_every_rank_and_leaves_the_control_plane_in_step():
+    """rank 0's make_id() raising (librccl cannot be opened - the case bench.py's gloo fallback exists for) used to leave the
+    other ranks blocked in the broadcast while rank 0 went on to an all_reduce of the same group.  The error now travels IN the broadcast:
+    every rank raises together, and the next collective of the control plane lines up."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_fail_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] and "librccl.so could not be opened" in r[1] for r in res), res
+    assert [r[2] for r in res] == [1.0, 1.0]

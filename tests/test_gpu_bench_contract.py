@@ -220,3 +220,50 @@ def test_bench_verify_all_compares_every_sequence_with_its_single_run():
     assert d["verify_all"] == {"sequences": 20, "differ_from_their_single_runs": []}
     assert d["repeats"]["n"] == 2 and d["repeats"]["bit_identical_trajectories"] is True
 
+
+
+@pytest.mark.gpu
+def test_bench_range_input_keeps_range_images_resident_and_matches_the_oracle():
+    """`--range-input` (SURVEY 8(f) rank 1 inside the bench): sweeps enter and STAY as u32 range images (ptl_seq_cfg.range_input: 4
+    resident bytes per pixel), the LUT runs on the device, the oracle is fed the points the device LUT makes of the same images -
+    parity as on the xyz path; `--ray-jitter-deg` is part of the workload (key and text)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "4", "--seqs-per-gpu", "16", "--range-input",
+                          "--repeats", "1", "--cpu-budget", "4", "--no-single-sequence"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    assert "_range" in d["config"]["workload_key"] and "range images" in d["config"]["workload"]
+    assert d["parity_vs_oracle"]["scans"] >= 12 and d["parity_vs_oracle"]["max_dpos_m"] < 1e-9
+    assert d["parity_vs_oracle"]["extra_sequences"]["max_dpos_m"] < 1e-9
+    assert d["config"]["library_built_from_this_source_tree"] is True and len(d["config"]["code_id"]) == 12
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--seqs-per-gpu", "8", "--ray-jitter-deg", "0.3",
+                          "--repeats", "1", "--cpu-budget", "3", "--no-single-sequence"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    assert "_jit0.3" in d["config"]["workload_key"] and "jittered" in d["config"]["workload"]
+    assert d["parity_vs_oracle"]["max_dpos_m"] < 1e-9
+
+
+@pytest.mark.gpu
+def test_icp_only_ranks_gather_the_registrations_own_poses(tmp_path):
+    """`--icp-only` multi-rank runs gather too: no filter, so the rows are the registration's own poses stamped with the
+    scan index.  Two self-launched ranks share GPU 0 here (host rows over gloo); a one-rank batch under the launcher takes the library's
+    path (ptl_batch_gather_trajectories -> k_kiss_rows -> ncclAllGather)."""
+    import numpy as np
+    dump = str(tmp_path / "traj.npz")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--icp-only",
+                          "--gn-wgs", "64", "--seqs-per-gpu", "1", "--dump-traj", dump], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    assert d["gathered_trajectories"]["sequences"] == 2 and d["gathered_trajectories"]["rows_each"] == [9]
+    got = np.load(dump)
+    assert np.array_equal(got["rank0_seq0"][:, 0], np.arange(9.0)) and np.abs(got["rank0_seq0"][-1, 1:4]).max() > 0
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+    dump1 = str(tmp_path / "traj1.npz")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3", "--icp-only", "--seqs-per-gpu", "16",
+                          "--repeats", "1", "--no-cpu-baseline", "--no-single-sequence", "--dump-traj", dump1], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    g = d["gathered_trajectories"]
+    assert g["sequences"] == 16 and g["rows_each"] == [9] and "RCCL" in g["backend"] and "FALLBACK" not in g["backend"], g
+    rows = np.load(dump1)["rank0_seq3"]
+    assert np.array_equal(rows[:, 0], np.arange(9.0)) and abs(np.linalg.norm(rows[-1, 4:8]) - 1.0) < 1e-12
