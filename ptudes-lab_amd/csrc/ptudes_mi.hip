@@ -1482,6 +1482,7 @@ struct ptl_batch {
     int *d_flags, *h_flags;     // [GN_MAX_SEQ + 1] error flags of every sequence + the status word, gathered by k_finish_all (h_flags: pinned)
     unsigned* d_status;         // one sticky word: why teams of the free-running kernel left a launch early (SEQ_EXIT_*), cleared by a reset
     int force_agent;            // PTL_TEAM_SYNC=agent in the environment when the batch was created: no XCD-local barrier shortcut
+    int balance_margin;         // PTL_SCHED_MARGIN (default 1; -1 = a team looks abroad only when its own XCD has nothing for it): seq_kernel.h SeqRun
     int dbg_dead_block, dbg_dead_round;  // test hook: ptl_batch_debug_stall_block
     int um_alt;                 // test hook: ptl_batch_debug_set_map_points_per_thread
     bool free_running;
@@ -1602,6 +1603,9 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     {   // PTL_TEAM_SYNC=agent: the teams of the free-running kernel keep the agent-scope release at every barrier (seq_kernel.h team_sync)
         const char* e = getenv("PTL_TEAM_SYNC");
         b->force_agent = (e && strcmp(e, "agent") == 0) ? 1 : 0;
+        const char* m = getenv("PTL_SCHED_MARGIN");
+        b->balance_margin = (m && *m) ? atoi(m) : 1;
+        if (b->balance_margin < -1 || b->balance_margin > 4096) b->balance_margin = 1;
     }
     b->free_running = cfg->icp.gn_lanes_per_point == 8;
     if (!b->free_running && cfg->icp.map_small_blocks > 0) { ptl_batch_destroy(b); return set_err(PTL_ERR_ARG, "map_small_blocks (two block classes) needs the free-running driver (gn_lanes_per_point = 8)"); }
@@ -1768,6 +1772,7 @@ static int batch_enqueue_free(ptl_batch* b, int64_t n) {
         const int gseq = batch_gseq(b);
         r.G = gseq;
         r.um_alt = b->um_alt;
+        r.balance_margin = b->balance_margin;
         r.force_agent = b->force_agent; r.dbg_dead_block = b->dbg_dead_block; r.dbg_dead_round = b->dbg_dead_round;
         const bool p20 = ic.max_points_per_voxel == 20;
 #define KXR(GC) do { if (p20) kx_seq_run<20, GC><<<ic.gn_workgroups, ic.gn_threads, 0, st>>>(b->d_ctx, r, b->d_sched, b->d_bar, b->d_status); \

@@ -254,6 +254,8 @@ struct SeqRun {
     int force_agent;     // PTL_TEAM_SYNC=agent: every team barrier keeps the agent-scope release (no XCD-local shortcut)
     int dbg_dead_block;  // test hook (ptl_batch_debug_stall_block): this workgroup of the grid leaves right before the job barrier of its
     int dbg_dead_round;  // dbg_dead_round-th job (0 = the first); -1 = none
+    int balance_margin;  // >= 0: a team helps another XCD as soon as that XCD's least-advanced free sequence is this many scans behind its own
+                         // XCD's (sched_most_behind); -1: only when its own XCD has nothing for it (rounds 3-5).  PTL_SCHED_MARGIN, default 1
 };
 // Why a team left the launch other than "all scans done".  Sticky bits in one word of device memory per batch (never cleared by a
 // launch; ptl_batch_wait reports them): no exit of the free-running kernel is silent.
@@ -323,6 +325,37 @@ __device__ __forceinline__ int sched_pick(SeqSched* sc, int nslots, int k1, int*
     }
     return SCHED_RETRY;
 }
+// Where is the sequence that is furthest behind?  The leader's first wavefront reads all eight tables in one round trip (8 lanes per XCD, 4
+// slots each) and returns, in every lane: *k_home = the fewest scans done among the FREE sequences of XCD x (INT_MAX: none), and the XCD
+// other than x whose least-advanced free sequence has the fewest scans done, with that count in *k_other (-1 / INT_MAX: none).
+// Round 6: the XCDs' sequences differ in cost by several per cent, and a team that only ever looks abroad when its own XCD has NOTHING left
+// meets the slow XCD's sequences at the end of the run - a handful of chains with a few scans each that cannot be split, the other teams idle
+// (the driver's 20-step form lost ~ 6 % there).  Helping as soon as somebody is a scan behind keeps all sequences of the device within a scan
+// of each other: the run ends everywhere at once.  Nothing is lost in the caches - 30 sequences time-share one XCD's 4 MB L2, a sequence
+// finds nothing of its previous scan there either way - and every hand-over is agent-scope already.
+__device__ __forceinline__ int sched_most_behind(const SeqSched* sched, int S, int k1, int x, int* k_home, int* k_other) {
+    const int lane = (int)(threadIdx.x & 63u), xo = lane >> 3;
+    const int nso = xo < S ? (S - xo + 7) >> 3 : 0;
+    int kk[4], bz[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int slot = (lane & 7) * 4 + j;
+        kk[j] = k1; bz[j] = 1;
+        if (slot < nso) {
+            kk[j] = __hip_atomic_load(&sched[xo].next_scan[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bz[j] = __hip_atomic_load(&sched[xo].busy[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    int kmin = 0x7FFFFFFF;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (kk[j] < k1 && bz[j] == 0) kmin = min(kmin, kk[j]);
+    for (int o = 4; o > 0; o >>= 1) kmin = min(kmin, __shfl_xor(kmin, o));  // (the 8 lanes of an XCD)
+    *k_home = __shfl(kmin, 8 * x);
+    unsigned key = (xo != x && kmin != 0x7FFFFFFF) ? (((unsigned)kmin << 3) | (unsigned)xo) : 0xFFFFFFFFu;
+    for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+    *k_other = key == 0xFFFFFFFFu ? 0x7FFFFFFF : (int)(key >> 3);
+    return key == 0xFFFFFFFFu ? -1 : (int)(key & 7u);
+}
 __device__ __forceinline__ void sched_release(SeqSched* sc, int q, int next_scan) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (always the full release: the next scan may run on any team - any XCD as far as this protocol knows)
     __hip_atomic_store(&sc->next_scan[q], next_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -388,7 +421,16 @@ __global__ __launch_bounds__(GN8_MAX_THREADS) SEQ_OCC void kx_seq_run(const SeqC
         if (wg == 0 && threadIdx.x < 64u) {  // the leader workgroup's first wavefront: hand the finished scan back (lane 0), take the next job
             if (lead && q_mine >= 0) sched_release(sched + x_mine, q_mine, k_mine + 1);
             int k = 0, xs = x;
-            int q = sched_pick(sc, nslots, r.k1, &k, 16u);  // (a short wait at home, then a look at the neighbours, then round the team barrier and again)
+            int q = -1;
+            if (r.balance_margin >= 0) {  // is another XCD's least-advanced free sequence behind ours?  Then that one first.
+                int kh, ko;
+                const int xb = sched_most_behind(sched, r.S, r.k1, x, &kh, &ko);
+                if (xb >= 0 && kh != 0x7FFFFFFF && ko + r.balance_margin <= kh) {
+                    const int qo = sched_pick(sched + xb, (r.S - xb + 7) >> 3, r.k1, &k, 1u);
+                    if (qo >= 0) { q = qo; xs = xb; }
+                }
+            }
+            if (q < 0) q = sched_pick(sc, nslots, r.k1, &k, 16u);  // (a short wait at home, then a look at the neighbours, then round the team barrier and again)
             if (q < 0) {
                 // Nothing to do at home: is a sequence of another XCD waiting for a team?  (24 sequences per XCD differ enough in cost
                 // that the XCDs finish 5-10 ms apart in a 150 ms run, and the L2 they would share is far too small for any of this

@@ -81,6 +81,25 @@ def test_sequences_that_migrate_between_xcds_equal_their_runs_alone():
     for s in range(S):
         assert _same(b2.results(s), outs[s]), s
     b2.close()
+    # round 6: a team helps another XCD as soon as that XCD's least-advanced free sequence is a scan behind its own (PTL_SCHED_MARGIN,
+    # default 1).  The policy of rounds 3-5 (-1: only when the own XCD has nothing left) must give the same bits.
+    old = os.environ.get("PTL_SCHED_MARGIN")
+    os.environ["PTL_SCHED_MARGIN"] = "-1"
+    try:
+        b3 = core.BatchRunner(S, n, seqs[0].H * seqs[0].W, n_imu, **kw)
+    finally:
+        if old is None:
+            del os.environ["PTL_SCHED_MARGIN"]
+        else:
+            os.environ["PTL_SCHED_MARGIN"] = old
+    _load(b3, seqs, n, n_imu)
+    b3.run()
+    assert b3.status() == 0
+    for s in range(S):
+        assert _same(b3.results(s), outs[s]), s
+    stolen3 = sum(b3.sched_counters(s)["stolen"] for s in range(S))
+    assert stolen3 > 0, (stolen3, stolen)  # (XCD 0's third sequence is still taken by the others once they have run out of work)
+    b3.close()
 
 
 def test_default_geometry_counts_its_migrations_and_stays_bit_exact():
