@@ -521,6 +521,13 @@ class BatchRunner:
         n = max(out[6], 1)
         return tuple(out[i] / n / 100.0 for i in range(6))
 
+    def seq_clocks_raw(self, s):
+        """the same clocks as they are kept: (six sums of 100 MHz ticks since the cold start, scans) - a caller that wants the means over
+        SOME of the scans (the timed ones, without the warm-up) takes differences"""
+        out = (C.c_int64 * 8)()
+        L.check(L.lib().ptl_batch_seq_clocks(self._h, s, out))
+        return tuple(int(out[i]) for i in range(6)), int(out[6])
+
     def profile(self, enable=True, reset=False):
         ms, n = C.c_double(), C.c_int64()
         L.check(L.lib().ptl_batch_profile(self._h, int(enable), C.byref(ms), C.byref(n), int(reset)))

@@ -2110,15 +2110,6 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
     // (blockDim points) at [q blockDim, (q + 1) blockDim).  Chunks beyond the array (a team of 2 on a scan of > 6144 source
     // points) keep theirs in src_cur.
     __shared__ double posL[3][GN8_LDS_PTS];
-#ifdef GN8_BLOCKSUM_PROBE
-    // make EXTRA=-DGN8_BLOCKSUM_PROBE: a TIMING PROBE of team-size-invariant sums ("measure it").  A summation that does not
-    // depend on how many workgroups walk a scan has to be defined on the points alone: a fixed lane tree per 64-point block, then a fixed
-    // tree over the blocks.  This build pays the first half - every wavefront reduces its 18 moments after EVERY chunk (its block of 64
-    // points) and adds them to per-wavefront accumulators in LDS, instead of once per iteration - and nothing of the second (class
-    // accumulators per block residue, the way of a searched point's term back to its block): a LOWER bound on what the invariant form costs.
-    // Same correspondences, the sums differ in association only.
-    __shared__ double blkacc[GN8_MAX_THREADS / 64][GN8_ROW_ENTRIES];
-#endif
     DevState* st = c.st;
     const int tid = threadIdx.x;
     const int NT = blockDim.x, NG32 = blockDim.x >> 5, NW = blockDim.x >> 6;
@@ -2299,18 +2290,6 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
             const long long pa2 = GN_CLK();
             if (wg == 0 && tl == 0 && it > 0) { atomicAdd((unsigned long long*)&c.wg_clk[56], (unsigned long long)(pa1 - pa0)); atomicAdd((unsigned long long*)&c.wg_clk[57], (unsigned long long)(pa2 - pa1)); atomicAdd((unsigned long long*)&c.wg_clk[59], 1ull); }
 #endif
-#ifdef GN8_BLOCKSUM_PROBE
-            {   // the block's sums: fixed lane tree, then into this wavefront's accumulator (lane 0), the lanes start the next block from zero
-#pragma unroll
-                for (int e = 0; e < GN8_ROW_ENTRIES; ++e) {
-                    double v = M[e];
-                    v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v);
-                    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-                    if ((tl & 63) == 0) blkacc[tl >> 6][e] = (qb == 0 ? 0.0 : blkacc[tl >> 6][e]) + v;
-                    M[e] = 0.0;
-                }
-            }
-#endif
             if (qb + NW < my_blocks && ((qb / NW + 1) % GN8_QCHUNKS) != 0) continue;  // (a region holds GN8_QCHUNKS chunks whatever they bring)
             if ((tl & 63) == 0) { qcount[0][tl >> 6] = nq; qcount[1][tl >> 6] = nqr; }
             nq = 0; nqr = 0;
@@ -2398,12 +2377,6 @@ __device__ __forceinline__ void gn8_body(const Ctx& c_in, int mode, const int G_
         pre = preload_chunk(0, false);
         if ((tl & 63) == 0 && nemp) atomicAdd(&xcnt[3], (unsigned)nemp);
         const long long c1 = GN_CLK();
-#ifdef GN8_BLOCKSUM_PROBE
-        if ((tl & 63) == 0 && my_blocks > 0) {
-#pragma unroll
-            for (int e = 0; e < GN8_ROW_ENTRIES; ++e) M[e] += blkacc[tl >> 6][e];
-        }
-#endif
         // ---- workgroup reduction, fixed tree: the 64 lanes of a wavefront (DPP inside the rows, two crossbar steps across
         // them), then the wavefronts in order
 #pragma unroll

@@ -48,6 +48,10 @@ def test_one_rank_gather_of_a_batch_and_of_a_single_sequence():
     assert np.array_equal(got1[(0, 0)][: n - 1], got[(0, 1)])  # the batch member and the single run of the same sequence (32 workgroups each)
     with pytest.raises(ValueError):
         comm.gather_rows(ptr, 1, n, [n + 1])  # a count beyond T
+    # ... a failure on this rank behind communicator creation ABORTS the communicator (the peers' collective fails instead of waiting for
+    # ever); the handle then refuses further calls instead of entering a collective alone
+    with pytest.raises(RuntimeError, match="aborted"):
+        comm.gather_rows(ptr, 1, n, [n_rows])
     comm.close()
     # a second communicator in the same process (a new id)
     c2 = parallel.Comm(parallel.Comm.unique_id(), 1, 0, 0)
