@@ -101,17 +101,21 @@ def test_wrapper_and_runner_take_range_images():
     assert len(w._sigmas) == 5
 
 
-@pytest.mark.parametrize("free", [True, False])
-def test_batch_takes_range_images(free):
+@pytest.mark.parametrize("free,compact", [(True, False), (False, False), (True, True), (False, True)])
+def test_batch_takes_range_images(free, compact):
     """range images + reduce_active_beams through the batched runner (both drivers: the free-running kernel converts four
-    pixels per thread) == the single-sequence runner on the same images"""
+    pixels per thread) == the single-sequence runner on the same images.  compact: ptl_seq_cfg.range_input (round 6) - the sweeps
+    stay u32 range images in HBM, 4 resident bytes per pixel instead of a 12-byte slot; xyz uploads are then refused."""
     S, n = 3, 5
     seqs = [synth.make_sequence(seed=1060 + s, n_scans=n) for s in range(S)]
     H, W = seqs[0].H, seqs[0].W
     alt, az = np.linspace(45.0, -45.0, H), np.zeros(H)
     lut = core.Lut(H, W, alt, az)
-    b = core.BatchRunner(S, n, H * W, 0, with_ekf=False, free_running=free)
+    b = core.BatchRunner(S, n, H * W, 0, with_ekf=False, free_running=free, range_input=compact)
     b.set_lut(lut, active_beams=64)
+    if compact:
+        with pytest.raises(RuntimeError, match="range images"):
+            b.upload_scan(0, 0, seqs[0].scan(0))
     singles = []
     for s, sq in enumerate(seqs):
         r = core.SeqRunner(n, H * W, 0, max_range=70.0, min_range=1.0, with_ekf=False, gn_workgroups=32, gn_lanes_per_point=8, gn_threads=512)
