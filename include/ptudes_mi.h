@@ -265,7 +265,12 @@ typedef struct {
                                  * one: 4 resident bytes per pixel instead of the 12 of a float32 xyz sweep - 240 sequences x 1 000 sweeps of 128x1024 are
                                  * 126 GB instead of 377 GB (the reference walks a recording of any length, data.py:31-77).  ptl_batch_upload_scan is then
                                  * refused.  0 (default): 12-byte slots, either form may be uploaded.  Ignored by ptl_seq_create. */
-    int32_t reserved0;
+    int32_t resident_scans;     /* batches, free-running driver: 0 (default) = every sweep of the run resident (n_scans slots per sequence).  R >= 2 = a RING of
+                                 * R sweep slots per sequence - a recording of any length at the full batch width (the reference walks a file scan by scan,
+                                 * data.py:31-77, cli/ekf_bench.py:493-563): sweeps are uploaded in order, sweep k takes slot k % R once scan k - R is known
+                                 * to be complete (ptl_batch_wait), and uploads of later sweeps may run while a launch works on earlier ones - between
+                                 * ptl_batch_enqueue and ptl_batch_wait, or from another host thread (the only calls of a handle that may overlap).
+                                 * ptl_batch_enqueue refuses scans whose sweeps are not there.  Ignored by ptl_seq_create. */
 } ptl_seq_cfg;
 
 int ptl_seq_create(const ptl_seq_cfg *cfg, ptl_seq **out);
@@ -385,6 +390,8 @@ int ptl_batch_debug_stall_block(ptl_batch *b, int32_t block, int32_t round);
 int ptl_batch_debug_set_map_points_per_thread(ptl_batch *b, int32_t points, int32_t *points_out);
 /* Environment: PTL_TEAM_SYNC=agent when the batch is created keeps the agent-scope release (L2 write-back) at every team
  * barrier of the free-running kernel instead of the XCD-local shortcut (same results; a diagnostic switch).
+ * PTL_SCHED_MARGIN=n (default 1): a team takes the least-advanced free sequence of ANOTHER XCD as soon as it is n scans behind its own
+ * XCD's least-advanced one (all sequences of the device stay within a scan of each other); -1 = only when its own XCD has nothing left.
  *
  * Memory: one sequence of a batch holds 480 B per point of points_per_scan of work buffers (probe and answer rows, ...:
  * 63 MB at 128x1024), its two per-scan voxel tables (64 and 16 slots of 16 B per point: 134 + 34 MB - sparse on purpose,

@@ -58,7 +58,7 @@ class EkfCfg(_Cfg):
 class SeqCfg(_Cfg):
     _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("icp", IcpCfg), ("ekf", EkfCfg), ("n_scans", C.c_int64), ("points_per_scan", C.c_int64),
                 ("n_imu", C.c_int64), ("use_imu_prediction", C.c_int32), ("with_ekf", C.c_int32), ("range_input", C.c_int32),
-                ("reserved0", C.c_int32)]
+                ("resident_scans", C.c_int32)]
 
 
 _vp = C.c_void_p

@@ -393,11 +393,13 @@ class BatchRunner:
 
     def __init__(self, n_sequences, n_scans, points_per_scan, n_imu, *, max_range=70.0, min_range=1.0,
                  use_imu_prediction=False, with_ekf=True, device_id=0, ekf=None, free_running=None, scans_per_launch=0,
-                 team_workgroups=0, range_input=False, **icp_over):
+                 team_workgroups=0, range_input=False, resident_scans=0, **icp_over):
         """range_input: every sweep will arrive as a raw range image (set_lut + upload_range) and stays one in HBM - 4 bytes per pixel
-        resident instead of 12 (include/ptudes_mi.h ptl_seq_cfg.range_input)"""
+        resident instead of 12 (include/ptudes_mi.h ptl_seq_cfg.range_input).  resident_scans: R >= 2 = a ring of R sweep slots per sequence
+        instead of all n_scans - sweeps are uploaded in order, later ones while a launch works on earlier ones (ptl_seq_cfg.resident_scans)"""
         cfg = L.SeqCfg()
         cfg.range_input = int(bool(range_input))
+        cfg.resident_scans = int(resident_scans)
         icp_over.setdefault("gn_lanes_per_point", 8)  # a workgroup walks ~200 points per iteration here: the throughput form
         if icp_over["gn_lanes_per_point"] == 8:
             icp_over.setdefault("gn_threads", 512)

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -1495,6 +1496,13 @@ struct ptl_batch {
     ptl_lut* lut;
     SeqCtx* d_ctx;
     int64_t next_scan, n_out;
+    // Sweep ring (ptl_seq_cfg.resident_scans, round 6): the batch keeps `ring` sweep slots per sequence (ring == n_scans: every sweep resident, as
+    // before); scan k lives in slot k % ring.  ring_lap = the lap d_ctx's scan_base is set for (a launch never crosses a lap: enqueue splits there).
+    // up_hi[s] = sweeps of sequence s uploaded so far (in order); done_scans = scans whose launches are known complete (ptl_batch_wait).  Both are
+    // atomics: uploads may run on another host thread while ptl_batch_wait blocks.
+    int64_t ring, ring_lap;
+    std::atomic<int64_t> up_hi[GN_MAX_SEQ];
+    std::atomic<int64_t> done_scans;
     int64_t imu_pos[GN_MAX_SEQ];
     bool ctx_dirty;
     bool prof;
@@ -1586,14 +1594,16 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
         ptl_icp_cfg ic0 = cfg->icp;
         if (ic0.max_points_per_scan < cfg->points_per_scan) ic0.max_points_per_scan = cfg->points_per_scan;
         const size_t slot0 = cfg->range_input ? 4 : 12;  // resident bytes per pixel of a sweep
-        const size_t per_seq = icp_footprint_bytes(&ic0) + (size_t)cfg->n_scans * (size_t)cfg->points_per_scan * slot0 +
+        if (cfg->resident_scans < 0 || cfg->resident_scans == 1) return set_err(PTL_ERR_ARG, "resident_scans must be 0 (every sweep resident) or >= 2 sweep slots per sequence");
+        const size_t res0 = (cfg->resident_scans > 0 && cfg->resident_scans < cfg->n_scans) ? (size_t)cfg->resident_scans : (size_t)cfg->n_scans;
+        const size_t per_seq = icp_footprint_bytes(&ic0) + res0 * (size_t)cfg->points_per_scan * slot0 +
                                (size_t)(cfg->n_imu > 0 ? cfg->n_imu : 1) * 56 + (size_t)cfg->n_scans * (128 + 8 + 64 + 4) + (64u << 10);
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && per_seq * (size_t)n_sequences > free_b)
             return set_err(PTL_ERR_CAPACITY, "batch of %d sequences needs %.1f GB of device memory (%.0f MB per sequence: %.0f MB of work buffers, map table "
                            "and block pool, %.0f MB of sweeps), %.1f GB are free of %.1f GB: fewer sequences, fewer resident sweeps or a smaller map_block_capacity",
                            n_sequences, per_seq * (double)n_sequences / 1e9, per_seq / 1e6, icp_footprint_bytes(&ic0) / 1e6,
-                           (double)cfg->n_scans * cfg->points_per_scan * slot0 / 1e6, free_b / 1e9, total_b / 1e9);
+                           (double)res0 * cfg->points_per_scan * slot0 / 1e6, free_b / 1e9, total_b / 1e9);
     }
     ptl_batch* b = new ptl_batch();
     b->cfg = *cfg;
@@ -1612,6 +1622,10 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     b->team_wgs = 0; b->seq_run_checked = false;
     b->scans_per_launch = 256;
     b->next_scan = 0; b->n_out = 0; b->ctx_dirty = true; b->prof = false; b->ev_used = 0; b->gn_ms = 0; b->gn_launches = 0;
+    b->ring = (cfg->resident_scans > 0 && cfg->resident_scans < cfg->n_scans) ? cfg->resident_scans : cfg->n_scans;
+    b->ring_lap = 0; b->done_scans = 0;
+    for (int s = 0; s < GN_MAX_SEQ; ++s) b->up_hi[s] = 0;
+    if (b->ring < cfg->n_scans && !b->free_running) { delete b; return set_err(PTL_ERR_ARG, "resident_scans (the sweep ring) is served by the free-running driver (gn_lanes_per_point = 8)"); }
     for (int s = 0; s < GN_MAX_SEQ; ++s) {
         b->icp[s] = nullptr; b->ekf[s] = nullptr; b->d_scans[s] = nullptr; b->d_imu[s] = nullptr; b->d_imu_end[s] = nullptr;
         b->d_res_poses[s] = nullptr; b->d_res_t[s] = nullptr; b->d_rows[s] = nullptr; b->imu_pos[s] = 0;
@@ -1632,7 +1646,7 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
         if (rc == PTL_OK) rc = ekf_create_impl(&ec, b->stream, &b->ekf[s]);
         while (rc == PTL_OK && b->icp[s]->traj_cap < cfg->n_scans) rc = icp_grow_traj(b->icp[s]);
         if (rc == PTL_OK &&
-            (hipMalloc((void**)&b->d_scans[s], (size_t)cfg->n_scans * cfg->points_per_scan * (cfg->range_input ? 4 : 12)) != hipSuccess ||
+            (hipMalloc((void**)&b->d_scans[s], (size_t)b->ring * cfg->points_per_scan * (cfg->range_input ? 4 : 12)) != hipSuccess ||
              dalloc(&b->d_imu[s], nim * 7) != hipSuccess || dalloc(&b->d_res_poses[s], (size_t)cfg->n_scans * 16) != hipSuccess ||
              dalloc(&b->d_res_t[s], (size_t)cfg->n_scans) != hipSuccess || dalloc(&b->d_rows[s], (size_t)cfg->n_scans * 8) != hipSuccess ||
              dalloc(&b->d_imu_end[s], (size_t)cfg->n_scans) != hipSuccess))
@@ -1650,20 +1664,38 @@ extern "C" int ptl_batch_create(const ptl_seq_cfg* cfg, int32_t n_sequences, ptl
     *out = b;
     return PTL_OK;
 }
+// Sweep ring (resident_scans < n_scans): sweeps arrive in order, and sweep k may take its slot (k % ring) only when the scan that used the slot
+// before - k - ring - is known to be complete (ptl_batch_wait has returned for it).  Uploads of later sweeps may run while a launch works on
+// earlier ones - from the thread that enqueued it, between ptl_batch_enqueue and ptl_batch_wait, or from another host thread.
+static int batch_ring_slot_free(ptl_batch* b, int32_t s, int64_t k) {
+    if (b->ring >= b->cfg.n_scans) return PTL_OK;
+    const int64_t hi = b->up_hi[s], done = b->done_scans;
+    if (k != hi) return set_err(PTL_ERR_STATE, "sweep ring (resident_scans = %lld): sweeps are uploaded in order - sequence %d expects sweep %lld, got %lld",
+                                (long long)b->ring, s, (long long)hi, (long long)k);
+    if (k >= done + b->ring) return set_err(PTL_ERR_STATE, "sweep ring (resident_scans = %lld): slot of sweep %lld still holds sweep %lld, which is not known to be done "
+                                            "(%lld scans complete): ptl_batch_wait first", (long long)b->ring, (long long)k, (long long)(k - b->ring), (long long)done);
+    return PTL_OK;
+}
 extern "C" int ptl_batch_upload_scan(ptl_batch* b, int32_t s, int64_t k, const float* xyz) {
     if (!b || !xyz || s < 0 || s >= b->S || k < 0 || k >= b->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
     if (b->is_range || b->cfg.range_input) return set_err(PTL_ERR_STATE, "this batch holds range images");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    int rc = batch_ring_slot_free(b, s, k);
+    if (rc) return rc;
     const size_t bytes = (size_t)b->cfg.points_per_scan * 12;
-    HIPCHK(hipMemcpy((char*)b->d_scans[s] + (size_t)k * bytes, xyz, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy((char*)b->d_scans[s] + (size_t)(k % b->ring) * bytes, xyz, bytes, hipMemcpyHostToDevice));
+    if (b->ring < b->cfg.n_scans) b->up_hi[s] = k + 1;
     return PTL_OK;
 }
 extern "C" int ptl_batch_upload_range(ptl_batch* b, int32_t s, int64_t k, const uint32_t* range_mm) {
     if (!b || !range_mm || s < 0 || s >= b->S || k < 0 || k >= b->cfg.n_scans) return set_err(PTL_ERR_ARG, "bad argument");
     if (!b->lut) return set_err(PTL_ERR_STATE, "set the LUT first (ptl_batch_set_lut)");
     HIPCHK(hipSetDevice(b->cfg.icp.device_id));
+    int rc = batch_ring_slot_free(b, s, k);
+    if (rc) return rc;
     const size_t slot = (size_t)b->cfg.points_per_scan * (b->cfg.range_input ? 4 : 12);
-    HIPCHK(hipMemcpy((char*)b->d_scans[s] + (size_t)k * slot, range_mm, (size_t)b->cfg.points_per_scan * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy((char*)b->d_scans[s] + (size_t)(k % b->ring) * slot, range_mm, (size_t)b->cfg.points_per_scan * 4, hipMemcpyHostToDevice));
+    if (b->ring < b->cfg.n_scans) b->up_hi[s] = k + 1;
     return PTL_OK;
 }
 extern "C" int ptl_batch_set_lut(ptl_batch* b, ptl_lut* lut, int32_t active_beams) {
@@ -1703,8 +1735,9 @@ static int batch_push_ctx(ptl_batch* b) {
         c.ext_guess = (with_ekf && b->cfg.use_imu_prediction) ? (const double*)((char*)b->ekf[s]->st + offsetof(EkfState, pose)) : nullptr;
         if (b->is_range) { c.lut_dir = b->lut->dir; c.lut_off = b->lut->off; c.row_mask = b->icp[s]->d_row_mask; }
         h[s].c = c;
-        h[s].scan_base = b->d_scans[s];
         h[s].scan_stride_floats = (long long)b->cfg.points_per_scan * (b->cfg.range_input ? 1 : 3);
+        // (sweep ring: scan k of lap L = k / ring sits in slot k - L ring; the kernel addresses scan_base + k stride, so the base moves back a ring per lap)
+        h[s].scan_base = b->d_scans[s] - (long long)b->ring_lap * (long long)b->ring * h[s].scan_stride_floats;
         h[s].input_is_range = b->is_range;
         h[s].n_scans = (int)b->cfg.n_scans;
         h[s].fd_buf[0] = b->icp[s]->fd_buf[0]; h[s].fd_buf[1] = b->icp[s]->fd_buf[1];
@@ -1726,11 +1759,19 @@ static int batch_reset(ptl_batch* b) {
     }
     b->next_scan = 0;
     b->n_out = 0;
+    b->done_scans = 0;
+    if (b->ring_lap != 0) { b->ring_lap = 0; b->ctx_dirty = true; }
+    if (b->ring < b->cfg.n_scans)  // a ring that has been lapped no longer holds the run's first sweeps: they are uploaded again; else what is there stays
+        for (int s = 0; s < b->S; ++s) if (b->up_hi[s] > b->ring) b->up_hi[s] = 0;
     HIPCHK(hipMemsetAsync(b->d_status, 0, sizeof(unsigned), b->stream));
     HIPCHK(hipStreamSynchronize(b->side));
     HIPCHK(hipStreamSynchronize(b->stream));
     b->ev_side_valid = false;
     return PTL_OK;
+}
+__global__ void k_ring_rebase(SeqCtx* a, int S, long long delta_floats) {
+    const int s = (int)threadIdx.x;
+    if (s < S) a[s].scan_base += delta_floats;
 }
 // free-running driver: the scans [next_scan, next_scan + n) of every sequence in launches of up to scans_per_launch scans
 static int batch_enqueue_free(ptl_batch* b, int64_t n) {
@@ -1740,8 +1781,21 @@ static int batch_enqueue_free(ptl_batch* b, int64_t n) {
     hipStream_t st = b->stream;
     const int64_t end = b->next_scan + n;
     if (!b->seq_run_checked) { int rc = batch_check_seq_run(b); if (rc) return rc; b->seq_run_checked = true; }
+    if (b->ring < b->cfg.n_scans)
+        for (int s = 0; s < S; ++s)
+            if (b->up_hi[s] < end) return set_err(PTL_ERR_STATE, "sweep ring: sequence %d has sweeps [0, %lld) uploaded, the launch needs [%lld, %lld)", s, (long long)b->up_hi[s].load(),
+                                                  (long long)b->next_scan, (long long)end);
     while (b->next_scan < end) {
-        const int64_t k0 = b->next_scan, k1 = (end - k0 > b->scans_per_launch) ? k0 + b->scans_per_launch : end;
+        const int64_t k0 = b->next_scan;
+        int64_t k1 = (end - k0 > b->scans_per_launch) ? k0 + b->scans_per_launch : end;
+        if (b->ring < b->cfg.n_scans) {  // a launch stays inside one lap of the ring (its sweeps are contiguous there)
+            const int64_t lap = k0 / b->ring, lap_end = (lap + 1) * b->ring;
+            if (k1 > lap_end) k1 = lap_end;
+            if (lap != b->ring_lap) {
+                k_ring_rebase<<<1, GN_MAX_SEQ, 0, st>>>(b->d_ctx, S, -(long long)(lap - b->ring_lap) * (long long)b->ring * (long long)b->cfg.points_per_scan * (b->cfg.range_input ? 1 : 3));
+                b->ring_lap = lap;
+            }
+        }
         if (with_ekf) {  // IMU samples before the first scan of the launch that the filter has not seen (a run's first scan)
             for (int s0 = 0; s0 < S; s0 += EKF_MAX_SEQ) {  // (the argument block holds EKF_MAX_SEQ sequences)
                 EkfBatchArgs ea;
@@ -1807,6 +1861,7 @@ extern "C" int ptl_batch_set_driver(ptl_batch* b, int32_t free_running, int64_t 
     if (scans_per_launch > 4096) return set_err(PTL_ERR_ARG, "scans_per_launch: at most 4096 (every wait inside the persistent kernel has a poll budget worth seconds, and a launch must stay well below it)");
     if (scans_per_launch > 0) b->scans_per_launch = scans_per_launch;
     if (!free_running && b->cfg.icp.map_small_blocks > 0) return set_err(PTL_ERR_ARG, "map_small_blocks (two block classes) needs the free-running driver");
+    if (!free_running && b->ring < b->cfg.n_scans) return set_err(PTL_ERR_ARG, "resident_scans (the sweep ring) needs the free-running driver");
     const bool was = b->free_running;
     b->free_running = free_running != 0;
     b->seq_run_checked = false;
@@ -1950,6 +2005,7 @@ extern "C" int ptl_batch_wait(ptl_batch* b) {
     k_finish_all<<<(b->S + 63) / 64, 64, 0, b->stream>>>(b->d_ctx, b->S, b->d_status, b->d_flags);
     HIPCHK(hipMemcpyAsync(b->h_flags, b->d_flags, (size_t)(GN_MAX_SEQ + 1) * sizeof(int), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    b->done_scans = b->next_scan;  // (every launch enqueued so far is through: their sweep slots may be overwritten)
     const int* flags = b->h_flags;
     const unsigned status = (unsigned)b->h_flags[GN_MAX_SEQ];
     for (size_t i = 0; i + 1 < b->ev_used; i += 2) {

@@ -557,3 +557,62 @@ def _oracle_run_cfg(sq, n, max_range, voxel_size):
         res.append(ekf.pose_mat())
     return np.array(kiss), np.array(res), icp.stats
 
+
+
+def test_sweep_ring_streams_a_long_run_and_equals_the_resident_run():
+    """ptl_seq_cfg.resident_scans (round 6): a ring of R sweep slots per sequence instead of every sweep of the run - a recording of any length at
+    the full batch width (the reference walks a file scan by scan, data.py:31-77, cli/ekf_bench.py:493-563).  22 sweeps of 9 sequences through a ring
+    of 8 in launches of 4, the sweeps of launch n + 1 uploaded WHILE launch n runs (between enqueue and wait): every pose, filter state and statistic
+    bit-equal to the fully resident batch; the guards (order, a slot still in use, scans without their sweeps, the lockstep driver) refuse."""
+    import pytest
+    S, n, R, L = 9, 22, 8, 4
+    seqs = [synth.make_sequence(seed=2300 + s, n_scans=n) for s in range(S)]
+    pps = seqs[0].H * seqs[0].W
+    n_imu = seqs[0].imu_range_for_scan(n - 1)[1]
+    sweeps = [[sq.scan(k) for k in range(n)] for sq in seqs]
+    kw = dict(use_imu_prediction=True, with_ekf=True, scans_per_launch=L)
+
+    def imu(b):
+        for s, sq in enumerate(seqs):
+            b.upload_imu(s, sq.imu[:n_imu], [sq.imu_range_for_scan(k)[1] for k in range(n)])
+
+    full = core.BatchRunner(S, n, pps, n_imu, **kw)
+    for s in range(S):
+        for k in range(n):
+            full.upload_scan(s, k, sweeps[s][k])
+    imu(full)
+    full.run()
+    want = [full.results(s) for s in range(S)]
+    full.close()
+
+    ring = core.BatchRunner(S, n, pps, n_imu, resident_scans=R, **kw)
+    imu(ring)
+
+    def feed(k0, k1):
+        for s in range(S):
+            for k in range(k0, min(k1, n)):
+                ring.upload_scan(s, k, sweeps[s][k])
+
+    with pytest.raises(RuntimeError, match="uploaded"):
+        ring.run(L)  # nothing there yet
+    with pytest.raises(RuntimeError, match="in order"):
+        ring.upload_scan(0, 1, sweeps[0][1])
+    feed(0, R)  # the ring is full ...
+    with pytest.raises(RuntimeError, match="still holds"):
+        ring.upload_scan(0, R, sweeps[0][R])  # ... and its first slot is not free before scan 0 is known to be done
+    ring.run(L)  # cold start + scans [0, L), waits
+    done = L
+    while done < n:
+        m = min(L, n - done)
+        ring.enqueue(m)           # scans [done, done + m) on their way ...
+        feed(done + R - L, done + R)  # ... while the slots of the scans BEFORE them (known to be done) take the next sweeps
+        ring.wait()
+        done += m
+    assert ring.status() == 0
+    for s in range(S):
+        got = ring.results(s)
+        assert np.array_equal(got["kiss_poses"], want[s]["kiss_poses"]) and np.array_equal(got["res_poses"], want[s]["res_poses"]), s
+        assert np.array_equal(got["res_t"], want[s]["res_t"]) and got["stats"] == want[s]["stats"], s
+    ring.close()
+    with pytest.raises(ValueError, match="free-running"):
+        core.BatchRunner(4, n, pps, n_imu, resident_scans=R, gn_lanes_per_point=32, **kw)
