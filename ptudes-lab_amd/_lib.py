@@ -127,6 +127,8 @@ PROTOTYPES = {
     "ptl_seq_wait": (C.c_int, [_vp]),
     "ptl_seq_copy_traj": (C.c_int, [_vp, _vp, C.c_int64, c_i64_p]),
     "ptl_device_sync": (C.c_int, [C.c_int]),
+    "ptl_host_pin": (C.c_int, [C.c_int, _vp, C.c_uint64]),
+    "ptl_host_unpin": (C.c_int, [_vp]),
     "ptl_seq_results": (C.c_int, [_vp, c_d_p, c_d_p, c_d_p, C.POINTER(IcpStats), C.c_int64, c_i64_p]),
     "ptl_seq_traj_device": (C.c_int, [_vp, _vpp, c_i64_p]),
     "ptl_seq_icp": (C.c_int, [_vp, _vpp]),

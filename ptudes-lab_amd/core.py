@@ -296,6 +296,17 @@ def device_sync(device_id=0):
     L.check(L.lib().ptl_device_sync(device_id))
 
 
+def host_pin(array, device_id=0):
+    """page-lock a C-contiguous numpy array the sweeps will be uploaded from (include/ptudes_mi.h ptl_host_pin); keep the array alive until host_unpin"""
+    if not array.flags["C_CONTIGUOUS"]:
+        raise ValueError("host_pin needs a C-contiguous array")
+    L.check(L.lib().ptl_host_pin(device_id, C.c_void_p(array.ctypes.data), array.nbytes))
+
+
+def host_unpin(array):
+    L.check(L.lib().ptl_host_unpin(C.c_void_p(array.ctypes.data)))
+
+
 class SeqRunner:
     """Whole sequence in HBM, no host round trip per scan."""
 

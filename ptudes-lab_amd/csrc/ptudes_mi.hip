@@ -36,6 +36,18 @@ extern "C" int ptl_device_count(void) {
     return n;
 }
 extern "C" int ptl_backend(void) { return ptl_device_count() > 0 ? 1 : 0; }
+extern "C" int ptl_host_pin(int device_id, void* host_ptr, uint64_t bytes) {
+    if (!host_ptr || bytes == 0) return set_err(PTL_ERR_ARG, "null argument");
+    if (ptl_device_count() <= device_id || device_id < 0) return set_err(PTL_ERR_HIP, "no HIP device %d", device_id);
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipHostRegister(host_ptr, (size_t)bytes, hipHostRegisterDefault));
+    return PTL_OK;
+}
+extern "C" int ptl_host_unpin(void* host_ptr) {
+    if (!host_ptr) return set_err(PTL_ERR_ARG, "null argument");
+    HIPCHK(hipHostUnregister(host_ptr));
+    return PTL_OK;
+}
 
 // ---- ABI guard (include/ptudes_mi.h): a configuration struct says how big its writer thinks it is and which ABI it was written against
 extern "C" int ptl_abi_version(void) { return PTL_ABI_VERSION; }

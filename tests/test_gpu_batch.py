@@ -616,3 +616,31 @@ def test_sweep_ring_streams_a_long_run_and_equals_the_resident_run():
     ring.close()
     with pytest.raises(ValueError, match="free-running"):
         core.BatchRunner(4, n, pps, n_imu, resident_scans=R, gn_lanes_per_point=32, **kw)
+
+
+def test_uploads_from_a_page_locked_host_buffer_give_the_same_run():
+    """ptl_host_pin / ptl_host_unpin: the caller's recording buffer page-locked once, the (synchronous) uploads then go by DMA straight from it.
+    Same bytes on the device: the run equals the one fed from pageable memory."""
+    S, n = 3, 4
+    seqs = [synth.make_sequence(seed=2400 + s, n_scans=n) for s in range(S)]
+    pps = seqs[0].H * seqs[0].W
+    buf = np.ascontiguousarray(np.stack([np.stack([sq.scan(k) for k in range(n)]) for sq in seqs]))  # (S, n, pps, 3) f32
+    outs = []
+    for pinned in (False, True):
+        if pinned:
+            core.host_pin(buf)
+        b = core.BatchRunner(S, n, pps, 0, with_ekf=False)
+        for s in range(S):
+            for k in range(n):
+                b.upload_scan(s, k, buf[s, k])
+            b.upload_imu(s, np.zeros((0, 7)), [0] * n)
+        b.run()
+        outs.append([b.results(s) for s in range(S)])
+        b.close()
+        if pinned:
+            core.host_unpin(buf)
+    for s in range(S):
+        assert np.array_equal(outs[0][s]["kiss_poses"], outs[1][s]["kiss_poses"]) and outs[0][s]["stats"] == outs[1][s]["stats"]
+    import pytest
+    with pytest.raises((RuntimeError, ValueError)):
+        core.host_unpin(buf)  # (not registered any more)

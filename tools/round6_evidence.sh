@@ -10,8 +10,9 @@
 # B5: config 5's line, kernel stats, dispatches, HBM counters, the same command with that pass in place, stage clocks
 # J:  the jitter workload (the stage-bound regime): line, kernel stats, HBM counters
 # X:  --icp-only, --range-input (driver's form), --verify-all, the per-call loop
+# S:  tools/stream_feed.py: the sweep ring, resident against streamed
 R="${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it)}"
-PART="${1:?T, C5, D, B5, J or X}"; TAG="${2:-r06_a}"
+PART="${1:?T, C5, D, B5, J, X or S}"; TAG="${2:-r06_a}"
 O="$R/gpurun_out"; mkdir -p "$O"; V="$R/tools/variants"
 cd "$R"
 C5="--seqs-per-gpu 160 --team-wgs 4 --rows 64 --cols 2048 --max-range 100 --voxel-size 0.1 --steps 40 --warmup 20 --map-blocks 600000 --map-small-blocks 2200000 --map-table 33554432 --workload-name config5 --no-single-sequence"
@@ -47,6 +48,11 @@ X)
   python3 bench.py --steps 20 --warmup 5 --range-input --no-single-sequence --cpu-budget 10 > "$O/${TAG}_bench_range_input.json" 2> "$O/${TAG}_bench_range_input.err"
   python3 bench.py --steps 20 --warmup 5 --verify-all --repeats 1 --no-cpu-baseline --no-single-sequence > "$O/${TAG}_bench_verify_all.json" 2> "$O/${TAG}_bench_verify_all.err"
   python3 tools/percall.py > "$O/${TAG}_percall.txt" 2>&1; tail -4 "$O/${TAG}_percall.txt" | cut -c1-160
+  ;;
+S)
+  # a recording of any length at the full batch width: the sweep ring fed while the kernel runs (pageable, then page-locked host buffer)
+  PTL_STREAM_PIN=0 timeout 1500 python3 tools/stream_feed.py 240 120 32 16 > "$O/${TAG}_stream_feed_pageable.txt" 2>&1; cut -c1-300 "$O/${TAG}_stream_feed_pageable.txt"
+  PTL_STREAM_PIN=1 timeout 1500 python3 tools/stream_feed.py 240 120 32 16 > "$O/${TAG}_stream_feed_pinned.txt" 2>&1; cut -c1-300 "$O/${TAG}_stream_feed_pinned.txt"
   ;;
 B5)
   bash tools/profile_round.sh "${TAG}_config5" $C5 > "$O/${TAG}_config5_prof.txt" 2>&1; tail -2 "$O/${TAG}_config5_prof.txt" | cut -c1-300

@@ -37,6 +37,11 @@ for s, sq in enumerate(seqs):
         img[s, k] = np.round(np.sqrt((x * x).sum(axis=1)) * 1000.0).astype(np.uint32)
 n_imu = seqs[0].imu_range_for_scan(T - 1)[1]
 print("rendered %d x %d range images (%.1f GB of host memory) in %.0f s" % (S, T, img.nbytes / 1e9, time.perf_counter() - t0), flush=True)
+PIN = os.environ.get("PTL_STREAM_PIN", "1") != "0"
+if PIN:  # the recording's buffer page-locked once: the uploads go by DMA straight from it (PTL_STREAM_PIN=0: pageable, through the runtime's staging buffer)
+    t0 = time.perf_counter()
+    core.host_pin(img)
+    print("host buffer page-locked in %.1f s" % (time.perf_counter() - t0), flush=True)
 kw = dict(use_imu_prediction=True, with_ekf=True, scans_per_launch=LAUNCH, range_input=True, scan_cols=W, map_block_capacity=65536)
 
 
@@ -102,3 +107,5 @@ print("streamed (ring of %d, launches of %d): %d scans in %.3f s = %.0f scans/s;
       "(%.1f GB/s); sequences that differ from the resident run: %s" %
       (RING, LAUNCH, (T - LAUNCH) * S, dt_ring, (T - LAUNCH) * S / dt_ring, up_bytes / 1e9, t_feed, up_bytes / max(t_feed, 1e-9) / 1e9, bad or "none"), flush=True)
 print("resident memory for sweeps: %.1f GB (all %d) against %.1f GB (ring)" % (S * T * H * W * 4 / 1e9, T, S * RING * H * W * 4 / 1e9))
+if PIN:
+    core.host_unpin(img)
