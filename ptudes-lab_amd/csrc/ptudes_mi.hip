@@ -23,10 +23,12 @@ static int set_err(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+// (a failed runtime call also leaves its code in the runtime's sticky "last error": it is cleared here, or a LATER, unrelated
+// HIPCHK(hipGetLastError()) - behind a kernel launch of another handle - would report this call's failure as its own)
 #define HIPCHK(x)                                                                                    \
     do {                                                                                             \
         hipError_t e_ = (x);                                                                         \
-        if (e_ != hipSuccess) return set_err(PTL_ERR_HIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+        if (e_ != hipSuccess) { (void)hipGetLastError(); return set_err(PTL_ERR_HIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } \
     } while (0)
 
 extern "C" const char* ptl_last_error(void) { return g_err; }

@@ -644,3 +644,6 @@ def test_uploads_from_a_page_locked_host_buffer_give_the_same_run():
     import pytest
     with pytest.raises((RuntimeError, ValueError)):
         core.host_unpin(buf)  # (not registered any more)
+    # ... and that failure must not stay behind in the runtime's sticky "last error": the next, unrelated call that checks it after a kernel
+    # launch - a handle's reset here - would report it as its own (it did: round 6, found by the suite's next test)
+    core.SeqRunner(2, pps, 0, with_ekf=False).close()
